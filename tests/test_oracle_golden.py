@@ -1,0 +1,157 @@
+"""Pins oracle/sdt_oracle.py against the fixtures produced by the reference's own modules
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdt_oracle as O
+
+
+def sl(t, n=64):
+    f = t.detach().reshape(-1).double()
+    step = max(1, f.numel() // n)
+    return np.concatenate([f[::step][:n].numpy(), [f.sum().item(), f.abs().sum().item()]])
+
+
+def close(a, b, rtol=2e-5, atol=2e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"max err {err.max():.3e} (tol {tol.flat[err.argmax()]:.3e})"
+
+
+@pytest.fixture(scope="module")
+def batch2():
+    return O.make_batch(2, 16, step=0, seed=1)
+
+
+def test_mel_restatement_matches_float64_dft(batch2):
+    # torchaudio 0.7.0 is unavailable: mel parity is UNPINNED; this checks the restatement's STFT
+    # against an independent float64 direct DFT and the fixture for drift.
+    a = batch2["audio"]
+    p32 = O.stft_power(a, O.mel_window())
+    p64 = O.stft_power_dft64(a)
+    assert p32.shape == (2, 257, 427)
+    rel = (p32.double() - p64).abs().max() / p64.abs().max()
+    assert rel < 1e-5, rel
+    fb = O.mel_filterbank()
+    assert fb.shape == (257, 80) and float(fb.min()) >= 0 and (fb.sum(0) > 0).all()
+
+
+def test_mel_fixture(batch2, golden_modules):
+    close(O.mel_spectrogram(batch2["audio"])[:1].numpy(), golden_modules["mel"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("norm", ["IN", "BN"])
+@pytest.mark.parametrize("dim", [None, 32])
+def test_generator_forward(batch2, golden_modules, norm, dim):
+    cfg = O.default_cfg(**{"VOICE2POSE.GENERATOR.NORM": norm, "VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION": dim})
+    st = {}
+    O.fill_generator(st, np.random.Generator(np.random.PCG64(3)), "netG", cfg)
+    mel = O.mel_spectrogram(batch2["audio"])
+    code = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((2, 32)).astype(np.float32))
+    out = O.generator(st, "netG", mel, 64, code if dim else None, cfg, True)
+    tag = f"G_{norm}_{dim}"
+    close(out.numpy(), golden_modules[tag], 1e-4, 1e-5)
+    if norm == "BN":
+        close(st["netG.audio_encoder.specgram_encoder_2d.0.0.norm.running_mean"].numpy(), golden_modules[tag + "/rm0"])
+        close(st["netG.decoder.3.norm.running_var"].numpy(), golden_modules[tag + "/rv_last"])
+        assert int(st["netG.unet.e3.norm.num_batches_tracked"]) == 1
+    if norm == "IN" and dim == 32:
+        out = O.generator(st, "netG", mel[:, :, :300], 40, code, cfg, False)
+        close(out.numpy(), golden_modules[tag + "/T40"], 1e-4, 1e-5)
+
+
+def test_discriminator(batch2, golden_modules):
+    motion = batch2["poses"][:, 1:] - batch2["poses"][:, :-1]
+    for leaky, tag in ((True, "D_leaky"), (False, "D_relu")):
+        cfg = O.cfg_named("voice2pose_s2g") if leaky else O.default_cfg()
+        st = {}
+        O.fill_discriminator(st, np.random.Generator(np.random.PCG64(4)), "netD_pose", O.cfg_named("voice2pose_s2g"))
+        close(O.discriminator(st, "netD_pose", motion, cfg, True).numpy(), golden_modules[tag], 1e-4, 1e-5)
+
+
+def test_pose_encoder_and_autoencoder(batch2, golden_modules):
+    cfg = O.cfg_named("pose2pose")
+    st = {}
+    O.fill_pose_encoder(st, np.random.Generator(np.random.PCG64(5)), "enc", cfg)
+    mu, lv = O.pose_seq_encoder(st, "enc", batch2["poses"], cfg, True)
+    close(mu.numpy(), golden_modules["PoseEnc/mu"], 1e-4, 1e-5)
+    close(lv.numpy(), golden_modules["PoseEnc/logvar"], 1e-4, 1e-5)
+    mu, _ = O.pose_seq_encoder(st, "enc", batch2["poses"], cfg, False)
+    close(mu.numpy(), golden_modules["PoseEnc_eval/mu"], 1e-4, 1e-5)
+    st = O.make_pose2pose_state(cfg, 16, seed=6)
+    eps = torch.from_numpy(np.random.Generator(np.random.PCG64(2)).standard_normal((2, 32)).astype(np.float32))
+    out, mu, lv = O.autoencoder(st, "ae", batch2["poses"], 64, cfg, True, eps)
+    close(out.numpy(), golden_modules["AE/out"], 1e-4, 1e-5)
+    close(mu.numpy(), golden_modules["AE/mu"], 1e-4, 1e-5)
+    close(lv.numpy(), golden_modules["AE/logvar"], 1e-4, 1e-5)
+
+
+def test_dataset_transforms(batch2, golden_modules):
+    fin = O.get_final_results(batch2["poses"].clone(), batch2["speaker_stat"])
+    assert fin.dtype == torch.float64
+    close(fin.numpy(), golden_modules["final_results"], 1e-12, 1e-12)
+    import os
+    from conftest import GOLDEN
+    sp = np.load(os.path.join(GOLDEN, "speaker_stat_oliver.npz"))
+    parted = {"mean": torch.tensor(sp["parted_mean"], dtype=torch.float32), "std": torch.tensor(sp["parted_std"], dtype=torch.float32)}
+    glob = {"mean": torch.tensor(sp["global_mean"], dtype=torch.float32), "std": torch.tensor(sp["global_std"], dtype=torch.float32)}
+    out = O.transform_normalized_parted2global(batch2["poses"].clone(), parted, glob)
+    close(out.numpy(), golden_modules["p2g_oliver"], 1e-6, 1e-6)
+
+
+def _stats_s2g():
+    import os
+    from conftest import GOLDEN
+    sp = np.load(os.path.join(GOLDEN, "speaker_stat_oliver.npz"))
+    parted = {"mean": torch.tensor(sp["parted_mean"], dtype=torch.float32), "std": torch.tensor(sp["parted_std"], dtype=torch.float32)}
+    glob = {"mean": torch.tensor(sp["global_mean"], dtype=torch.float32), "std": torch.tensor(sp["global_std"], dtype=torch.float32)}
+    return parted, glob
+
+
+@pytest.mark.parametrize("name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_bp_zero", 0.0), ("voice2pose_s2g", 0.0)])
+def test_train_trajectory(golden_traj, name, code_std):
+    torch.manual_seed(0)
+    cfg_name = name.replace("_zero", "")
+    cfg = O.cfg_named(cfg_name)
+    st = O.make_voice2pose_state(cfg, 16, seed=0, code_std=code_std)
+    eng = O.OracleVoice2Pose(cfg, st)
+    stats = _stats_s2g() if cfg_name == "voice2pose_s2g" else None
+    g = {k[len(name) + 1:]: v for k, v in golden_traj.items() if k.startswith(name + "/")}
+    for step in range(3):
+        batch = O.make_batch(4, 16, step=step, seed=1)
+        if step == 0:
+            # capture grads of the G backward before the optimiser consumes them
+            losses, results = O.voice2pose_forward(st, batch, cfg, True, stats)
+            # undo the BN running-stat side effects of this probing forward by rebuilding the engine
+            st = O.make_voice2pose_state(cfg, 16, seed=0, code_std=code_std)
+            eng = O.OracleVoice2Pose(cfg, st)
+        losses, results = eng.train_step(batch, stats)
+        want = {k.split("/")[-1] for k in g if k.startswith(f"s{step}/loss/")}
+        assert want == set(losses) - {"L2_dist", "lip_sync_error_n"}, (want, set(losses))
+        for k in want:
+            close(losses[k].item(), g[f"s{step}/loss/{k}"], 2e-5, 1e-6)
+        for k in ("L2_dist", "lip_sync_error_n"):
+            close(losses[k].item(), g[f"s{step}/metric/{k}"], 2e-5, 1e-6)
+        if step == 0:
+            close(results["poses_pred_batch"].detach().numpy(), g["s0/pred"], 1e-4, 1e-5)
+        for k in ("mu_pred", "mu_gt", "logvar_pred", "logvar_gt"):
+            close(results[k].numpy(), g[f"s{step}/{k}"], 2e-3, 2e-4)
+    # weights after 3 Adam steps (dense Adam on the code table included), BN buffers, counters
+    for k, v in st.items():
+        ref = g[f"final/{k}"]
+        if v.is_floating_point():
+            close(sl(v), ref, 2e-3, 2e-5)
+        else:
+            assert int(v) == int(ref), k
+    if "clips_code" in st:
+        close(st["clips_code"][:12].detach().numpy(), g["final_full/clips_code_rows"], 2e-3, 2e-6)
+
+
+def test_kl_skip_on_zero_codes(golden_traj):
+    # all-zero code table -> batch variance == 0 -> the KL term is skipped on step 0 (voice2pose.py:154)
+    assert "voice2pose_sdt_bp_zero/s0/loss/G_clipcode_kl_loss" not in golden_traj
+    assert "voice2pose_sdt_bp_zero/s1/loss/G_clipcode_kl_loss" not in golden_traj
+    assert "voice2pose_sdt_bp/s0/loss/G_clipcode_kl_loss" in golden_traj
