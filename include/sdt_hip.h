@@ -1,0 +1,160 @@
+/*
+ * sdt_hip.h -- C ABI of libsdt_hip.so: the MI355X (gfx950) kernels behind the SDT voice2pose
+ * training hot path.  Plain pointers + sizes + a hipStream_t (passed as void*); no torch types.
+ *
+ * All activation tensors are CHANNELS-LAST fp32 in HBM:
+ *     2-D stage  (B, H, W, C)      1-D stage (B, T, C)  == (B, 1, T, C)
+ * Conv weights are (Cout, taps, Cin) with Cin contiguous (taps = kh*kw, row-major).  The host
+ * mirror keeps the reference's logical shapes (Cout,Cin,kh,kw)/(Cout,Cin,k) as strided views of
+ * that storage, so reference checkpoints load unchanged.
+ *
+ * Every entry point: allocates nothing, launches on the caller's stream, returns 0 on success or
+ * a negative sdt_status; sdt_last_error() gives the message.  Each comment names the reference
+ * operator (file:line in ShenhanQian/SpeechDrivesTemplates) the entry point replaces.
+ */
+#ifndef SDT_HIP_H
+#define SDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDT_MAX_TAPS 20
+
+enum sdt_status { SDT_OK = 0, SDT_ERR_ARG = -1, SDT_ERR_LAUNCH = -2, SDT_ERR_UNSUPPORTED = -3 };
+
+const char* sdt_last_error(void);
+int sdt_abi_version(void);
+
+/*
+ * Tap-table convolution geometry (implicit GEMM):
+ *   Y[b, oy*osy+ooy, ox*osx+oox, n] = bias[n] +
+ *       sum_{t<ntaps} sum_{c<Cin} X[b, oy*sy+dy[t], ox*sx+dx[t], c] * W[n, wt[t], c]
+ * for (b,oy,ox) in B x Ho x Wo; out-of-range X reads are 0.  X is (B,Hi,Wi,Cin), Y is
+ * (B,Hy,Wy,Cout), W is (Cout,Tw,Cin).  One geometry describes a forward conv (any stride), and --
+ * with transposed weights and flipped taps -- the input-gradient of a stride-1 conv or one output
+ * parity class of a strided conv.
+ */
+typedef struct sdt_conv_geom {
+    int32_t B, Hi, Wi, Cin;
+    int32_t Ho, Wo;
+    int32_t Hy, Wy, Cout;
+    int32_t sy, sx;
+    int32_t osy, osx, ooy, oox;
+    int32_t ntaps, Tw;
+    int32_t dy[SDT_MAX_TAPS], dx[SDT_MAX_TAPS], wt[SDT_MAX_TAPS];
+} sdt_conv_geom;
+
+/* nn.Conv2d / nn.Conv1d forward and input-gradient (building_blocks.py:15-22,31-38; ATen conv). */
+int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
+                      const sdt_conv_geom* g, void* stream);
+/* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
+ *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
+int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);
+/* (Cout,T,Cin) -> (Cin,T,Cout): operand layout for the input-gradient GEMM. */
+int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+/* out[c] += sum_rows x[row, c]  (bias gradient of the k1 head conv, generator.py:103). */
+int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream);
+
+/*
+ * Column-statistics normalisation over a (G, R, C) view: statistics per (g, c) over R rows.
+ *   G=B, R=H*W  -> nn.InstanceNorm2d            (building_blocks.py:26)
+ *   G=1, R=B*HW -> nn.BatchNorm{1,2}d, training (building_blocks.py:24,39)
+ * followed by LeakyReLU(slope) (slope = 0 -> ReLU)  (building_blocks.py:46).
+ * sums: workspace of 2*G*C doubles (zeroed by the call).  num_batches_tracked (nullable) is the
+ * BatchNorm int64 counter, incremented on the device.  gamma/beta/running_* may be NULL (IN).
+ * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
+ * momentum (unbiased variance), as nn.BatchNorm does in training mode.
+ * eval: z = act(gamma*(y-running_mean)/sqrt(running_var+eps)+beta).
+ */
+int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
+                        float slope, void* stream);
+int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var,
+                         int64_t rows, int C, float eps, float slope, void* stream);
+/* bwd: dy <- d(loss)/dy given dz; dgamma/dbeta (nullable) are ACCUMULATED. dy may alias dz. */
+int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                        float* dbeta, int G, int64_t R, int C, float slope, void* stream);
+
+/*
+ * Row normalisation over C for each of `rows` rows + LeakyReLU: the reference's InstanceNorm1d
+ * applied to the (B,T,C)-permuted tensor (building_blocks.py:50-51) == per-(b,t) LayerNorm, no affine.
+ */
+int sdt_rownorm_fwd_f32(const float* y, float* z, float* mean, float* rstd, int64_t rows, int C,
+                        float eps, float slope, void* stream);
+int sdt_rownorm_bwd_f32(const float* dz, const float* y, const float* mean, const float* rstd, float* dy,
+                        int64_t rows, int C, float slope, void* stream);
+
+/*
+ * F.interpolate(x,(1,T),'bilinear') on the (B,H,W,C) encoder output, squeezed, with the gathered
+ * clip code broadcast-concatenated along channels (generator.py:41-42,110-111; voice2pose.py:94):
+ *   out (B,T,C+D);  out[b,t,C+d] = table[idx[b], d]   (D may be 0, table/idx NULL).
+ */
+int sdt_resize_concat_fwd_f32(const float* x, const float* table, const int64_t* idx, float* out,
+                              int B, int H, int W, int C, int T, int D, void* stream);
+/* dx (B,H,W,C) is fully written; dtable rows are ACCUMULATED (dense gradient of the code table). */
+int sdt_resize_concat_bwd_f32(const float* dout, const int64_t* idx, float* dx, float* dtable,
+                              int B, int H, int W, int C, int T, int D, void* stream);
+
+/* F.interpolate(prev, To, 'linear') (+ skip) on (B,Ti,C)->(B,To,C) (generator.py:79-83, autoencoder.py:62-66). */
+int sdt_upsample_add_fwd_f32(const float* prev, const float* skip, float* out, int B, int Ti, int To, int C, void* stream);
+int sdt_upsample_add_bwd_f32(const float* dout, float* dprev, int B, int Ti, int To, int C, void* stream);
+
+/* nn.L1Loss(reduction='none')(pred,gt)*lambda .mean() (voice2pose.py:141-142). partial: >=256 doubles. */
+int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n, float lambda, double* partial, float* loss, void* stream);
+int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, int64_t n, float lambda, float* dpred, void* stream);
+
+/*
+ * Clip-code batch KL (voice2pose.py:147-157): code = table[idx] (B,D); mu/unbiased var over the batch;
+ * loss = 0.5*mean(-log v + mu^2 + v - 1)*lambda if every v != 0 else 0; valid[0] = that predicate
+ * (kept on the device: no host sync).  code_out (B,D) receives the gathered rows.
+ */
+int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int B, int D, float lambda,
+                        float* code_out, float* loss, int32_t* valid, void* stream);
+int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* gout, const int64_t* idx,
+                        int B, int D, float lambda, float* dtable, void* stream);
+
+/*
+ * GestureDataset.get_final_results x2 + Voice2Pose.evaluate_step (gesture_dataset.py:193-220,
+ * voice2pose.py:412-430), float64 like the reference: final_* (B,T,2,K) f64 (nullable),
+ * metrics[0]=L2_dist, metrics[1]=lip_sync_error_n.  work: >= 2*B*T + 4 doubles.
+ */
+int sdt_final_metrics_f64(const float* pred, const float* gt, const double* mean, const double* std,
+                          const double* scale, int hierarchical, int B, int T, int K,
+                          double* final_pred, double* final_gt, double* work, double* metrics, void* stream);
+
+/* torch.optim.Adam(betas, eps, weight_decay) step over a flat fp32 buffer (voice2pose.py:249-279,302-304).
+ * lr_dev: device float (so that LR schedules do not invalidate a captured hipGraph);
+ * state_dev: 16 device bytes {int64 step; float bc1; float bc2_sqrt}, zero-initialised by the caller;
+ * the call increments `step` on the device and derives the bias corrections from it. */
+int sdt_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
+                      float beta2, float eps, float weight_decay, void* state_dev, void* stream);
+
+/*
+ * Mel front end (torchaudio 0.7 MelSpectrogram as configured at voice2pose.py:27-30):
+ * reflect-pad 256, 512-sample frames every 160, periodic-Hann(400) centred, |rFFT|^2, HTK filterbank.
+ * The STFT is run as an MFMA GEMM by sdt_conv_taps_f32 over the hop matrix:
+ *   sdt_stft_frames_f32 : audio (B,L) -> hops (B, nhops, 160), hops[b, j] = reflect_pad(audio)[j + 56]
+ *   sdt_conv_taps_f32   : X = hops as (B,1,nhops,160), W = windowed DFT basis (514, 3, 160)
+ *                         (row 2f = w*cos, 2f+1 = -w*sin of bin f; taps >= 400 samples are zero) -> spec (B,F,514)
+ *   sdt_mel_fb_f32      : spec (B,F,2*nfreq) interleaved re/im -> mel (B, nmel, F) = fb^T |spec|^2
+ */
+int sdt_stft_frames_f32(const float* audio, float* hops, int B, int L, int nhops, void* stream);
+int sdt_mel_fb_f32(const float* spec, const float* fb, float* mel, int B, int F, int nfreq, int nmel, void* stream);
+
+/* dst[idx[b], :] += src[b, :]  -- dense gradient of the clip-code table for `clips_code[clip_indices]` (voice2pose.py:94). */
+int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int B, int D, void* stream);
+
+/* y[i] = a[i+stride]-a[i] helper for the motion discriminator input (voice2pose.py:187-188): (B,T,C)->(B,T-1,C) */
+int sdt_time_diff_fwd_f32(const float* x, float* y, int B, int T, int C, void* stream);
+int sdt_time_diff_bwd_f32(const float* dy, float* dx, int B, int T, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDT_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libsdt_hip.so (the C ABI declared in include/sdt_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, loading
+raises; if a kernel call returns an error status, ``check`` raises RuntimeError with the library's
+message (the reference signals errors with Python exceptions, core/networks/__init__.py:14-19).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdt_hip.so")
+MAX_TAPS = 20
+
+
+class ConvGeom(C.Structure):
+    """Mirror of ``sdt_conv_geom`` (include/sdt_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Hy", "Wy", "Cout", "sy", "sx", "osy", "osx", "ooy", "oox",
+                 "ntaps", "Tw")] + [("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wt", C.c_int32 * MAX_TAPS)]
+
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_G = C.POINTER(ConvGeom)
+
+# name -> argtypes; every function returns int status.  Keep in lock-step with include/sdt_hip.h
+SIGNATURES = {
+    "sdt_conv_taps_f32": [_p, _p, _p, _p, _G, _p],
+    "sdt_conv_dw_f32": [_p, _p, _p, _G, _p],
+    "sdt_weight_transpose_f32": [_p, _p, _i, _i, _i, _p],
+    "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
+    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
+    "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
+    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p],
+    "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],
+    "sdt_rownorm_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i, _f, _p],
+    "sdt_resize_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdt_resize_concat_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sdt_upsample_add_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sdt_upsample_add_bwd_f32": [_p, _p, _i, _i, _i, _i, _p],
+    "sdt_l1_loss_fwd_f32": [_p, _p, _i64, _f, _p, _p, _p],
+    "sdt_l1_loss_bwd_f32": [_p, _p, _p, _i64, _f, _p, _p],
+    "sdt_code_kl_fwd_f32": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
+    "sdt_code_kl_bwd_f32": [_p, _p, _p, _p, _i, _i, _f, _p, _p],
+    "sdt_final_metrics_f64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "sdt_adam_step_f32": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p],
+    "sdt_stft_frames_f32": [_p, _p, _i, _i, _i, _p],
+    "sdt_mel_fb_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _p],
+    "sdt_time_diff_fwd_f32": [_p, _p, _i, _i, _i, _p],
+    "sdt_time_diff_bwd_f32": [_p, _p, _i, _i, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the kernel library and bind every exported entry point (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsdt_hip.so not found at %s -- run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+            "this package has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.sdt_last_error.restype = C.c_char_p
+    lib.sdt_abi_version.restype = C.c_int
+    if lib.sdt_abi_version() != 1:
+        raise ImportError("libsdt_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError("libsdt_hip: %s (status %d)" % (load().sdt_last_error().decode(), status))

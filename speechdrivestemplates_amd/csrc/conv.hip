@@ -1,0 +1,459 @@
+// Implicit-GEMM convolution kernels for gfx950 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   conv_taps_kernel : Y[m][n] = sum_k im2col(X)[m][k] * W[n][k]      (forward conv and input-gradient)
+//   conv_dw_kernel   : dW[n][k] += sum_m dY[m][n] * im2col(X)[m][k]   (weight gradient, split over m)
+//
+// Data layout: channels-last activations, (Cout, taps, Cin) weights -> both GEMM operands of the
+// forward/dX product are K-contiguous, so global loads are 16-B vectors along K and LDS tiles are
+// [row][K] with a 36-float pitch (conflict-free ds_read_b128).  A workgroup is 4 waves
+// in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile as TMxTN 32x32 MFMA accumulators.
+//
+// Replaces the ATen/cuDNN convolution calls made by building_blocks.py:15-22,31-38 (ConvNormRelu),
+// generator.py:103 and discriminator.py:16 (k1 / k3 head convs) in forward and backward.
+#include "common.h"
+
+#define BK 32
+#define LDP 36  // LDS pitch of a [row][BK] tile, in floats
+
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, bool VEC4>
+__global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ Y,
+                                                        const sdt_conv_geom g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
+    __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
+    __shared__ int sOut[BM];
+    __shared__ int sTap[3 * SDT_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = g.B * g.Ho * g.Wo;
+    const int nmb = (M + BM - 1) / BM;
+    const int m0 = xcd_remap(blockIdx.x, nmb) * BM;
+    const int n0 = blockIdx.y * BN;
+
+    if (tid < g.ntaps) {
+        sTap[tid] = g.dy[tid];
+        sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
+        sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
+    }
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            off = ((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout;
+        }
+        sOut[tid] = off;
+    }
+    // loader mapping: 8 threads x 16 B cover one 32-float K row; 32 rows per pass
+    const int kv = tid & 7, r0 = tid >> 3;
+    int rbH[RA], riy[RA], rix[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            rbH[i] = b * g.Hi;
+            riy[i] = oy * g.sy;
+            rix[i] = ox * g.sx;
+        } else {
+            rbH[i] = 0;
+            riy[i] = -(1 << 20);  // always out of range
+            rix[i] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int nkc = (g.Cin + BK - 1) / BK;
+    const int Ktot = g.ntaps * g.Cin;
+    const int nsteps = VEC4 ? g.ntaps * nkc : (Ktot + BK - 1) / BK;
+
+    f32x4 ra[RA], rb[RB];
+    auto load = [&](int step) {
+        if constexpr (VEC4) {
+            const int t = step / nkc;
+            const int c = (step - t * nkc) * BK + kv * 4;
+            const bool cok = c < g.Cin;
+            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int iy = riy[i] + dy, ix = rix[i] + dx;
+                const bool ok = cok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *(const f32x4*)(X + ((size_t)(rbH[i] + iy) * g.Wi + ix) * g.Cin + c);
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && n < g.Cout) v = *(const f32x4*)(W + ((size_t)n * g.Tw + wt) * g.Cin + c);
+                rb[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = step * BK + kv * 4 + e;
+                const bool kok = kk < Ktot;
+                const int t = kok ? kk / g.Cin : 0;
+                const int c = kk - t * g.Cin;
+                const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int iy = riy[i] + dy, ix = rix[i] + dx;
+                    const bool ok = kok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                    ra[i][e] = ok ? X[((size_t)(rbH[i] + iy) * g.Wi + ix) * g.Cin + c] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int n = n0 + r0 + 32 * i;
+                    rb[i][e] = (kok && n < g.Cout) ? W[((size_t)n * g.Tw + wt) * g.Cin + c] : 0.f;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
+    const float* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
+
+    load(0);
+    for (int step = 0; step < nsteps; ++step) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
+        __syncthreads();
+        if (step + 1 < nsteps) load(step + 1);
+        // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
+        // sub-step (j,e) consumes k = 8j + 4h + e, so each lane feeds 4 MFMAs from one ds_read_b128.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *(const f32x4*)(pa + tm * 32 * LDP + j * 8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *(const f32x4*)(pb + tn * 32 * LDP + j * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+            const bool nok = n < g.Cout;
+            const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int off = sOut[row];
+                if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient.  GEMM with the reduction over output positions m; operands are m-major in HBM
+// (dY rows are Cout-contiguous, X rows Cin-contiguous) so LDS tiles are [k=m][row] and MFMA operands
+// are read with conflict-free ds_read_b32.  grid = (m-splits, column tiles, Cout tiles); partial
+// products are accumulated into dW with fp32 global atomics.
+template <int BM, int BN, bool VEC4>
+__global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                      float* __restrict__ dW, const sdt_conv_geom g,
+                                                      const int rows_per_split) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RA = BM / 32, RB = BN / 32;      // float4 loads per thread per tile
+    constexpr int PA = 1024 / BM, PB = 1024 / BN;  // tile rows covered per pass
+    __shared__ __attribute__((aligned(16))) float sA[BK * BM];
+    __shared__ __attribute__((aligned(16))) float sB[BK * BN];
+    __shared__ int sRow[2][4][BK];
+    __shared__ int sTap[3 * SDT_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = g.B * g.Ho * g.Wo;
+    const int mbeg = blockIdx.x * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    const int n0 = blockIdx.z * BM;
+    const int ncb = (g.Cin + BN - 1) / BN;
+    const int tapv = VEC4 ? (int)blockIdx.y / ncb : 0;
+    const int c0 = VEC4 ? ((int)blockIdx.y % ncb) * BN : (int)blockIdx.y * BN;  // scalar path: flattened (tap,c)
+    const int Ktot = g.ntaps * g.Cin;
+
+    if (tid < g.ntaps) {
+        sTap[tid] = g.dy[tid];
+        sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
+        sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
+    }
+    auto decode = [&](int step) {  // called by tid < BK
+        int m = mbeg + step * BK + tid;
+        int offY = -1, bH = 0, iy0 = -(1 << 20), ix0 = 0;
+        if (m < mend) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            offY = ((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout;
+            bH = b * g.Hi;
+            iy0 = oy * g.sy;
+            ix0 = ox * g.sx;
+        }
+        int (*R)[BK] = sRow[step & 1];
+        R[0][tid] = offY;
+        R[1][tid] = bH;
+        R[2][tid] = iy0;
+        R[3][tid] = ix0;
+    };
+
+    const int nva = tid % (BM / 4), rra = tid / (BM / 4);
+    const int nvb = tid % (BN / 4), rrb = tid / (BN / 4);
+    const int nsteps = (mend - mbeg + BK - 1) / BK;
+    if (nsteps <= 0) return;
+
+    f32x4 ra[RA], rb[RB];
+    auto load = [&](int step) {
+        int (*R)[BK] = sRow[step & 1];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int r = rra + PA * i;
+            const int offY = R[0][r];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + 4 * nva;
+            if constexpr (VEC4) {
+                if (offY >= 0 && n < g.Cout) v = *(const f32x4*)(dY + (size_t)offY + n);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (offY >= 0 && n + e < g.Cout) v[e] = dY[(size_t)offY + n + e];
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = rrb + PB * i;
+            const int bH = R[1][r], iy0 = R[2][r], ix0 = R[3][r];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (VEC4) {
+                const int c = c0 + 4 * nvb;
+                const int iy = iy0 + sTap[tapv], ix = ix0 + sTap[SDT_MAX_TAPS + tapv];
+                if (c < g.Cin && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
+                    v = *(const f32x4*)(X + ((size_t)(bH + iy) * g.Wi + ix) * g.Cin + c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = c0 + 4 * nvb + e;
+                    if (j < Ktot) {
+                        const int t = j / g.Cin, c = j - t * g.Cin;
+                        const int iy = iy0 + sTap[t], ix = ix0 + sTap[SDT_MAX_TAPS + t];
+                        if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
+                            v[e] = X[((size_t)(bH + iy) * g.Wi + ix) * g.Cin + c];
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (tid < BK) decode(0);
+    __syncthreads();
+    load(0);
+    const float* pa = sA + (lane >> 5) * BM + wm * (BM / 2) + (lane & 31);
+    const float* pb = sB + (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
+    for (int step = 0; step < nsteps; ++step) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(rra + PA * i) * BM + 4 * nva] = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(rrb + PB * i) * BN + 4 * nvb] = rb[i];
+        if (step + 1 < nsteps && tid < BK) decode(step + 1);
+        __syncthreads();
+        if (step + 1 < nsteps) load(step + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = pa[2 * kk * BM + tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = pb[2 * kk * BN + tn * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int jl = wn * (BN / 2) + tn * 32 + (lane & 31);
+            int wt, c;
+            bool cok;
+            if constexpr (VEC4) {
+                c = c0 + jl;
+                cok = c < g.Cin;
+                wt = sTap[2 * SDT_MAX_TAPS + tapv];
+            } else {
+                const int j = c0 + jl;
+                cok = j < Ktot;
+                const int t = cok ? j / g.Cin : 0;
+                c = j - t * g.Cin;
+                wt = sTap[2 * SDT_MAX_TAPS + t];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cok && n < g.Cout) atomicAdd(&dW[((size_t)n * g.Tw + wt) * g.Cin + c], acc[tm][tn][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ W, float* __restrict__ Wt,
+                                                               int cout, int taps, int cin) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int co = co0 + ty + 8 * i, ci = ci0 + tx;
+        tile[ty + 8 * i][tx] = (co < cout && ci < cin) ? W[((size_t)co * taps + t) * cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ci = ci0 + ty + 8 * i, co = co0 + tx;
+        if (ci < cin && co < cout) Wt[((size_t)ci * taps + t) * cout + co] = tile[tx][ty + 8 * i];
+    }
+}
+
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                      int64_t rows, int C, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_geom(const sdt_conv_geom* g) {
+    SDT_CHECK_ARG(g != nullptr, "null geometry");
+    SDT_CHECK_ARG(g->B > 0 && g->Hi > 0 && g->Wi > 0 && g->Cin > 0 && g->Ho > 0 && g->Wo > 0 && g->Cout > 0, "non-positive dims");
+    SDT_CHECK_ARG(g->ntaps > 0 && g->ntaps <= SDT_MAX_TAPS && g->Tw >= 1, "bad tap count");
+    SDT_CHECK_ARG((int64_t)g->B * g->Hy * g->Wy * g->Cout < (1ll << 31), "output tensor too large for 32-bit offsets");
+    SDT_CHECK_ARG((int64_t)g->B * g->Ho * g->Wo < (1ll << 31), "too many output positions");
+    SDT_CHECK_ARG((g->Ho - 1) * g->osy + g->ooy < g->Hy && (g->Wo - 1) * g->osx + g->oox < g->Wy, "output grid exceeds Y");
+    for (int t = 0; t < g->ntaps; ++t) SDT_CHECK_ARG(g->wt[t] >= 0 && g->wt[t] < g->Tw, "weight tap out of range");
+    return SDT_OK;
+}
+
+template <int BM, int BN>
+static void launch_taps(bool vec4, const float* x, const float* w, const float* bias, float* y,
+                        const sdt_conv_geom& g, hipStream_t s) {
+    const int M = g.B * g.Ho * g.Wo;
+    dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN));
+    if (vec4)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g);
+    else
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g);
+}
+
+extern "C" int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
+                                 const sdt_conv_geom* g, void* stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    SDT_CHECK_ARG(x && w && y, "null pointer");
+    const bool vec4 = (g->Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)w) % 16 == 0);
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    hipStream_t s = (hipStream_t)stream;
+    if (g->Cout <= 64) {
+        if (M >= 128 * 512) launch_taps<128, 64>(vec4, x, w, bias, y, *g, s);
+        else launch_taps<64, 64>(vec4, x, w, bias, y, *g, s);
+    } else {
+        const int64_t tiles = cdiv64(M, 128) * cdiv(g->Cout, 128);
+        if (tiles >= 512) launch_taps<128, 128>(vec4, x, w, bias, y, *g, s);
+        else launch_taps<64, 64>(vec4, x, w, bias, y, *g, s);
+    }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+template <int BM, int BN>
+static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, const sdt_conv_geom& g, hipStream_t s) {
+    const int M = g.B * g.Ho * g.Wo;
+    const int coltiles = vec4 ? g.ntaps * cdiv(g.Cin, BN) : cdiv(g.ntaps * g.Cin, BN);
+    const int ntiles = cdiv(g.Cout, BM);
+    int nsplit = cdiv(1536, coltiles * ntiles);
+    nsplit = max(1, min(nsplit, cdiv(M, BK)));
+    int rows = cdiv(cdiv(M, nsplit), BK) * BK;
+    nsplit = cdiv(M, rows);
+    dim3 grid(nsplit, coltiles, ntiles);
+    if (vec4)
+        hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
+    else
+        hipLaunchKernelGGL((conv_dw_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
+}
+
+extern "C" int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    SDT_CHECK_ARG(x && dy && dw, "null pointer");
+    const bool vec4 = (g->Cin % 4 == 0) && (g->Cout % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const bool bigm = g->Cout > 64;
+    const bool bign = vec4 ? g->Cin > 64 : g->ntaps * g->Cin > 64;
+    if (bigm && bign) launch_dw<128, 128>(vec4, x, dy, dw, *g, s);
+    else if (bigm) launch_dw<128, 64>(vec4, x, dy, dw, *g, s);
+    else if (bign) launch_dw<64, 128>(vec4, x, dy, dw, *g, s);
+    else launch_dw<64, 64>(vec4, x, dy, dw, *g, s);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream) {
+    SDT_CHECK_ARG(w && wt && cout > 0 && taps > 0 && cin > 0, "bad argument");
+    dim3 grid(cdiv(cin, 32), cdiv(cout, 32), taps);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, cout, taps, cin);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream) {
+    SDT_CHECK_ARG(x && out && rows > 0 && c > 0, "bad argument");
+    const int rpb = 64;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)cdiv64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, rows, c, rpb);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}

@@ -1,0 +1,591 @@
+// Resampling, loss, metric, optimiser and mel-front-end kernels (all HBM/latency-bound element-wise or
+// small-reduction work: 16-B coalesced accesses along the channel dimension, wave-shuffle reductions).
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void sdt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sdt_last_error(void) { return g_err; }
+extern "C" int sdt_abi_version(void) { return 1; }
+
+// PyTorch's area_pixel_compute_source_index(align_corners=False) in fp32
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.interpolate(x,(1,T),'bilinear').squeeze(2) ++ code  (generator.py:41-42,110-111)
+__global__ __launch_bounds__(256) void resize_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                                                const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                                int B, int H, int W, int C, int T, int D) {
+    const int CD = C + D, nv = CD >> 2;
+    const int64_t total = (int64_t)B * T * nv;
+    const float sh = (float)H, sw = (float)W / (float)T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nv);
+        const int64_t bt = i / nv;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int c = cv * 4;
+        f32x4 o;
+        if (c < C) {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            src_index(sh, 0, H, y0, y1, ly);
+            src_index(sw, t, W, x0, x1, lx);
+            const float* p = x + (size_t)b * H * W * C + c;
+            const f32x4 v00 = *(const f32x4*)(p + ((size_t)y0 * W + x0) * C), v01 = *(const f32x4*)(p + ((size_t)y0 * W + x1) * C);
+            const f32x4 v10 = *(const f32x4*)(p + ((size_t)y1 * W + x0) * C), v11 = *(const f32x4*)(p + ((size_t)y1 * W + x1) * C);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            o = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        } else {
+            o = *(const f32x4*)(table + (size_t)idx[b] * D + (c - C));
+        }
+        *(f32x4*)(out + (size_t)bt * CD + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B,
+                                                         int H, int W, int C, int T, int CD) {
+    const int nv = C >> 2;
+    const int64_t total = (int64_t)B * H * W * nv;
+    const float sh = (float)H, sw = (float)W / (float)T;
+    int y0, y1;
+    float ly;
+    src_index(sh, 0, H, y0, y1, ly);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nv);
+        int64_t r = i / nv;
+        const int xw = (int)(r % W);
+        r /= W;
+        const int yh = (int)(r % H), b = (int)(r / H);
+        const float wy = (yh == y0 ? 1.f - ly : 0.f) + (yh == y1 ? ly : 0.f);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wy != 0.f) {
+            for (int t = 0; t < T; ++t) {
+                int x0, x1;
+                float lx;
+                src_index(sw, t, W, x0, x1, lx);
+                const float wx = (xw == x0 ? 1.f - lx : 0.f) + (xw == x1 ? lx : 0.f);
+                if (wx != 0.f) acc += (wy * wx) * *(const f32x4*)(dout + ((size_t)b * T + t) * CD + 4 * cv);
+            }
+        }
+        *(f32x4*)(dx + 4 * i) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void code_scatter_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dtable, int B, int C, int T, int D) {
+    const int total = B * D;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int d = i % D, b = i / D;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += dout[((size_t)b * T + t) * (C + D) + C + d];
+    atomicAdd(&dtable[(size_t)idx[b] * D + d], s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.interpolate(prev, To, 'linear') (+ skip)   (generator.py:79-83)
+__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __restrict__ prev, const float* __restrict__ skip,
+                                                               float* __restrict__ out, int B, int Ti, int To, int C) {
+    const int nv = C >> 2;
+    const int64_t total = (int64_t)B * To * nv;
+    const float sc = (float)Ti / (float)To;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nv);
+        const int64_t bj = i / nv;
+        const int j = (int)(bj % To), b = (int)(bj / To);
+        int i0, i1;
+        float l1;
+        src_index(sc, j, Ti, i0, i1, l1);
+        const float* p = prev + (size_t)b * Ti * C + 4 * cv;
+        f32x4 o = (1.f - l1) * *(const f32x4*)(p + (size_t)i0 * C) + l1 * *(const f32x4*)(p + (size_t)i1 * C);
+        if (skip) o += *(const f32x4*)(skip + 4 * i);
+        *(f32x4*)(out + 4 * i) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dprev, int B,
+                                                           int Ti, int To, int C) {
+    const int nv = C >> 2;
+    const int64_t total = (int64_t)B * Ti * nv;
+    const float sc = (float)Ti / (float)To;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nv);
+        const int64_t bi = i / nv;
+        const int ii = (int)(bi % Ti), b = (int)(bi / Ti);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < To; ++j) {
+            int i0, i1;
+            float l1;
+            src_index(sc, j, Ti, i0, i1, l1);
+            const float w = (ii == i0 ? 1.f - l1 : 0.f) + (ii == i1 ? l1 : 0.f);
+            if (w != 0.f) acc += w * *(const f32x4*)(dout + ((size_t)b * To + j) * C + 4 * cv);
+        }
+        *(f32x4*)(dprev + 4 * i) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L1 regression loss (voice2pose.py:141-142)
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)fabsf(p[i] - g[i]);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const double* __restrict__ partial, int nblk, double scale,
+                                                       float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) * scale);
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                     const float* __restrict__ gout, int64_t n, float scale,
+                                                     float* __restrict__ dp) {
+    const float go = gout[0] * scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = p[i] - g[i];
+        dp[i] = d > 0.f ? go : (d < 0.f ? -go : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip-code batch KL (voice2pose.py:147-157); one workgroup, one thread per code dimension
+__global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          int B, int D, float lambda, float* __restrict__ code,
+                                                          float* __restrict__ loss, int* __restrict__ valid) {
+    __shared__ float sTerm[256];
+    __shared__ int sBad;
+    const int d = threadIdx.x;
+    if (d == 0) sBad = 0;
+    __syncthreads();
+    float term = 0.f;
+    if (d < D) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float v = table[(size_t)idx[b] * D + d];
+            code[(size_t)b * D + d] = v;
+            s += v;
+        }
+        const float mu = s / (float)B;
+        float q = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float dv = table[(size_t)idx[b] * D + d] - mu;
+            q += dv * dv;
+        }
+        const float var = q / (float)(B - 1);
+        if (!(var != 0.f)) atomicOr(&sBad, 1);
+        term = -logf(var) + mu * mu + var - 1.f;
+    }
+    sTerm[d] = term;
+    __syncthreads();
+    if (d == 0) {
+        float s = 0.f;
+        for (int j = 0; j < D; ++j) s += sTerm[j];
+        const int ok = sBad ? 0 : 1;
+        valid[0] = ok;
+        loss[0] = ok ? 0.5f * (s / (float)D) * lambda : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void code_kl_bwd_kernel(const float* __restrict__ code, const int* __restrict__ valid,
+                                                          const float* __restrict__ gout, const int64_t* __restrict__ idx,
+                                                          int B, int D, float lambda, float* __restrict__ dtable) {
+    const int d = threadIdx.x;
+    if (d >= D || valid[0] == 0) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += code[(size_t)b * D + d];
+    const float mu = s / (float)B;
+    float q = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float dv = code[(size_t)b * D + d] - mu;
+        q += dv * dv;
+    }
+    const float var = q / (float)(B - 1);
+    const float k = gout[0] * lambda * 0.5f / (float)D;
+    const float dmu = k * 2.f * mu / (float)B;
+    const float dvar = k * (1.f - 1.f / var) * 2.f / (float)(B - 1);
+    for (int b = 0; b < B; ++b) atomicAdd(&dtable[(size_t)idx[b] * D + d], dmu + dvar * (code[(size_t)b * D + d] - mu));
+}
+
+// ---------------------------------------------------------------------------------------------
+// get_final_results x2 + evaluate_step in float64 (gesture_dataset.py:193-220, voice2pose.py:412-430)
+// one workgroup of 128 threads per (b,t); thread k handles keypoint k (x and y).
+__global__ __launch_bounds__(128) void final_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                            const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                            const double* __restrict__ scale, int hier, int T, int K,
+                                                            double* __restrict__ fpred, double* __restrict__ fgt,
+                                                            double* __restrict__ work, int BT) {
+    __shared__ double sv[2][2][128];
+    __shared__ double red[2];
+    const int bt = blockIdx.x, b = bt / T, k = threadIdx.x;
+    const size_t base = (size_t)bt * 2 * K;
+    if (k < K) {
+#pragma unroll
+        for (int xy = 0; xy < 2; ++xy) {
+            const double m = mean[(size_t)b * 2 * K + xy * K + k], sd = stdv[(size_t)b * 2 * K + xy * K + k];
+            sv[0][xy][k] = (double)pred[base + xy * K + k] * sd + m;
+            sv[1][xy][k] = (double)gt[base + xy * K + k] * sd + m;
+        }
+    }
+    __syncthreads();
+    double l2 = 0.0;
+    double v[2][2];
+    if (k < K) {
+        int root = -1;
+        if (hier) {  // parted_to_global, gesture_dataset.py:147-155 (head root 39, hand roots 6 / 3)
+            if (k >= 9 && k < 79 && k != 39) root = 39;
+            else if (k >= 79 && k < 100) root = 6;
+            else if (k >= 100 && k < 121) root = 3;
+        }
+        const double sc = scale[b];
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int xy = 0; xy < 2; ++xy) {
+                double t = sv[w][xy][k];
+                if (root >= 0) t = t + sv[w][xy][root];
+                v[w][xy] = t * sc;
+            }
+        if (fpred) {
+            fpred[base + k] = v[0][0];
+            fpred[base + K + k] = v[0][1];
+        }
+        if (fgt) {
+            fgt[base + k] = v[1][0];
+            fgt[base + K + k] = v[1][1];
+        }
+        const double dx = v[0][0] - v[1][0], dy = v[0][1] - v[1][1];
+        l2 = sqrt(dx * dx + dy * dy);
+    }
+    __syncthreads();
+    if (k < K) {
+        sv[0][0][k] = v[0][0];
+        sv[0][1][k] = v[0][1];
+        sv[1][0][k] = v[1][0];
+        sv[1][1][k] = v[1][1];
+    }
+    l2 = wave_sum_d(l2);
+    if ((k & 63) == 0) red[k >> 6] = l2;
+    __syncthreads();
+    if (k == 0) {
+        atomicAdd(&work[0], red[0] + red[1]);
+        if (K > 75) {
+            const double px = sv[0][0][75] - sv[0][0][71], py = sv[0][1][75] - sv[0][1][71];
+            const double gx = sv[1][0][75] - sv[1][0][71], gy = sv[1][1][75] - sv[1][1][71];
+            work[4 + bt] = sqrt(px * px + py * py);
+            work[4 + BT + bt] = sqrt(gx * gx + gy * gy);
+        } else {
+            work[4 + bt] = 0.0;
+            work[4 + BT + bt] = 0.0;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void final_metrics_reduce_kernel(const double* __restrict__ work, int B, int T, int K,
+                                                                   double* __restrict__ metrics) {
+    __shared__ double red[4];
+    const int BT = B * T;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        double mx = -1.0;
+        for (int t = 0; t < T; ++t) mx = fmax(mx, work[4 + BT + b * T + t]);
+        const double den = mx + 1e-4;
+        for (int t = 0; t < T; ++t) s += fabs(work[4 + b * T + t] / den - work[4 + BT + b * T + t] / den);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        metrics[0] = work[0] / ((double)BT * (double)K);
+        metrics[1] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)BT;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, voice2pose.py:249-279) over one flat fp32 buffer.
+struct AdamState {
+    int64_t step;
+    float bc1, bc2_sqrt;
+};
+__global__ void adam_prep_kernel(AdamState* st, float beta1, float beta2) {
+    const int64_t s = st->step + 1;
+    st->step = s;
+    st->bc1 = (float)(1.0 - pow((double)beta1, (double)s));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)s));
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev,
+                                                   float beta1, float beta2, float eps, float wd,
+                                                   const AdamState* __restrict__ st) {
+    const float lr = lr_dev[0];
+    const float step_size = lr / st->bc1, bc2s = st->bc2_sqrt;
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = *(f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i), mv = *(f32x4*)(m + 4 * i), vv = *(f32x4*)(v + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gg = gv[e];
+            if (wd != 0.f) gg += wd * pv[e];
+            mv[e] = mv[e] * beta1 + (1.f - beta1) * gg;
+            vv[e] = vv[e] * beta2 + (1.f - beta2) * gg * gg;
+            const float denom = sqrtf(vv[e]) / bc2s + eps;
+            pv[e] = pv[e] - step_size * (mv[e] / denom);
+        }
+        *(f32x4*)(p + 4 * i) = pv;
+        *(f32x4*)(m + 4 * i) = mv;
+        *(f32x4*)(v + 4 * i) = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        float gg = g[i];
+        if (wd != 0.f) gg += wd * p[i];
+        const float mm = m[i] * beta1 + (1.f - beta1) * gg;
+        const float vv = v[i] * beta2 + (1.f - beta2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2s + eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mel front end.  The STFT is a GEMM: frames(B*F, 480) x basis(514, 480)^T, run by conv_taps on the
+// hop matrix (B, nh, 160) built here with torch.stft's reflect padding; power + HTK filterbank follow.
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ audio, float* __restrict__ hops, int B,
+                                                          int L, int nh) {
+    const int64_t per = (int64_t)nh * 160, total = (int64_t)B * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / per);
+        const int64_t j = i - (int64_t)b * per;
+        // padded[p] with p = j + 56 (window of 400 centred in the 512 frame), padded = reflect(audio, 256)
+        const int64_t p = j + 56;
+        float v = 0.f;
+        if (p < (int64_t)L + 512) {
+            int64_t s = p - 256;
+            if (s < 0) s = -s;
+            if (s >= L) s = 2 * ((int64_t)L - 1) - s;
+            if (s >= 0 && s < L) v = audio[(size_t)b * L + s];
+        }
+        hops[i] = v;
+    }
+}
+
+// spec (B,F,2*nfreq) interleaved re/im -> mel (B,nmel,F); block = 32 frames, 320 threads
+#define MEL_FT 32
+__global__ __launch_bounds__(320) void mel_fb_kernel(const float* __restrict__ spec, const float* __restrict__ fb,
+                                                     float* __restrict__ mel, int F, int nfreq, int nmel) {
+    extern __shared__ float sP[];  // [MEL_FT][nfreq+1]
+    const int b = blockIdx.y, f0 = blockIdx.x * MEL_FT;
+    const int ldp = nfreq + 1;
+    for (int i = threadIdx.x; i < MEL_FT * nfreq; i += 320) {
+        const int fr = i / nfreq, k = i - fr * nfreq;
+        float pw = 0.f;
+        if (f0 + fr < F) {
+            const float* s = spec + ((size_t)b * F + f0 + fr) * 2 * nfreq + 2 * k;
+            pw = s[0] * s[0] + s[1] * s[1];
+        }
+        sP[fr * ldp + k] = pw;
+    }
+    __syncthreads();
+    const int npg = 320 / nmel;  // frame groups handled in parallel (4 for 80 mels)
+    const int m = threadIdx.x % nmel, fg = threadIdx.x / nmel;
+    if (fg >= npg) return;
+    constexpr int MAXF = 16;
+    float acc[MAXF];
+#pragma unroll
+    for (int i = 0; i < MAXF; ++i) acc[i] = 0.f;
+    for (int k = 0; k < nfreq; ++k) {
+        const float w = fb[(size_t)k * nmel + m];
+        if (w != 0.f) {
+#pragma unroll
+            for (int i = 0; i < MAXF; ++i) {
+                const int fr = fg + npg * i;
+                if (fr < MEL_FT) acc[i] += w * sP[fr * ldp + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXF; ++i) {
+        const int fr = fg + npg * i;
+        if (fr < MEL_FT && f0 + fr < F) mel[((size_t)b * nmel + m) * F + f0 + fr] = acc[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dst, int B, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    const int d = i % D, b = i / D;
+    atomicAdd(&dst[(size_t)idx[b] * D + d], src[i]);
+}
+
+__global__ __launch_bounds__(256) void time_diff_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T,
+                                                            int C) {
+    const int64_t total = (int64_t)B * (T - 1) * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bt = i / C;
+        const int c = (int)(i - bt * C);
+        const int t = (int)(bt % (T - 1)), b = (int)(bt / (T - 1));
+        const size_t o = ((size_t)b * T + t) * C + c;
+        y[i] = x[o + C] - x[o];
+    }
+}
+__global__ __launch_bounds__(256) void time_diff_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int T,
+                                                            int C) {
+    const int64_t total = (int64_t)B * T * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bt = i / C;
+        const int c = (int)(i - bt * C);
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const size_t o = ((size_t)b * (T - 1)) * C + c;
+        float v = 0.f;
+        if (t >= 1) v += dy[o + (size_t)(t - 1) * C];
+        if (t < T - 1) v -= dy[o + (size_t)t * C];
+        dx[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 256), 4096)); }
+
+extern "C" int sdt_resize_concat_fwd_f32(const float* x, const float* table, const int64_t* idx, float* out, int B, int H,
+                                         int W, int C, int T, int D, void* stream) {
+    SDT_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && T > 0, "bad argument");
+    SDT_CHECK_ARG(C % 4 == 0 && D % 4 == 0 && D >= 0, "C and D must be multiples of 4");
+    SDT_CHECK_ARG(D == 0 || (table && idx), "code table / indices missing");
+    hipLaunchKernelGGL(resize_concat_fwd_kernel, dim3(ew_grid((int64_t)B * T * (C + D) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, table, idx, out, B, H, W, C, T, D);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_resize_concat_bwd_f32(const float* dout, const int64_t* idx, float* dx, float* dtable, int B, int H, int W,
+                                         int C, int T, int D, void* stream) {
+    SDT_CHECK_ARG(dout && dx && B > 0 && H > 0 && W > 0 && T > 0 && C % 4 == 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C / 4)), dim3(256), 0, s, dout, dx, B, H, W, C, T, C + D);
+    if (D > 0 && dtable != nullptr) {
+        SDT_CHECK_ARG(idx != nullptr, "indices missing");
+        hipLaunchKernelGGL(code_scatter_bwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, dout, idx, dtable, B, C, T, D);
+    }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_upsample_add_fwd_f32(const float* prev, const float* skip, float* out, int B, int Ti, int To, int C, void* stream) {
+    SDT_CHECK_ARG(prev && out && B > 0 && Ti > 0 && To > 0 && C % 4 == 0, "bad argument");
+    hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(ew_grid((int64_t)B * To * C / 4)), dim3(256), 0, (hipStream_t)stream, prev, skip, out, B, Ti, To, C);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_upsample_add_bwd_f32(const float* dout, float* dprev, int B, int Ti, int To, int C, void* stream) {
+    SDT_CHECK_ARG(dout && dprev && B > 0 && Ti > 0 && To > 0 && C % 4 == 0, "bad argument");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid((int64_t)B * Ti * C / 4)), dim3(256), 0, (hipStream_t)stream, dout, dprev, B, Ti, To, C);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n, float lambda, double* partial, float* loss, void* stream) {
+    SDT_CHECK_ARG(pred && gt && partial && loss && n > 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)std::min<int64_t>(256, cdiv64(n, 256));
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk), dim3(256), 0, s, pred, gt, n, partial);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, (double)lambda / (double)n, loss);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, int64_t n, float lambda, float* dpred, void* stream) {
+    SDT_CHECK_ARG(pred && gt && gout && dpred && n > 0, "bad argument");
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, pred, gt, gout, n, (float)((double)lambda / (double)n), dpred);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int B, int D, float lambda, float* code_out,
+                                   float* loss, int32_t* valid, void* stream) {
+    SDT_CHECK_ARG(table && idx && code_out && loss && valid && B > 0 && D > 0 && D <= 256, "bad argument");
+    hipLaunchKernelGGL(code_kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, idx, B, D, lambda, code_out, loss, valid);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* gout, const int64_t* idx, int B, int D,
+                                   float lambda, float* dtable, void* stream) {
+    SDT_CHECK_ARG(code && valid && gout && idx && dtable && B > 1 && D > 0 && D <= 256, "bad argument");
+    hipLaunchKernelGGL(code_kl_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, code, valid, gout, idx, B, D, lambda, dtable);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_final_metrics_f64(const float* pred, const float* gt, const double* mean, const double* stdv,
+                                     const double* scale, int hierarchical, int B, int T, int K, double* final_pred,
+                                     double* final_gt, double* work, double* metrics, void* stream) {
+    SDT_CHECK_ARG(pred && gt && mean && stdv && scale && work && metrics, "null pointer");
+    SDT_CHECK_ARG(B > 0 && T > 0 && K > 0 && K <= 128, "bad dims (K <= 128)");
+    SDT_CHECK_ARG(!hierarchical || K == 121, "hierarchical poses need the 121-keypoint layout");
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(work, 0, 4 * sizeof(double), s);
+    hipLaunchKernelGGL(final_metrics_kernel, dim3(B * T), dim3(128), 0, s, pred, gt, mean, stdv, scale, hierarchical, T, K,
+                       final_pred, final_gt, work, B * T);
+    hipLaunchKernelGGL(final_metrics_reduce_kernel, dim3(1), dim3(256), 0, s, work, B, T, K, metrics);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
+                                 float beta2, float eps, float weight_decay, void* state_dev, void* stream) {
+    SDT_CHECK_ARG(p && g && m && v && lr_dev && state_dev && n > 0, "bad argument");
+    SDT_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0, "buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, s, (AdamState*)state_dev, beta1, beta2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, n, lr_dev, beta1, beta2, eps,
+                       weight_decay, (const AdamState*)state_dev);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_stft_frames_f32(const float* audio, float* hops, int B, int L, int nhops, void* stream) {
+    SDT_CHECK_ARG(audio && hops && B > 0 && L > 256 && nhops > 0, "bad argument (L must exceed the 256-sample reflect pad)");
+    hipLaunchKernelGGL(stft_frames_kernel, dim3(ew_grid((int64_t)B * nhops * 160)), dim3(256), 0, (hipStream_t)stream, audio, hops, B, L, nhops);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_mel_fb_f32(const float* spec, const float* fb, float* mel, int B, int F, int nfreq, int nmel, void* stream) {
+    SDT_CHECK_ARG(spec && fb && mel && B > 0 && F > 0 && nfreq > 0, "bad argument");
+    SDT_CHECK_ARG(nmel > 0 && nmel <= 320 && (MEL_FT + 320 / nmel - 1) / (320 / nmel) <= 16, "unsupported mel count");
+    const size_t lds = (size_t)MEL_FT * (nfreq + 1) * sizeof(float);
+    SDT_CHECK_ARG(lds <= 64 * 1024, "too many frequency bins");
+    hipLaunchKernelGGL(mel_fb_kernel, dim3(cdiv(F, MEL_FT), B), dim3(320), lds, (hipStream_t)stream, spec, fb, mel, F, nfreq, nmel);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int B, int D, void* stream) {
+    SDT_CHECK_ARG(src && idx && dst && B > 0 && D > 0, "bad argument");
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, B, D);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_time_diff_fwd_f32(const float* x, float* y, int B, int T, int C, void* stream) {
+    SDT_CHECK_ARG(x && y && B > 0 && T > 1 && C > 0, "bad argument");
+    hipLaunchKernelGGL(time_diff_fwd_kernel, dim3(ew_grid((int64_t)B * (T - 1) * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, C);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_time_diff_bwd_f32(const float* dy, float* dx, int B, int T, int C, void* stream) {
+    SDT_CHECK_ARG(dy && dx && B > 0 && T > 1 && C > 0, "bad argument");
+    hipLaunchKernelGGL(time_diff_bwd_kernel, dim3(ew_grid((int64_t)B * T * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, T, C);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}

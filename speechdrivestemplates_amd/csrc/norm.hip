@@ -1,0 +1,354 @@
+// Normalisation + activation kernels (HBM-bound; 16-B coalesced channel vectors, wave-shuffle and
+// LDS reductions, fp64 accumulation of the per-(group,channel) statistics).
+//
+//  colnorm_* : statistics per (g, c) over the R rows of a (G, R, C) channels-last view
+//              G=B,R=HW  -> nn.InstanceNorm2d  (building_blocks.py:26)
+//              G=1,R=B*L -> nn.BatchNorm1d/2d in training mode (building_blocks.py:24,39)
+//  rownorm_* : statistics per row over C -> the reference's InstanceNorm1d on the permuted tensor
+//              (building_blocks.py:50-51), i.e. a per-(b,t) LayerNorm without affine
+//  both followed by LeakyReLU(0.2) / ReLU (building_blocks.py:46).
+#include "common.h"
+
+#define MAXC 1024
+
+// ---------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ a,   // fwd: y      bwd: dz
+                                                       const float* __restrict__ y,   // bwd only
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float slope, double* __restrict__ sums, int64_t R, int C,
+                                                       int rows_per_block) {
+    __shared__ double sS[MAXC], sQ[MAXC];
+    const int tid = threadIdx.x, g = blockIdx.y;
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int cv = tid % tpr, rr = tid / tpr;
+    for (int c = tid; c < C; c += 256) sS[c] = 0.0, sQ[c] = 0.0;
+    __syncthreads();
+    if (rr < rpp) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r1 = min(R, r0 + rows_per_block);
+        const size_t base = (size_t)g * R * C + 4 * cv;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+        f32x4 mu, rs, ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BWD) {
+            mu = *(const f32x4*)(mean + (size_t)g * C + 4 * cv);
+            rs = *(const f32x4*)(rstd + (size_t)g * C + 4 * cv);
+            if (gamma) ga = *(const f32x4*)(gamma + 4 * cv);
+            if (beta) be = *(const f32x4*)(beta + 4 * cv);
+        }
+        for (int64_t r = r0 + rr; r < r1; r += rpp) {
+            const f32x4 v = *(const f32x4*)(a + base + (size_t)r * C);
+            if constexpr (!BWD) {
+                s += v;
+                q += v * v;
+            } else {
+                const f32x4 yv = *(const f32x4*)(y + base + (size_t)r * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yh = (yv[e] - mu[e]) * rs[e];
+                    const float gg = v[e] * act_grad(yh * ga[e] + be[e], slope);
+                    s[e] += gg;
+                    q[e] += gg * yh;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sS[4 * cv + e], (double)s[e]);
+            atomicAdd(&sQ[4 * cv + e], (double)q[e]);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        atomicAdd(&sums[((size_t)g * C + c) * 2], sS[c]);
+        atomicAdd(&sums[((size_t)g * C + c) * 2 + 1], sQ[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __restrict__ y, float* __restrict__ z,
+                                                                const double* __restrict__ sums, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                                                int64_t R, int C, int rows_per_block, float eps,
+                                                                float momentum, float slope) {
+    const int tid = threadIdx.x, g = blockIdx.y;
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int cv = tid % tpr, rr = tid / tpr;
+    if (rr >= rpp) return;
+    f32x4 mu, rs, ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    double var[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double s = sums[((size_t)g * C + 4 * cv + e) * 2], q = sums[((size_t)g * C + 4 * cv + e) * 2 + 1];
+        const double m = s / (double)R;
+        double v = q / (double)R - m * m;
+        v = v > 0.0 ? v : 0.0;
+        var[e] = v;
+        mu[e] = (float)m;
+        rs[e] = (float)(1.0 / sqrt(v + (double)eps));
+    }
+    if (gamma) ga = *(const f32x4*)(gamma + 4 * cv);
+    if (beta) be = *(const f32x4*)(beta + 4 * cv);
+    if (blockIdx.x == 0 && rr == 0) {
+        *(f32x4*)(mean + (size_t)g * C + 4 * cv) = mu;
+        *(f32x4*)(rstd + (size_t)g * C + 4 * cv) = rs;
+        if (rmean != nullptr && g == 0) {  // nn.BatchNorm training-mode running statistics (unbiased variance)
+            const double unb = R > 1 ? (double)R / (double)(R - 1) : 1.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * cv + e;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu[e];
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var[e] * unb);
+            }
+            if (nbt != nullptr && cv == 0) nbt[0] += 1;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    const size_t base = (size_t)g * R * C + 4 * cv;
+    for (int64_t r = r0 + rr; r < r1; r += rpp) {
+        const f32x4 v = *(const f32x4*)(y + base + (size_t)r * C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
+        *(f32x4*)(z + base + (size_t)r * C) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void colnorm_eval_kernel(const float* __restrict__ y, float* __restrict__ z,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                           int64_t rows, int C, float eps, float slope) {
+    const int64_t nvec = rows * (C >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % (C >> 2));
+        const f32x4 v = *(const f32x4*)(y + 4 * i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * cv + e;
+            const float rs = 1.f / sqrtf(rvar[c] + eps);
+            const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+            o[e] = act_fwd(((v[e] - rmean[c]) * rs) * ga + be, slope);
+        }
+        *(f32x4*)(z + 4 * i) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                                float* __restrict__ dy, const double* __restrict__ sums,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int64_t R, int C, int rows_per_block, float slope) {
+    const int tid = threadIdx.x, g = blockIdx.y;
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int cv = tid % tpr, rr = tid / tpr;
+    if (rr >= rpp) return;
+    f32x4 mu = *(const f32x4*)(mean + (size_t)g * C + 4 * cv);
+    f32x4 rs = *(const f32x4*)(rstd + (size_t)g * C + 4 * cv);
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f}, mg, mgy;
+    if (gamma) ga = *(const f32x4*)(gamma + 4 * cv);
+    if (beta) be = *(const f32x4*)(beta + 4 * cv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double sg = sums[((size_t)g * C + 4 * cv + e) * 2], sgy = sums[((size_t)g * C + 4 * cv + e) * 2 + 1];
+        mg[e] = (float)(sg / (double)R);
+        mgy[e] = (float)(sgy / (double)R);
+        if (blockIdx.x == 0 && rr == 0) {
+            if (dgamma) atomicAdd(&dgamma[4 * cv + e], (float)sgy);
+            if (dbeta) atomicAdd(&dbeta[4 * cv + e], (float)sg);
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    const size_t base = (size_t)g * R * C + 4 * cv;
+    for (int64_t r = r0 + rr; r < r1; r += rpp) {
+        const f32x4 gz = *(const f32x4*)(dz + base + (size_t)r * C);
+        const f32x4 yv = *(const f32x4*)(y + base + (size_t)r * C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float yh = (yv[e] - mu[e]) * rs[e];
+            const float gg = gz[e] * act_grad(yh * ga[e] + be[e], slope);
+            o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
+        }
+        *(f32x4*)(dy + base + (size_t)r * C) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One wave per row; NV float4 per lane (C <= 256*NV).
+template <int NV, bool BWD>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ a,  // fwd: y   bwd: dz
+                                                      const float* __restrict__ y, float* __restrict__ out,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                      int C, float eps, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * C;
+    f32x4 v[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        ok[i] = c < C;
+        v[i] = ok[i] ? *(const f32x4*)(a + base + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float invC = 1.f / (float)C;
+    if constexpr (!BWD) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mu;
+                    q += d * d;
+                }
+            }
+        const float var = wave_sum(q) * invC;
+        const float rs = 1.f / sqrtf(var + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act_fwd((v[i][e] - mu) * rs, slope);
+                *(f32x4*)(out + base + 4 * (lane + 64 * i)) = o;
+            }
+    } else {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 yh[NV];
+        float sg = 0.f, sgy = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 yv = ok[i] ? *(const f32x4*)(y + base + 4 * (lane + 64 * i)) : (f32x4){mu, mu, mu, mu};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yh[i][e] = (yv[e] - mu) * rs;
+                v[i][e] = v[i][e] * act_grad(yh[i][e], slope);  // dz==0 on masked lanes
+                sg += v[i][e];
+                sgy += v[i][e] * yh[i][e];
+            }
+        }
+        sg = wave_sum(sg) * invC;
+        sgy = wave_sum(sgy) * invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (v[i][e] - sg - yh[i][e] * sgy);
+                *(f32x4*)(out + base + 4 * (lane + 64 * i)) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int colnorm_rows_per_block(int C) {
+    const int rpp = 256 / (C >> 2);
+    return rpp * 64;
+}
+static int check_colnorm(int G, int64_t R, int C) {
+    SDT_CHECK_ARG(G > 0 && R > 0, "non-positive dims");
+    SDT_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= MAXC, "C must be a multiple of 4 in [4,1024]");
+    return SDT_OK;
+}
+
+extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
+                                   float slope, void* stream) {
+    int rc = check_colnorm(G, R, C);
+    if (rc) return rc;
+    SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = colnorm_rows_per_block(C);
+    dim3 grid((unsigned)cdiv64(R, rpb), G);
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
+    hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rpb);
+    hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
+                       running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, int64_t rows, int C, float eps,
+                                    float slope, void* stream) {
+    int rc = check_colnorm(1, rows, C);
+    if (rc) return rc;
+    SDT_CHECK_ARG(y && z && running_mean && running_var, "null pointer");
+    const int64_t nvec = rows * (C >> 2);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(nvec, 256), 2048);
+    hipLaunchKernelGGL(colnorm_eval_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, z, gamma, beta, running_mean,
+                       running_var, rows, C, eps, slope);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                   int G, int64_t R, int C, float slope, void* stream) {
+    int rc = check_colnorm(G, R, C);
+    if (rc) return rc;
+    SDT_CHECK_ARG(dz && y && dy && sums && mean && rstd, "null pointer");
+    SDT_CHECK_ARG(!(dgamma || dbeta) || G == 1, "affine gradients need G == 1");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = colnorm_rows_per_block(C);
+    dim3 grid((unsigned)cdiv64(R, rpb), G);
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
+    hipLaunchKernelGGL((colstats_kernel<true>), grid, dim3(256), 0, s, dz, y, mean, rstd, gamma, beta, slope, sums, R, C, rpb);
+    hipLaunchKernelGGL(colnorm_apply_bwd_kernel, grid, dim3(256), 0, s, dz, y, dy, sums, mean, rstd, gamma, beta, dgamma,
+                       dbeta, R, C, rpb, slope);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+template <bool BWD>
+static int launch_rownorm(const float* a, const float* y, float* out, float* mean, float* rstd, int64_t rows, int C,
+                          float eps, float slope, hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv64(rows, 4);
+    const int nv = cdiv(C, 256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL((rownorm_kernel<1, BWD>), dim3(grid), dim3(256), 0, s, a, y, out, mean, rstd, rows, C, eps, slope); break;
+        case 2: hipLaunchKernelGGL((rownorm_kernel<2, BWD>), dim3(grid), dim3(256), 0, s, a, y, out, mean, rstd, rows, C, eps, slope); break;
+        case 3:
+        case 4: hipLaunchKernelGGL((rownorm_kernel<4, BWD>), dim3(grid), dim3(256), 0, s, a, y, out, mean, rstd, rows, C, eps, slope); break;
+        default: return SDT_ERR_UNSUPPORTED;
+    }
+    return SDT_OK;
+}
+
+extern "C" int sdt_rownorm_fwd_f32(const float* y, float* z, float* mean, float* rstd, int64_t rows, int C, float eps,
+                                   float slope, void* stream) {
+    SDT_CHECK_ARG(y && z && mean && rstd && rows > 0, "bad argument");
+    SDT_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= MAXC, "C must be a multiple of 4 in [4,1024]");
+    int rc = launch_rownorm<false>(y, nullptr, z, mean, rstd, rows, C, eps, slope, (hipStream_t)stream);
+    if (rc) return rc;
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_rownorm_bwd_f32(const float* dz, const float* y, const float* mean, const float* rstd, float* dy,
+                                   int64_t rows, int C, float slope, void* stream) {
+    SDT_CHECK_ARG(dz && y && mean && rstd && dy && rows > 0, "bad argument");
+    SDT_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= MAXC, "C must be a multiple of 4 in [4,1024]");
+    int rc = launch_rownorm<true>(dz, y, dy, (float*)mean, (float*)rstd, rows, C, 0.f, slope, (hipStream_t)stream);
+    if (rc) return rc;
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}

@@ -1,0 +1,503 @@
+"""Host-side wrappers of the libsdt_hip.so kernels: geometry builders (pure Python), thin launchers that
+marshal raw device pointers + the current HIP stream, and the ``torch.autograd.Function`` glue that lets
+the reference-shaped ``nn.Module``s in ``core.networks`` train through the hand-written kernels.
+
+Conventions
+  * activations are channels-last contiguous fp32: (B,H,W,C) / (B,T,C);
+  * conv weights keep the reference's logical shape (Cout,Cin,kh,kw) / (Cout,Cin,k) as a strided view of
+    (Cout,taps,Cin) storage (``weight_storage`` returns that storage, copying only if the layout is foreign);
+  * parameter gradients are ACCUMULATED by the kernels straight into ``param.grad`` (created zero-filled when
+    absent) -- the autograd functions return None for parameters.  This is what lets a pipeline place all
+    parameters / gradients in two flat buffers (one fused Adam launch, one all-reduce).
+There is no CPU or eager-PyTorch fallback: a non-CUDA tensor raises.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, check
+
+LEAKY_SLOPE = 0.2  # building_blocks.py:46
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm / nn.InstanceNorm defaults used at building_blocks.py:24-26,39-41
+
+
+# --------------------------------------------------------------------------------------------
+# geometry (host only; validated on CPU against F.conv2d by tests/test_geometry.py)
+# --------------------------------------------------------------------------------------------
+def out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def _geom(**kw):
+    g = ConvGeom()
+    taps = kw.pop("taps")
+    for k, v in kw.items():
+        setattr(g, k, int(v))
+    g.ntaps = len(taps)
+    assert 0 < g.ntaps <= _lib.MAX_TAPS, "kernel has too many taps (%d)" % g.ntaps
+    for i, (dy, dx, wt) in enumerate(taps):
+        g.dy[i], g.dx[i], g.wt[i] = int(dy), int(dx), int(wt)
+    return g
+
+
+def fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p):
+    """Forward conv: X (B,Hi,Wi,Cin) * W (Cout,kh*kw,Cin) -> Y (B,Ho,Wo,Cout)."""
+    Ho, Wo = out_size(Hi, kh, s, p), out_size(Wi, kw, s, p)
+    taps = [(i - p, j - p, i * kw + j) for i in range(kh) for j in range(kw)]
+    return _geom(B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Hy=Ho, Wy=Wo, Cout=Cout, sy=s, sx=s, osy=1, osx=1, ooy=0, oox=0,
+                 Tw=kh * kw, taps=taps)
+
+
+def dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, s, p):
+    """Input gradient as tap-convs of dY (B,Ho,Wo,Cout) with W^T (Cin,kh*kw,Cout) -> dX (B,Hi,Wi,Cin):
+    one geometry per output parity class (iy%s, ix%s); only taps with (iy+p-kh)%s==0 contribute, so a k4-s2
+    conv costs 4 taps per class instead of 16 masked ones."""
+    Ho, Wo = out_size(Hi, kh, s, p), out_size(Wi, kw, s, p)
+    out = []
+    for py in range(min(s, Hi)):
+        for px in range(min(s, Wi)):
+            taps = [((py + p - i) // s, (px + p - j) // s, i * kw + j)
+                    for i in range(kh) if (py + p - i) % s == 0
+                    for j in range(kw) if (px + p - j) % s == 0]
+            nqy, nqx = (Hi - py + s - 1) // s, (Wi - px + s - 1) // s
+            out.append((_geom(B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=nqy, Wo=nqx, Hy=Hi, Wy=Wi, Cout=Cin, sy=1, sx=1,
+                              osy=s, osx=s, ooy=py, oox=px, Tw=kh * kw, taps=taps) if taps else None, (py, px)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# pointer / layout helpers
+# --------------------------------------------------------------------------------------------
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("speechdrivestemplates_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback"
+                               % t.device)
+
+
+def cl(x):
+    """Logical channels-first (B,C,*spatial) -> channels-last contiguous (B,*spatial,C) (no copy when the
+    tensor already has channels-last strides)."""
+    perm = [0] + list(range(2, x.dim())) + [1]
+    return x.permute(perm).contiguous()
+
+
+def cf_view(x_cl):
+    """Channels-last (B,*spatial,C) storage -> logical channels-first view (no copy)."""
+    perm = [0, x_cl.dim() - 1] + list(range(1, x_cl.dim() - 1))
+    return x_cl.permute(perm)
+
+
+def weight_storage(w):
+    """(Cout,Cin,*k) logical weight -> (Cout,taps,Cin) contiguous storage tensor sharing memory when possible."""
+    perm = [0] + list(range(2, w.dim())) + [1]
+    s = w.permute(perm)
+    if not s.is_contiguous():
+        s = s.contiguous()
+    return s.reshape(w.shape[0], -1, w.shape[1])
+
+
+def to_weight_layout(w):
+    """Return a tensor equal to ``w`` whose memory is (Cout,*k,Cin)-contiguous (the kernels' layout)."""
+    perm = [0] + list(range(2, w.dim())) + [1]
+    inv = [0, w.dim() - 1] + list(range(1, w.dim() - 1))
+    return w.permute(perm).contiguous().permute(inv)
+
+
+def grad_buffer(p):
+    """``p.grad`` in the same physical layout as ``p`` (created zero-filled when absent)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)  # preserve_format keeps the (Cout,*k,Cin) strides
+    return p.grad
+
+
+def _ksize(w):
+    return (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, w.shape[2])
+
+
+def _as4(x_cl):
+    return x_cl if x_cl.dim() == 4 else x_cl.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------------
+# raw launchers
+# --------------------------------------------------------------------------------------------
+def conv_geom_for(x4_shape, w, stride, pad):
+    """Forward geometry of nn.Conv2d (4-D weight) or nn.Conv1d (3-D weight; the tensor is viewed as (B,1,T,C)
+    and neither stride nor padding applies to the dummy axis)."""
+    B, Hi, Wi, Cin = x4_shape
+    if w.dim() == 4:
+        return fwd_geom(B, Hi, Wi, Cin, w.shape[0], w.shape[2], w.shape[3], stride, pad)
+    k = w.shape[2]
+    Wo = out_size(Wi, k, stride, pad)
+    return _geom(B=B, Hi=1, Wi=Wi, Cin=Cin, Ho=1, Wo=Wo, Hy=1, Wy=Wo, Cout=w.shape[0], sy=1, sx=stride, osy=1, osx=1,
+                 ooy=0, oox=0, Tw=k, taps=[(0, j - pad, j) for j in range(k)])
+
+
+def dx_geoms_1d(B, Wi, Cin, Cout, k, s, p):
+    """1-D analogue of ``dx_geoms`` on (B,1,T,C) views."""
+    Wo = out_size(Wi, k, s, p)
+    out = []
+    for px in range(min(s, Wi)):
+        taps = [(0, (px + p - j) // s, j) for j in range(k) if (px + p - j) % s == 0]
+        nq = (Wi - px + s - 1) // s
+        out.append((_geom(B=B, Hi=1, Wi=Wo, Cin=Cout, Ho=1, Wo=nq, Hy=1, Wy=Wi, Cout=Cin, sy=1, sx=1, osy=1, osx=s,
+                          ooy=0, oox=px, Tw=k, taps=taps) if taps else None, (0, px)))
+    return out
+
+
+def conv_forward(x_cl, w, bias, stride, pad):
+    """x_cl (B,H,W,Cin)|(B,T,Cin); w logical (Cout,Cin,kh,kw)|(Cout,Cin,k) -> y channels-last."""
+    _req_cuda(x_cl, w, bias)
+    lib = _lib.load()
+    x4 = _as4(x_cl)
+    g = conv_geom_for(x4.shape, w, stride, pad)
+    ws = weight_storage(w)
+    y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
+    check(lib.sdt_conv_taps_f32(_p(x4), _p(ws), _p(bias), _p(y), g, _stream()))
+    return y if x_cl.dim() == 4 else y.squeeze(1)
+
+
+def conv_input_grad(gy_cl, w, x_shape, stride, pad):
+    """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights (one per output parity class)."""
+    lib = _lib.load()
+    gy4 = _as4(gy_cl)
+    one_d = w.dim() == 3
+    B, Hi, Wi, Cin = (x_shape[0], 1, x_shape[1], x_shape[2]) if one_d else x_shape
+    Cout = w.shape[0]
+    kh, kw = _ksize(w)
+    ws = weight_storage(w)
+    wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
+    st = _stream()
+    check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
+    dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
+    geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, stride, pad) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad)
+    for g, (py, px) in geoms:
+        if g is None:  # parity class that no tap reaches: the gradient is zero there
+            dx[:, py::(1 if one_d else stride), px::stride].zero_()
+            continue
+        check(lib.sdt_conv_taps_f32(_p(gy4), _p(wt), None, _p(dx), g, st))
+    return dx.squeeze(1) if one_d else dx
+
+
+def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
+    """Accumulate dW into ``w.grad`` (kernel layout)."""
+    lib = _lib.load()
+    x4, gy4 = _as4(x_cl), _as4(gy_cl)
+    g = conv_geom_for(x4.shape, w, stride, pad)
+    gw = grad_buffer(w)
+    gws = weight_storage(gw)
+    if gws.data_ptr() != gw.data_ptr():
+        raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
+    check(lib.sdt_conv_dw_f32(_p(x4), _p(gy4), _p(gws), g, _stream()))
+
+
+class ConvFn(torch.autograd.Function):
+    """nn.Conv1d/nn.Conv2d (building_blocks.py:15-22,31-38; generator.py:103) on channels-last tensors."""
+
+    @staticmethod
+    def forward(ctx, x_cl, w, bias, stride, pad):
+        x_cl = x_cl.contiguous()
+        ctx.save_for_backward(x_cl, w, bias)
+        ctx.stride, ctx.pad = stride, pad
+        return conv_forward(x_cl, w, bias, stride, pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_cl, w, bias = ctx.saved_tensors
+        gy = gy.contiguous()
+        if w.requires_grad:
+            conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
+        if bias is not None and bias.requires_grad:
+            gb = grad_buffer(bias)
+            check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
+        dx = conv_input_grad(gy, w, x_cl.shape, ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None
+
+
+class ColNormActFn(torch.autograd.Function):
+    """InstanceNorm2d (groups = batch) or training-mode BatchNorm (groups = 1) + LeakyReLU/ReLU."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope):
+        _req_cuda(y)
+        lib = _lib.load()
+        y = y.contiguous()
+        C = y.shape[-1]
+        R = y.numel() // C // groups
+        z = torch.empty_like(y)
+        sums = torch.empty(2 * groups * C, device=y.device, dtype=torch.float64)
+        mean = torch.empty(groups * C, device=y.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, _stream()))
+        ctx.save_for_backward(y, mean, rstd, gamma, beta)
+        ctx.groups, ctx.slope = groups, slope
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        y, mean, rstd, gamma, beta = ctx.saved_tensors
+        lib = _lib.load()
+        gz = gz.contiguous()
+        C = y.shape[-1]
+        R = y.numel() // C // ctx.groups
+        dy = torch.empty_like(y)
+        sums = torch.empty(2 * ctx.groups * C, device=y.device, dtype=torch.float64)
+        dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
+        db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
+        check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
+                                      ctx.groups, R, C, ctx.slope, _stream()))
+        return dy, None, None, None, None, None, None, None
+
+
+def colnorm_eval(y, gamma, beta, rmean, rvar, slope):
+    lib = _lib.load()
+    y = y.contiguous()
+    z = torch.empty_like(y)
+    C = y.shape[-1]
+    check(lib.sdt_colnorm_eval_f32(_p(y), _p(z), _p(gamma), _p(beta), _p(rmean), _p(rvar), y.numel() // C, C, BN_EPS, slope,
+                                   _stream()))
+    return z
+
+
+class RowNormActFn(torch.autograd.Function):
+    """InstanceNorm1d over the permuted tensor == LayerNorm over C per (b,t), no affine (building_blocks.py:50-51)."""
+
+    @staticmethod
+    def forward(ctx, y, slope):
+        _req_cuda(y)
+        lib = _lib.load()
+        y = y.contiguous()
+        C = y.shape[-1]
+        rows = y.numel() // C
+        z = torch.empty_like(y)
+        mean = torch.empty(rows, device=y.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(lib.sdt_rownorm_fwd_f32(_p(y), _p(z), _p(mean), _p(rstd), rows, C, BN_EPS, slope, _stream()))
+        ctx.save_for_backward(y, mean, rstd)
+        ctx.slope = slope
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        y, mean, rstd = ctx.saved_tensors
+        gz = gz.contiguous()
+        C = y.shape[-1]
+        dy = torch.empty_like(y)
+        check(_lib.load().sdt_rownorm_bwd_f32(_p(gz), _p(y), _p(mean), _p(rstd), _p(dy), y.numel() // C, C, ctx.slope, _stream()))
+        return dy, None
+
+
+class ResizeConcatFn(torch.autograd.Function):
+    """F.interpolate(x,(1,T),'bilinear').squeeze(2) ++ code (generator.py:41-42,110-111), channels-last."""
+
+    @staticmethod
+    def forward(ctx, x_cl, code, T):
+        _req_cuda(x_cl, code)
+        lib = _lib.load()
+        x_cl = x_cl.contiguous()
+        B, H, W, C = x_cl.shape
+        D = 0 if code is None else code.shape[1]
+        idx = None
+        if code is not None:
+            code = code.contiguous()
+            idx = torch.arange(B, device=x_cl.device, dtype=torch.int64)
+        out = torch.empty((B, T, C + D), device=x_cl.device, dtype=torch.float32)
+        check(lib.sdt_resize_concat_fwd_f32(_p(x_cl), _p(code), _p(idx), _p(out), B, H, W, C, T, D, _stream()))
+        ctx.dims = (B, H, W, C, T, D)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, H, W, C, T, D = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty((B, H, W, C), device=g.device, dtype=torch.float32)
+        dcode = torch.zeros((B, D), device=g.device, dtype=torch.float32) if D and ctx.needs_input_grad[1] else None
+        check(_lib.load().sdt_resize_concat_bwd_f32(_p(g), _p(idx) if dcode is not None else None, _p(dx), _p(dcode),
+                                                     B, H, W, C, T, D, _stream()))
+        return dx, dcode, None
+
+
+class UpsampleAddFn(torch.autograd.Function):
+    """F.interpolate(prev, To, 'linear') (+ skip) (generator.py:79-83, autoencoder.py:62-66), channels-last."""
+
+    @staticmethod
+    def forward(ctx, prev, skip, To):
+        _req_cuda(prev, skip)
+        prev = prev.contiguous()
+        B, Ti, C = prev.shape
+        if skip is not None:
+            skip = skip.contiguous()
+        out = torch.empty((B, To, C), device=prev.device, dtype=torch.float32)
+        check(_lib.load().sdt_upsample_add_fwd_f32(_p(prev), _p(skip), _p(out), B, Ti, To, C, _stream()))
+        ctx.dims = (B, Ti, To, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Ti, To, C = ctx.dims
+        g = g.contiguous()
+        dprev = torch.empty((B, Ti, C), device=g.device, dtype=torch.float32)
+        check(_lib.load().sdt_upsample_add_bwd_f32(_p(g), _p(dprev), B, Ti, To, C, _stream()))
+        return dprev, (g if ctx.needs_input_grad[1] else None), None
+
+
+class L1LossFn(torch.autograd.Function):
+    """(nn.L1Loss(reduction='none')(pred, gt) * lambda).mean()  (voice2pose.py:141-142)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, lam):
+        _req_cuda(pred, gt)
+        pred, gt = pred.contiguous(), gt.contiguous()
+        partial = torch.empty(256, device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        check(_lib.load().sdt_l1_loss_fwd_f32(_p(pred), _p(gt), pred.numel(), lam, _p(partial), _p(loss), _stream()))
+        ctx.save_for_backward(pred, gt)
+        ctx.lam = lam
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, gt = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        gout = gout.contiguous()
+        check(_lib.load().sdt_l1_loss_bwd_f32(_p(pred), _p(gt), _p(gout), pred.numel(), ctx.lam, _p(dp), _stream()))
+        return dp, None, None
+
+
+class CodeGatherKLFn(torch.autograd.Function):
+    """code = table[idx] and the batch-KL regulariser on it (voice2pose.py:94,147-157) in one launch.
+    Returns (code, kl, valid); kl == 0 and valid == 0 when any batch variance is exactly zero (the
+    reference skips the term on the host, voice2pose.py:154 -- here the predicate stays on the device).
+    The gradient of both outputs is scatter-ACCUMULATED into the dense ``table.grad``."""
+
+    @staticmethod
+    def forward(ctx, table, idx, lam):
+        _req_cuda(table, idx)
+        B, D = idx.shape[0], table.shape[1]
+        code = torch.empty((B, D), device=table.device, dtype=torch.float32)
+        loss = torch.empty((), device=table.device, dtype=torch.float32)
+        valid = torch.empty((), device=table.device, dtype=torch.int32)
+        idx = idx.contiguous()
+        if B > 1:
+            check(_lib.load().sdt_code_kl_fwd_f32(_p(table), _p(idx), B, D, lam, _p(code), _p(loss), _p(valid), _stream()))
+        else:  # a single sample has no batch variance (torch.var -> nan != 0 -> the reference adds a nan term)
+            raise RuntimeError("clip-code KL needs a batch of at least 2 clips")
+        ctx.save_for_backward(code, valid, idx, table)
+        ctx.lam = lam
+        ctx.mark_non_differentiable(valid)
+        return code, loss, valid
+
+    @staticmethod
+    def backward(ctx, gcode, gloss, _gvalid):
+        code, valid, idx, table = ctx.saved_tensors
+        if not table.requires_grad:
+            return None, None, None
+        lib = _lib.load()
+        B, D = code.shape
+        gt = grad_buffer(table)
+        st = _stream()
+        if gcode is not None:
+            gcode = gcode.contiguous()
+            check(lib.sdt_rows_scatter_add_f32(_p(gcode), _p(idx), _p(gt), B, D, st))
+        if gloss is not None:
+            gloss = gloss.contiguous()
+            check(lib.sdt_code_kl_bwd_f32(_p(code), _p(valid), _p(gloss), _p(idx), B, D, ctx.lam, _p(gt), st))
+        return None, None, None
+
+
+class TimeDiffFn(torch.autograd.Function):
+    """x[:,1:]-x[:,:-1] on (B,T,C) (voice2pose.py:187-188)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _req_cuda(x)
+        x = x.contiguous()
+        B, T, C = x.shape
+        y = torch.empty((B, T - 1, C), device=x.device, dtype=torch.float32)
+        check(_lib.load().sdt_time_diff_fwd_f32(_p(x), _p(y), B, T, C, _stream()))
+        ctx.dims = (B, T, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, C = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty((B, T, C), device=g.device, dtype=torch.float32)
+        check(_lib.load().sdt_time_diff_bwd_f32(_p(g), _p(dx), B, T, C, _stream()))
+        return dx
+
+
+# --------------------------------------------------------------------------------------------
+# no-grad ops
+# --------------------------------------------------------------------------------------------
+def final_metrics(pred, gt, mean, std, scale, hierarchical, want_final=True):
+    """get_final_results x2 + evaluate_step in float64 (gesture_dataset.py:193-220, voice2pose.py:412-430).
+    pred/gt (B,T,2,K) fp32; mean/std (B,2K) f64; scale (B,) f64 -> (final_pred, final_gt, metrics[2])."""
+    _req_cuda(pred, gt, mean, std, scale)
+    B, T, _, K = pred.shape
+    pred, gt = pred.contiguous(), gt.contiguous()
+    dev = pred.device
+    fp = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
+    fg = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
+    work = torch.empty(2 * B * T + 4, device=dev, dtype=torch.float64)
+    metrics = torch.empty(2, device=dev, dtype=torch.float64)
+    check(_lib.load().sdt_final_metrics_f64(_p(pred), _p(gt), _p(mean.contiguous()), _p(std.contiguous()), _p(scale.contiguous()),
+                                            1 if hierarchical else 0, B, T, K, _p(fp), _p(fg), _p(work), _p(metrics), _stream()))
+    return fp, fg, metrics
+
+
+N_FFT, WIN, HOP, N_FREQ = 512, 400, 160, 257
+
+
+def dft_basis(window):
+    """(514, 3, 160) fp32 windowed real-DFT basis: row 2f = w*cos, row 2f+1 = -w*sin (bin f) over the 400
+    window samples that sit at offset 56 in the 512-sample frame; zero beyond sample 400."""
+    w = window.detach().double().cpu()
+    k = torch.arange(WIN, dtype=torch.float64)
+    f = torch.arange(N_FREQ, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.outer(f, k + (N_FFT - WIN) // 2) / N_FFT
+    basis = torch.zeros(2 * N_FREQ, 3 * HOP, dtype=torch.float64)
+    basis[0::2, :WIN] = torch.cos(ang) * w
+    basis[1::2, :WIN] = -torch.sin(ang) * w
+    return basis.float().reshape(2 * N_FREQ, 3, HOP).contiguous()
+
+
+def mel_spectrogram(audio, basis, fb):
+    """audio (B,L) -> power mel (B, n_mels, 1+L//160)  (torchaudio 0.7 MelSpectrogram as set up at voice2pose.py:27-30)."""
+    _req_cuda(audio, basis, fb)
+    lib = _lib.load()
+    audio = audio.contiguous()
+    B, L = audio.shape
+    F = 1 + L // HOP
+    nh = F + 2
+    st = _stream()
+    hops = torch.empty((B, nh, HOP), device=audio.device, dtype=torch.float32)
+    check(lib.sdt_stft_frames_f32(_p(audio), _p(hops), B, L, nh, st))
+    g = _geom(B=B, Hi=1, Wi=nh, Cin=HOP, Ho=1, Wo=F, Hy=1, Wy=F, Cout=2 * N_FREQ, sy=1, sx=1, osy=1, osx=1, ooy=0, oox=0,
+              Tw=3, taps=[(0, 0, 0), (0, 1, 1), (0, 2, 2)])
+    spec = torch.empty((B, F, 2 * N_FREQ), device=audio.device, dtype=torch.float32)
+    check(lib.sdt_conv_taps_f32(_p(hops), _p(basis), None, _p(spec), g, st))
+    nmel = fb.shape[1]
+    mel = torch.empty((B, nmel, F), device=audio.device, dtype=torch.float32)
+    check(lib.sdt_mel_fb_f32(_p(spec), _p(fb.contiguous()), _p(mel), B, F, N_FREQ, nmel, st))
+    return mel
+
+
+def adam_step(p, g, m, v, lr_dev, state_dev, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """One torch.optim.Adam step over flat fp32 buffers (voice2pose.py:249-279,302-304)."""
+    _req_cuda(p, g, m, v, lr_dev, state_dev)
+    check(_lib.load().sdt_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), beta1, beta2, eps, weight_decay,
+                                        _p(state_dev), _stream()))

@@ -1,0 +1,339 @@
+"""GPU parity tests, one per kernel family: each libsdt_hip.so entry point (called through the C ABI via
+speechdrivestemplates_amd.ops) against a float64 torch-CPU statement of the same reference operator on
+seeded inputs.  Tolerances are relative to the reference's max magnitude and written next to each check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), "non-finite values in kernel output"
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def check(name, got, ref, tol):
+    e = rel_err(got, ref)
+    print("  %-40s rel-max-err %.3e (tol %.1e)" % (name, e, tol))
+    assert e < tol, "%s: %.3e >= %.1e" % (name, e, tol)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from speechdrivestemplates_amd import ops as o
+    return o
+
+
+# every distinct conv shape on the hot path: (tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p) -- generator.py:15-30
+CONV2D = [
+    ("L0 1->64 k3", 2, 80, 427, 1, 64, 3, 3, 1, 1),
+    ("L1 64->64 k4s2", 2, 80, 427, 64, 64, 4, 4, 2, 1),
+    ("L2 64->128 k3", 2, 40, 213, 64, 128, 3, 3, 1, 1),
+    ("L3 128->128 k4s2", 2, 40, 213, 128, 128, 4, 4, 2, 1),
+    ("L4 128->256 k3", 2, 20, 106, 128, 256, 3, 3, 1, 1),
+    ("L5 256->256 k4s2", 2, 20, 106, 256, 256, 4, 4, 2, 1),
+    ("L6 256->256 k3", 2, 10, 53, 256, 256, 3, 3, 1, 1),
+    ("L7 256->256 k(6,3)p0", 2, 10, 53, 256, 256, 6, 3, 1, 0),
+    ("big-M 128x128 tile", 8, 40, 213, 64, 128, 3, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV2D, ids=[c[0] for c in CONV2D])
+def test_conv2d(ops, case):
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd = ops.cl(x.float()).to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    assert ops.weight_storage(wd).data_ptr() == wd.data_ptr()
+    yd = ops.ConvFn.apply(xd, wd, None, s, p)
+    yd.backward(ops.cl(gy.float()).to(DEV))
+    torch.cuda.synchronize()
+    check(tag + " fwd", ops.cf_view(yd), y, 2e-5)
+    check(tag + " dX", ops.cf_view(xd.grad), xr.grad, 2e-5)
+    check(tag + " dW", wd.grad, wr.grad, 5e-5)
+    # a second backward accumulates into .grad (standard autograd semantics)
+    yd2 = ops.ConvFn.apply(xd.detach(), wd, None, s, p)
+    yd2.backward(ops.cl(gy.float()).to(DEV))
+    check(tag + " dW accumulate", wd.grad, 2 * wr.grad, 5e-5)
+
+
+CONV1D = [  # (tag, B, T, Cin, Cout, k, s, p, bias)
+    ("e0 288->256 k3", 4, 64, 288, 256, 3, 1, 1, False),
+    ("e2 256->256 k4s2", 4, 64, 256, 256, 4, 2, 1, False),
+    ("e6 T4->2", 4, 4, 256, 256, 4, 2, 1, False),
+    ("d5 T4 k3", 4, 4, 256, 256, 3, 1, 1, False),
+    ("head 256->242 k1 bias", 4, 64, 256, 242, 1, 1, 0, True),
+    ("pose-enc 242->256 k3", 4, 64, 242, 256, 3, 1, 1, False),
+    ("pose-enc 256->64 k4s2", 4, 4, 256, 64, 4, 2, 1, False),
+    ("disc 242->256 k4s2 T63", 4, 63, 242, 256, 4, 2, 1, False),
+    ("disc 512->1024 k3 T15", 4, 15, 512, 1024, 3, 1, 1, False),
+    ("disc head 1024->1 k3 bias", 4, 15, 1024, 1, 3, 1, 1, True),
+    ("ae d5 32->256 k3 T4", 4, 4, 32, 256, 3, 1, 1, False),
+    ("T odd 37 k4s2", 3, 37, 256, 256, 4, 2, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV1D, ids=[c[0] for c in CONV1D])
+def test_conv1d(ops, case):
+    tag, B, T, Cin, Cout, k, s, p, has_bias = case
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, T, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, generator=g, dtype=torch.float64) * (2.0 / (Cin * k)) ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) if has_bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    y = F.conv1d(xr, wr, br, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd = ops.cl(x.float()).to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    bd = torch.nn.Parameter(b.float().to(DEV)) if has_bias else None
+    yd = ops.ConvFn.apply(xd, wd, bd, s, p)
+    yd.backward(ops.cl(gy.float()).to(DEV))
+    torch.cuda.synchronize()
+    check(tag + " fwd", ops.cf_view(yd), y, 2e-5)
+    check(tag + " dX", ops.cf_view(xd.grad), xr.grad, 2e-5)
+    check(tag + " dW", wd.grad, wr.grad, 5e-5)
+    if has_bias:
+        check(tag + " dbias", bd.grad, br.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 80, 427, 64), (2, 5, 51, 256), (3, 20, 106, 128)])
+def test_instance_norm2d_leaky(ops, shape):
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(C + H)
+    y = (torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 3 + 1.5).requires_grad_(True)
+    z = F.leaky_relu(F.instance_norm(y, eps=1e-5), 0.2)
+    gz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(gz)
+    yd = ops.cl(y.detach().float()).to(DEV).requires_grad_(True)
+    zd = ops.ColNormActFn.apply(yd, None, None, None, None, None, B, 0.2)
+    zd.backward(ops.cl(gz.float()).to(DEV))
+    check("IN2d fwd %s" % (shape,), ops.cf_view(zd), z, 1e-5)
+    check("IN2d bwd %s" % (shape,), ops.cf_view(yd.grad), y.grad, 2e-5)
+
+
+@pytest.mark.parametrize("slope", [0.2, 0.0])
+@pytest.mark.parametrize("shape", [(4, 64, 256), (4, 2, 64), (2, 40 * 213, 64), (4, 15, 1024)])
+def test_batch_norm_train_act(ops, shape, slope):
+    B, T, C = shape
+    g = torch.Generator().manual_seed(C + T)
+    y = (torch.randn(B, C, T, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    u = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    z = F.leaky_relu(u, slope) if slope else F.relu(u)
+    gz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(gz)
+    yd = ops.cl(y.detach().float()).to(DEV).requires_grad_(True)
+    gd = torch.nn.Parameter(gamma.detach().float().to(DEV))
+    bd = torch.nn.Parameter(beta.detach().float().to(DEV))
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    zd = ops.ColNormActFn.apply(yd, gd, bd, rmd, rvd, nbt, 1, slope)
+    zd.backward(ops.cl(gz.float()).to(DEV))
+    tag = "BN %s slope %.1f" % (shape, slope)
+    check(tag + " fwd", ops.cf_view(zd), z, 1e-5)
+    check(tag + " running_mean", rmd, rm, 1e-5)
+    check(tag + " running_var", rvd, rv, 1e-5)
+    assert int(nbt.item()) == 1
+    check(tag + " dy", ops.cf_view(yd.grad), y.grad, 5e-5)
+    check(tag + " dgamma", gd.grad, gamma.grad, 5e-5)
+    check(tag + " dbeta", bd.grad, beta.grad, 5e-5)
+    # eval mode uses the running statistics
+    ze = F.leaky_relu(F.batch_norm(y.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5), slope)
+    zde = ops.colnorm_eval(yd.detach(), gd.detach(), bd.detach(), rmd, rvd, slope)
+    check(tag + " eval", ops.cf_view(zde), ze, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 256), (4, 2, 256), (3, 7, 512), (2, 5, 64)])
+def test_rownorm_leaky(ops, shape):
+    B, T, C = shape
+    g = torch.Generator().manual_seed(C * T)
+    y = (torch.randn(B, C, T, generator=g, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
+    # the reference's InstanceNorm1d on the permuted tensor (building_blocks.py:50-51)
+    z = F.leaky_relu(F.instance_norm(y.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1), 0.2)
+    gz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(gz)
+    yd = ops.cl(y.detach().float()).to(DEV).requires_grad_(True)
+    zd = ops.RowNormActFn.apply(yd, 0.2)
+    zd.backward(ops.cl(gz.float()).to(DEV))
+    check("rownorm fwd %s" % (shape,), ops.cf_view(zd), z, 1e-5)
+    check("rownorm bwd %s" % (shape,), ops.cf_view(yd.grad), y.grad, 2e-5)
+
+
+@pytest.mark.parametrize("T,D", [(64, 32), (64, 0), (40, 32), (360, 32)])
+def test_resize_concat(ops, T, D):
+    B, H, W, C = 3, 5, 51 if T != 360 else 283, 256
+    g = torch.Generator().manual_seed(T + D)
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    code = torch.randn(B, D, generator=g, dtype=torch.float64, requires_grad=True) if D else None
+    r = F.interpolate(x, (1, T), mode="bilinear").squeeze(2)
+    if D:
+        r = torch.cat([r, code.unsqueeze(2).repeat(1, 1, T)], 1)
+    gr = torch.randn(r.shape, generator=g, dtype=torch.float64)
+    r.backward(gr)
+    xd = ops.cl(x.detach().float()).to(DEV).requires_grad_(True)
+    cd = code.detach().float().to(DEV).requires_grad_(True) if D else None
+    rd = ops.ResizeConcatFn.apply(xd, cd, T)
+    rd.backward(ops.cl(gr.float()).to(DEV))
+    check("resize+concat fwd T%d D%d" % (T, D), ops.cf_view(rd), r, 1e-6)
+    check("resize bwd dx", ops.cf_view(xd.grad), x.grad, 1e-5)
+    if D:
+        check("resize bwd dcode", cd.grad, code.grad, 1e-5)
+
+
+@pytest.mark.parametrize("Ti,To,skip", [(2, 4, True), (32, 64, True), (4, 8, False), (45, 90, True), (10, 23, True)])
+def test_upsample_add(ops, Ti, To, skip):
+    B, C = 3, 256
+    g = torch.Generator().manual_seed(Ti + To)
+    prev = torch.randn(B, C, Ti, generator=g, dtype=torch.float64, requires_grad=True)
+    sk = torch.randn(B, C, To, generator=g, dtype=torch.float64, requires_grad=True) if skip else None
+    r = F.interpolate(prev, To, mode="linear")
+    if skip:
+        r = r + sk
+    gr = torch.randn(r.shape, generator=g, dtype=torch.float64)
+    r.backward(gr)
+    pd = ops.cl(prev.detach().float()).to(DEV).requires_grad_(True)
+    sd = ops.cl(sk.detach().float()).to(DEV).requires_grad_(True) if skip else None
+    rd = ops.UpsampleAddFn.apply(pd, sd, To)
+    rd.backward(ops.cl(gr.float()).to(DEV))
+    check("upsample+add fwd %d->%d" % (Ti, To), ops.cf_view(rd), r, 1e-6)
+    check("upsample bwd dprev", ops.cf_view(pd.grad), prev.grad, 1e-5)
+    if skip:
+        check("upsample bwd dskip", ops.cf_view(sd.grad), sk.grad, 1e-6)
+
+
+def test_l1_loss(ops):
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(4, 64, 2, 121, generator=g, dtype=torch.float64, requires_grad=True)
+    gt = torch.randn(4, 64, 2, 121, generator=g, dtype=torch.float64)
+    gt[0, 0, 0, :5] = pred.detach()[0, 0, 0, :5]  # exact ties: sign(0) = 0
+    loss = (torch.abs(pred - gt) * 1.0).mean()
+    (loss * 1.7).backward()
+    pd = pred.detach().float().to(DEV).requires_grad_(True)
+    ld = ops.L1LossFn.apply(pd, gt.float().to(DEV), 1.0)
+    (ld * 1.7).backward()
+    check("L1 loss", ld, loss, 1e-6)
+    check("L1 grad", pd.grad, pred.grad, 1e-6)
+
+
+def test_code_gather_kl(ops):
+    from oracle import sdt_oracle as O
+    g = torch.Generator().manual_seed(6)
+    N, B, D = 50, 8, 32
+    table = torch.randn(N, D, generator=g, dtype=torch.float64) * 0.7
+    idx = torch.tensor([3, 17, 4, 49, 0, 21, 8, 30])
+    tr = table.clone().requires_grad_(True)
+    code = tr[idx]
+    kl = O.clip_code_kl(code, 0.1)
+    gcode = torch.randn(B, D, generator=g, dtype=torch.float64)
+    (kl * 1.3 + (code * gcode).sum()).backward()
+    td = torch.nn.Parameter(table.float().to(DEV))
+    cd, kd, valid = ops.CodeGatherKLFn.apply(td, idx.to(DEV), 0.1)
+    (kd * 1.3 + (cd * gcode.float().to(DEV)).sum()).backward()
+    assert int(valid.item()) == 1
+    check("code gather", cd, code, 1e-7)
+    check("code KL", kd, kl, 1e-5)
+    check("code table grad (dense)", td.grad, tr.grad, 1e-5)
+    # zero-variance column -> term skipped: loss 0, no KL gradient (voice2pose.py:154)
+    t0 = torch.zeros(N, D)
+    td0 = torch.nn.Parameter(t0.to(DEV))
+    c0, k0, v0 = ops.CodeGatherKLFn.apply(td0, idx.to(DEV), 0.1)
+    (k0 + (c0 * gcode.float().to(DEV)).sum()).backward()
+    assert int(v0.item()) == 0 and float(k0.item()) == 0.0
+    ref = torch.zeros(N, D, dtype=torch.float64)
+    ref[idx] = gcode
+    check("zero-var: only gather grad", td0.grad, ref, 1e-7)
+    assert O.clip_code_kl(t0[idx], 0.1) is None
+
+
+def test_final_metrics(ops):
+    from oracle import sdt_oracle as O
+    batch = O.make_batch(4, 16, step=2, seed=3)
+    g = torch.Generator().manual_seed(7)
+    pred = torch.randn(4, 64, 2, 121, generator=g)
+    st = batch["speaker_stat"]
+    for hier in (True, False):
+        fp = O.get_final_results(pred.clone(), st, hier)
+        fg = O.get_final_results(batch["poses"].clone(), st, hier)
+        m = O.evaluate_step(fp, fg)
+        dfp, dfg, dm = ops.final_metrics(pred.to(DEV), batch["poses"].to(DEV), st["mean"].to(DEV), st["std"].to(DEV),
+                                         st["scale_factor"].to(DEV), hier)
+        assert dfp.dtype == torch.float64
+        check("final pred hier=%s" % hier, dfp, fp, 1e-12)
+        check("final gt", dfg, fg, 1e-12)
+        check("L2_dist", dm[0], m["L2_dist"], 1e-10)
+        check("lip_sync_error_n", dm[1], m["lip_sync_error_n"], 1e-10)
+
+
+def test_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(8)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd = torch.zeros(((n + 3) // 4) * 4, device=DEV)
+    pd[:n] = p0.to(DEV)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    lr = torch.tensor([1e-3], device=DEV)
+    state = torch.zeros(2, dtype=torch.int64, device=DEV)
+    for step in range(4):
+        gr = torch.randn(n, generator=g) * (0.0 if step == 2 else 1.0)
+        pr.grad = gr.double()
+        opt.step()
+        gd = torch.zeros_like(pd)
+        gd[:n] = gr.to(DEV)
+        ops.adam_step(pd[:n], gd[:n], m[:n], v[:n], lr, state)
+    assert int(state[0].item()) == 4
+    check("Adam params after 4 steps", pd[:n], pr, 1e-6)
+
+
+def test_mel_frontend(ops):
+    from oracle import sdt_oracle as O
+    batch = O.make_batch(3, 16, step=0, seed=1)
+    audio = batch["audio"]
+    t = torch.arange(audio.shape[1]) / 16000.0
+    audio[1] += 0.3 * torch.sin(2 * np.pi * (200 + 1500 * t) * t)  # chirp
+    ref = O.mel_spectrogram(audio.double(), O.mel_window(torch.float64), O.mel_filterbank(torch.float64))
+    basis = ops.dft_basis(O.mel_window()).to(DEV)
+    mel = ops.mel_spectrogram(audio.to(DEV), basis, O.mel_filterbank().to(DEV))
+    assert mel.shape == (3, 80, 427)
+    check("mel vs float64 restatement", mel, ref, 2e-5)
+    check("mel vs fp32 torch.stft oracle", mel, O.mel_spectrogram(audio), 2e-5)
+    # odd length (demo path): F = 1 + L // 160
+    a2 = audio[:, :50001]
+    mel2 = ops.mel_spectrogram(a2.to(DEV), basis, O.mel_filterbank().to(DEV))
+    check("mel L=50001", mel2, O.mel_spectrogram(a2.double(), O.mel_window(torch.float64), O.mel_filterbank(torch.float64)), 2e-5)
+
+
+def test_time_diff(ops):
+    x = torch.randn(3, 64, 242, dtype=torch.float64, requires_grad=True)
+    y = x[:, 1:] - x[:, :-1]
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    yd = ops.TimeDiffFn.apply(xd)
+    yd.backward(gy.float().to(DEV))
+    check("time diff fwd", yd, y, 1e-6)
+    check("time diff bwd", xd.grad, x.grad, 1e-6)
+
+
+def test_error_reporting(ops):
+    # the C ABI returns a status + message; the binding raises (reference convention: Python exceptions)
+    x = torch.zeros(2, 4, 6, device=DEV)
+    with pytest.raises(RuntimeError, match="libsdt_hip"):
+        ops.RowNormActFn.apply(x, 0.2)  # C=6 is not a multiple of 4
