@@ -131,9 +131,10 @@ int sdt_final_metrics_f64(const float* pred, const float* gt, const double* mean
 /* torch.optim.Adam(betas, eps, weight_decay) step over a flat fp32 buffer (voice2pose.py:249-279,302-304).
  * lr_dev: device float (so that LR schedules do not invalidate a captured hipGraph);
  * state_dev: 16 device bytes {int64 step; float bc1; float bc2_sqrt}, zero-initialised by the caller;
- * the call increments `step` on the device and derives the bias corrections from it. */
+ * the call increments `step` on the device and derives the bias corrections from it.
+ * grad_scale multiplies g on load (1/world_size after a summing all-reduce: DDP's gradient averaging). */
 int sdt_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
-                      float beta2, float eps, float weight_decay, void* state_dev, void* stream);
+                      float beta2, float eps, float weight_decay, float grad_scale, void* state_dev, void* stream);
 
 /*
  * Mel front end (torchaudio 0.7 MelSpectrogram as configured at voice2pose.py:27-30):

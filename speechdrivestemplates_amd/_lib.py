@@ -42,7 +42,7 @@ SIGNATURES = {
     "sdt_code_kl_fwd_f32": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
     "sdt_code_kl_bwd_f32": [_p, _p, _p, _p, _i, _i, _f, _p, _p],
     "sdt_final_metrics_f64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
-    "sdt_adam_step_f32": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _p],
+    "sdt_adam_step_f32": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p, _p],
     "sdt_stft_frames_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_mel_fb_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _p],

@@ -1,0 +1,69 @@
+"""ConvNormRelu over the gfx950 kernels -- same constructor, state_dict keys and forward contract as the
+reference block (core/networks/building_blocks.py:4-55): Conv{1,2}d(bias=False) -> BatchNorm | InstanceNorm
+-> LeakyReLU(0.2) | ReLU, Kaiming-normal weights.
+
+``self.conv`` / ``self.norm`` are torch modules used purely as PARAMETER CONTAINERS (so checkpoints written
+by the reference load with strict=True); their forward() is never called.  The convolution weight keeps its
+logical (Cout,Cin,*k) shape but lives in (Cout,*k,Cin) memory, the layout the implicit-GEMM kernels read.
+Internally tensors are channels-last; ``forward`` accepts/returns the reference's channels-first logical
+shapes as zero-copy views, ``forward_cl`` is the channels-last fast path used between blocks.
+"""
+import torch
+from torch import nn
+
+from ... import ops
+
+
+class ConvNormRelu(nn.Module):
+    def __init__(self, conv_type='1d', in_channels=3, out_channels=64, downsample=False,
+                 kernel_size=None, stride=None, padding=None, norm='BN', leaky=False):
+        super().__init__()
+        if kernel_size is None:  # the two stock shapes, building_blocks.py:8-12
+            kernel_size, stride, padding = (4, 2, 1) if downsample else (3, 1, 1)
+        if conv_type == '2d':
+            conv_cls, bn_cls, in_cls = nn.Conv2d, nn.BatchNorm2d, nn.InstanceNorm2d
+        elif conv_type == '1d':
+            conv_cls, bn_cls, in_cls = nn.Conv1d, nn.BatchNorm1d, nn.InstanceNorm1d
+        else:
+            raise NotImplementedError(conv_type)
+        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride, padding, bias=False)
+        if norm == 'BN':
+            self.norm = bn_cls(out_channels)
+        elif norm == 'IN':
+            self.norm = in_cls(out_channels)
+        else:
+            raise NotImplementedError
+        nn.init.kaiming_normal_(self.conv.weight)
+        self.conv.weight.data = ops.to_weight_layout(self.conv.weight.data)
+        self.conv_type, self.norm_type = conv_type, norm
+        self.stride, self.padding = int(stride), int(padding)
+        self.slope = ops.LEAKY_SLOPE if leaky else 0.0
+
+    def forward_cl(self, x_cl):
+        """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last."""
+        y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding)
+        if self.norm_type == 'IN':
+            if self.conv_type == '2d':  # per-(b,c) statistics over H*W
+                return ops.ColNormActFn.apply(y, None, None, None, None, None, y.shape[0], self.slope)
+            return ops.RowNormActFn.apply(y, self.slope)  # InstanceNorm1d on the permuted tensor == norm over C
+        n = self.norm
+        if self.training:
+            return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
+                                          self.slope)
+        if torch.is_grad_enabled() and y.requires_grad:
+            raise RuntimeError("eval-mode BatchNorm is an inference-only path in this engine (wrap in torch.no_grad())")
+        return ops.colnorm_eval(y, n.weight, n.bias, n.running_mean, n.running_var, self.slope)
+
+    def forward(self, x):
+        return ops.cf_view(self.forward_cl(ops.cl(x)))
+
+
+def conv_head(x_cl, conv):
+    """Plain nn.Conv1d with bias (generator.py:103, discriminator.py:16, autoencoder.py:56) on channels-last data."""
+    return ops.ConvFn.apply(x_cl, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+
+
+def make_head(cin, cout, k, stride=1, padding=0):
+    conv = nn.Conv1d(cin, cout, kernel_size=k, stride=stride, padding=padding, bias=True)
+    conv.weight.data = ops.to_weight_layout(conv.weight.data)
+    return conv

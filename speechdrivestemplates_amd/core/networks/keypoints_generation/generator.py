@@ -1,0 +1,88 @@
+"""Generator networks with the reference's class names, constructor (cfg), forward signatures and
+state_dict keys (core/networks/keypoints_generation/generator.py:8-117), built from layer tables and run
+channels-last through the gfx950 kernels."""
+from torch import nn
+
+from .... import ops
+from ..building_blocks import ConvNormRelu, conv_head, make_head
+
+# (cin, cout, kernel, stride, padding) of the 8-layer mel encoder, two blocks per stage (generator.py:15-30)
+_SPEC_ENCODER = (
+    ((1, 64, None, None, None, False), (64, 64, None, None, None, True)),
+    ((64, 128, None, None, None, False), (128, 128, None, None, None, True)),
+    ((128, 256, None, None, None, False), (256, 256, None, None, None, True)),
+    ((256, 256, None, None, None, False), (256, 256, (6, 3), 1, 0, False)),
+)
+_UNET_DOWN = (False, False, True, True, True, True, True)  # e0..e6, generator.py:53-62
+
+
+class AudioEncoder(nn.Module):
+    def __init__(self, cfg) -> None:
+        super().__init__()
+        leaky, norm = cfg.VOICE2POSE.GENERATOR.LEAKY_RELU, cfg.VOICE2POSE.GENERATOR.NORM
+        self.specgram_encoder_2d = nn.Sequential(*[
+            nn.Sequential(*[ConvNormRelu('2d', ci, co, downsample=down, kernel_size=k, stride=s, padding=p, norm=norm, leaky=leaky)
+                            for (ci, co, k, s, p, down) in stage])
+            for stage in _SPEC_ENCODER])
+
+    def encode_cl(self, mel):
+        """mel (B,n_mels,F) -> (B,H',W',256) channels-last feature map (H'=5 for 80 mels)."""
+        x = mel.unsqueeze(-1)  # (B,H,W,1): the mel image is already channels-last with C=1
+        for stage in self.specgram_encoder_2d:
+            for block in stage:
+                x = block.forward_cl(x)
+        return x
+
+    def forward(self, x, num_frames):
+        """(B,80,F) -> (B,256,num_frames), generator.py:39-43."""
+        return ops.cf_view(ops.ResizeConcatFn.apply(self.encode_cl(x), None, int(num_frames)))
+
+
+class UNet_1D(nn.Module):
+    def __init__(self, cfg) -> None:
+        super().__init__()
+        leaky, norm = cfg.VOICE2POSE.GENERATOR.LEAKY_RELU, cfg.VOICE2POSE.GENERATOR.NORM
+        code_dim = cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION
+        for i, down in enumerate(_UNET_DOWN):
+            cin = 256 + code_dim if (i == 0 and code_dim is not None) else 256
+            setattr(self, 'e%d' % i, ConvNormRelu('1d', cin, 256, downsample=down, norm=norm, leaky=leaky))
+        for i in (5, 4, 3, 2, 1):
+            setattr(self, 'd%d' % i, ConvNormRelu('1d', 256, 256, downsample=False, norm=norm, leaky=leaky))
+
+    def forward_cl(self, x):
+        """(B,T,256[+D]) -> (B,T,256), generator.py:70-85: encoder pyramid, then conv(linear-upsample + skip)."""
+        skips = []
+        for i in range(7):
+            x = getattr(self, 'e%d' % i).forward_cl(x)
+            skips.append(x)
+        for i in (5, 4, 3, 2, 1):
+            skip = skips[i]
+            x = getattr(self, 'd%d' % i).forward_cl(ops.UpsampleAddFn.apply(x, skip, skip.shape[1]))
+        return x
+
+    def forward(self, x):
+        return ops.cf_view(self.forward_cl(ops.cl(x)))
+
+
+class SequenceGeneratorCNN(nn.Module):
+    def __init__(self, cfg) -> None:
+        super().__init__()
+        self.cfg = cfg
+        leaky, norm = cfg.VOICE2POSE.GENERATOR.LEAKY_RELU, cfg.VOICE2POSE.GENERATOR.NORM
+        self.audio_encoder = AudioEncoder(cfg)
+        self.unet = UNet_1D(cfg)
+        self.decoder = nn.Sequential(
+            *[ConvNormRelu('1d', 256, 256, downsample=False, norm=norm, leaky=leaky) for _ in range(4)],
+            make_head(256, cfg.DATASET.NUM_LANDMARKS * 2, 1))
+
+    def forward(self, x, num_frames, code=None):
+        """mel (B,80,F), code (B,D)|None -> poses (B,num_frames,2,K), generator.py:106-117."""
+        num_frames = int(num_frames)
+        feat = self.audio_encoder.encode_cl(x)
+        use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
+        h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
+        h = self.unet.forward_cl(h)
+        for block in list(self.decoder)[:4]:
+            h = block.forward_cl(h)
+        h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
+        return h.reshape(-1, num_frames, 2, self.cfg.DATASET.NUM_LANDMARKS)

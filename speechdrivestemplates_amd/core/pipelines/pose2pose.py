@@ -1,0 +1,81 @@
+"""Pose2Pose (pose-sequence VAE) pipeline on the gfx950 engine -- reference core/pipelines/pose2pose.py:20-169:
+L1 reconstruction + analytic KL on (mu, logvar), one Adam, per-clip code buffers written every step."""
+import torch
+from torch import nn
+
+from ... import dp, ops
+from ...mel import MelSpectrogram
+from ...optim import FlatAdam
+from ..networks import get_model
+from .trainer import Trainer
+from .voice2pose import _MultiStepLR
+
+
+class Pose2PoseModel(nn.Module):
+    def __init__(self, cfg, state_dict=None, num_train_samples=None, rank=0) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.mel_transfm = MelSpectrogram(win_length=400, hop_length=160, n_fft=512, f_min=55, f_max=7500.0, n_mels=80)
+        self.ae = get_model(cfg.POSE2POSE.AUTOENCODER.NAME)(cfg)
+        if num_train_samples is None:
+            assert state_dict is not None, 'No state_dict available, while no dataset is configured.'
+            num_train_samples = state_dict['module.clip_code_mu'].shape[0]
+        d = cfg.POSE2POSE.AUTOENCODER.CODE_DIM
+        self.register_buffer('clip_code_mu', torch.zeros([num_train_samples, d]))
+        self.register_buffer('clip_code_logvar', torch.zeros([num_train_samples, d]))
+
+    def forward(self, batch, return_loss=True, is_testing=False, interpolation_coeff=None):
+        dev = self.clip_code_mu.device
+        poses_gt = batch['poses'].to(dev, non_blocking=True) if return_loss else None
+        num_frames = int(batch['num_frames'][0])
+        if not return_loss:
+            raise NotImplementedError('Pose2Pose demo decoding from DEMO.CODE_PATH is not part of the training hot path')
+        # the reference computes the mel spectrogram here and discards it (pose2pose.py:48, autoencoder.py:79); skipped
+        pred, mu, logvar = self.ae(poses_gt, num_frames)
+        reg = ops.L1LossFn.apply(pred, poses_gt, float(self.cfg.POSE2POSE.LAMBDA_REG))
+        kl = 0.5 * (-logvar + mu ** 2 + torch.exp(logvar) - 1).mean() * self.cfg.POSE2POSE.LAMBDA_KL  # pose2pose.py:76
+        losses = {'reg_loss': reg, 'kl_loss': kl, 'loss': reg + kl}
+        return losses, {'poses_pred_batch': pred, 'poses_gt_batch': poses_gt, 'clip_code_mu': mu, 'clip_code_logvar': logvar}
+
+
+class Pose2Pose(Trainer):
+    def __init__(self, cfg) -> None:
+        super().__init__(cfg)
+
+    def setup_model(self, cfg, state_dict=None):
+        self.model = Pose2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank()).cuda()
+        if state_dict is not None:
+            self.model.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()})
+
+    def setup_optimizer(self, checkpoint=None, last_epoch=-1):
+        opt = FlatAdam(self.model.ae.parameters(), lr=self.cfg.TRAIN.LR, weight_decay=self.cfg.TRAIN.WD)
+        if checkpoint is not None:
+            opt.load_state_dict(checkpoint['optimizer_state_dict'])
+        self.optimizers['optimizer'] = opt
+        if self.cfg.TRAIN.LR_SCHEDULER:
+            E = self.cfg.TRAIN.NUM_EPOCHS
+            self.schedulers['scheduler'] = _MultiStepLR(opt, [E - 10, E - 2], 0.1, last_epoch)
+        self.reducer = dp.GradReducer(self.optimizers.values())
+
+    def train_step(self, batch, t_step, global_step, epoch):
+        dev = self.model.clip_code_mu.device
+        losses, results = self.model(batch)
+        stat = batch['speaker_stat']
+        _, _, metrics = ops.final_metrics(results['poses_pred_batch'].detach(), results['poses_gt_batch'], stat['mean'].to(dev),
+                                          stat['std'].to(dev), stat['scale_factor'].to(dev),
+                                          bool(self.cfg.DATASET.HIERARCHICAL_POSE), False)
+        idx = batch['clip_index'].to(dev)
+        self.model.clip_code_mu[idx] = results['clip_code_mu'].detach()  # pose2pose.py:135-137
+        self.model.clip_code_logvar[idx] = results['clip_code_logvar'].detach()
+        losses['L2_dist'], losses['lip_sync_error_n'] = metrics[0], metrics[1]
+        opt = self.optimizers['optimizer']
+        opt.zero_grad()
+        losses['loss'].backward()
+        self.reducer.all_reduce([opt])
+        opt.step()
+        self.last_losses = losses
+        if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
+            if self.cfg.SYS.DISTRIBUTED:
+                dp.reduce_scalars(losses)
+            if self.is_master_process():
+                self.logger_writer_step('TRAIN', losses, t_step, epoch, global_step)

@@ -1,0 +1,207 @@
+"""Training-loop shell around ``train_step`` (core/pipelines/trainer.py): rank helpers (:29-45), dataset /
+dataloader setup (:64-145), experiment setup with resume / pretrain (:162-224), step logging (:242-263),
+checkpoint wire format (:305-321), epoch loop (:367-405) and validation (:407-427).  TensorBoard / video
+output of the reference are out of scope; scalars go to the Python logger."""
+import logging
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from ..datasets import get_dataset
+
+
+def _collate_stat(samples):
+    """default_collate of the nested speaker_stat dict gives float64 (B,242)/(B,) tensors (gesture_dataset.py:107-119)."""
+    return torch.utils.data.default_collate(samples)
+
+
+class Trainer(object):
+    def __init__(self, cfg) -> None:
+        self.cfg = cfg
+        self.model = None
+        self.optimizers = {}
+        self.schedulers = {}
+        self.train_dataloader = None
+        self.test_dataloader = None
+        self.train_dataset = None
+        self.test_dataset = None
+        self.num_train_samples = None
+        self.result_saving_interval_train = 1 << 60
+        self.base_path = None
+        self.step_tic = time.time()
+        if not torch.cuda.is_available():
+            raise RuntimeError('this engine needs an AMD GPU (no CPU fallback); torch.cuda.is_available() is False')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', self.get_rank() % max(1, torch.cuda.device_count()))))
+
+    # -- process-group helpers (trainer.py:29-45) ---------------------------------------------------------
+    def get_rank(self):
+        return torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+
+    def get_world_size(self):
+        return torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    def is_master_process(self):
+        return self.get_rank() == 0
+
+    # -- data ------------------------------------------------------------------------------------------
+    def setup_dataset(self, cfg, split, demo_input=None):
+        ws = self.get_world_size()
+        ds_cls = get_dataset(cfg.DATASET.NAME)
+        if split == 'train':
+            self.train_dataset = ds_cls(cfg.DATASET.ROOT_DIR if cfg.DATASET.NAME == 'GestureDataset' else None,
+                                        cfg.DATASET.SPEAKER, 'train', cfg)
+            sampler = torch.utils.data.distributed.DistributedSampler(self.train_dataset) if cfg.SYS.DISTRIBUTED else None
+            self.train_sampler = sampler
+            self.train_dataloader = DataLoader(self.train_dataset, batch_size=cfg.TRAIN.BATCH_SIZE // ws, shuffle=sampler is None,
+                                               num_workers=cfg.SYS.NUM_WORKERS // ws, sampler=sampler, drop_last=True)
+            self.num_train_samples = len(self.train_dataset)
+            self.num_train_batches = len(self.train_dataloader)
+            self.result_saving_interval_train = max(1, self.num_train_batches // cfg.TRAIN.NUM_RESULT_SAMPLE)
+            if cfg.TRAIN.VALIDATE:
+                self._setup_eval(cfg, ds_cls, 'val', ws)
+        elif split == 'test':
+            self.num_train_samples = None
+            self._setup_eval(cfg, ds_cls, 'val', ws)
+        else:
+            raise Exception('Unknown data split.')
+
+    def _setup_eval(self, cfg, ds_cls, split, ws):
+        self.test_dataset = ds_cls(cfg.DATASET.ROOT_DIR if cfg.DATASET.NAME == 'GestureDataset' else None,
+                                   cfg.DATASET.SPEAKER, split, cfg)
+        sampler = torch.utils.data.distributed.DistributedSampler(self.test_dataset, shuffle=False) if cfg.SYS.DISTRIBUTED else None
+        self.test_dataloader = DataLoader(self.test_dataset, batch_size=cfg.TEST.BATCH_SIZE // ws, shuffle=False,
+                                          num_workers=cfg.SYS.NUM_WORKERS // ws, sampler=sampler)
+        self.num_test_samples = len(self.test_dataset)
+        self.num_test_batches = len(self.test_dataloader)
+
+    def setup_model(self, cfg, state_dict=None):
+        raise NotImplementedError
+
+    def setup_optimizer(self, checkpoint=None, last_epoch=-1):
+        raise NotImplementedError
+
+    # -- experiment / checkpoints (trainer.py:162-224, 305-321) ------------------------------------------
+    def setup_experiment(self, is_training, exp_tag, resume_from=None, checkpoint=None, demo_input=None):
+        dt = str(datetime.now()).replace('.', '-').replace(':', '-').replace(' ', '_')
+        exp_tag = '_'.join([dt, exp_tag])
+        if not is_training:
+            self.setup_dataset(self.cfg, 'test')
+            base_path = os.path.join(self.cfg.SYS.OUTPUT_DIR, exp_tag)
+            if self.is_master_process():
+                os.makedirs(base_path, exist_ok=True)
+            if checkpoint is None:
+                raise Exception('Checkpoint file is not provided.')
+            assert checkpoint.split('.')[-1] == 'pth', 'file type not supported: %s' % checkpoint
+            self.setup_model(self.cfg, state_dict=torch.load(checkpoint, map_location='cpu')['model_state_dict'])
+            return base_path
+        self.setup_dataset(self.cfg, 'train')
+        if resume_from is not None:
+            assert resume_from.split('.')[-1] == 'pth', 'file type not supported: %s' % resume_from
+            assert os.path.exists(resume_from), 'file not exists: %s' % resume_from
+            ckpt = torch.load(resume_from, map_location='cpu')
+            epoch, global_step = ckpt['epoch'], ckpt['step']
+            base_path = os.path.split(resume_from)[0]
+            self.setup_model(self.cfg, state_dict=ckpt['model_state_dict'])
+            self.setup_optimizer(checkpoint=ckpt, last_epoch=epoch)
+            return base_path, epoch, global_step
+        base_path = os.path.join(self.cfg.SYS.OUTPUT_DIR, exp_tag)
+        if self.is_master_process():
+            os.makedirs(base_path, exist_ok=True)
+        if self.cfg.TRAIN.PRETRAIN_FROM is not None:
+            ckpt = torch.load(self.cfg.TRAIN.PRETRAIN_FROM, map_location='cpu')
+            self.setup_model(self.cfg, state_dict=ckpt['model_state_dict'])
+        else:
+            self.setup_model(self.cfg)
+        self.setup_optimizer()
+        return base_path, 0, 0
+
+    def checkpoint_dict(self, epoch, global_step):
+        """{'epoch','step','model_state_dict' (keys prefixed 'module.'), '<optimizer>_state_dict'...} (trainer.py:313-319)."""
+        ckpt = {'epoch': epoch, 'step': global_step,
+                'model_state_dict': {'module.' + k: v.detach().clone().contiguous() for k, v in self.model.state_dict().items()}}
+        for k, v in self.optimizers.items():
+            ckpt['%s_state_dict' % k] = v.state_dict()
+        return ckpt
+
+    def save_checkpoint(self, epoch, global_step):
+        d = os.path.join(self.base_path, 'checkpoints')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'checkpoint_epoch-%d_step-%d.pth' % (epoch, global_step))
+        logging.info('Saving checkpoint to: %s' % path)
+        torch.save(self.checkpoint_dict(epoch, global_step), path)
+        return path
+
+    def save_results(self, tag, step, epoch, base_path, results_dict, extra_id=None):
+        d = os.path.join(base_path, 'results')
+        os.makedirs(d, exist_ok=True)
+        np.savez(os.path.join(d, '%s_epoch-%d_step-%d%s.npz' % (tag, epoch, step, '' if extra_id is None else '_%s' % extra_id)),
+                 **results_dict)
+
+    # -- logging (trainer.py:242-263) --------------------------------------------------------------------
+    def logger_writer_step(self, tag, losses, step, epoch=None, global_step=None):
+        toc = (time.time() - self.step_tic) / self.cfg.SYS.LOG_INTERVAL
+        self.step_tic = time.time()
+        msg = '[%s] epoch: %s/%d  step: %d  global_step: %s  time: %.3f  ' % (tag, epoch, self.cfg.TRAIN.NUM_EPOCHS, step, global_step, toc)
+        for k, v in self.optimizers.items():
+            msg += 'lr_%s: %.1e  ' % (k, v.param_groups[0]['lr'])
+        vals = torch.stack([v.detach().double().reshape(()) for v in losses.values()]).cpu().tolist()  # one D2H copy
+        msg += ''.join('%s: %.5f  ' % (k, x) for k, x in zip(losses.keys(), vals))
+        logging.info(msg)
+
+    def train_step(self, batch, t_step, global_step, epoch):
+        raise NotImplementedError
+
+    def test_step(self, batch, t_step, epoch=0):
+        raise NotImplementedError
+
+    def evaluate_epoch(self, results_dict):
+        return {}
+
+    # -- loops (trainer.py:367-427) ----------------------------------------------------------------------
+    def train(self, exp_tag, resume_from=None):
+        self.base_path, epoch_start, global_step = self.setup_experiment(True, exp_tag, resume_from=resume_from)
+        if self.cfg.SYS.DISTRIBUTED:
+            torch.distributed.barrier()
+        for epoch in range(epoch_start, self.cfg.TRAIN.NUM_EPOCHS):
+            self.model.train()
+            tic = time.time()
+            if getattr(self, 'train_sampler', None) is not None:
+                self.train_sampler.set_epoch(epoch)
+            for t_step, batch in enumerate(self.train_dataloader):
+                global_step += 1
+                self.train_step(batch, t_step + 1, global_step, epoch + 1)
+            if self.is_master_process() and (epoch + 1) % self.cfg.TRAIN.CHECKPOINT_INTERVAL == 0:
+                self.save_checkpoint(epoch + 1, global_step)
+            if self.cfg.TRAIN.VALIDATE:
+                self.validate(epoch + 1)
+            for s in self.schedulers.values():
+                s.step()
+            if self.is_master_process():
+                logging.info('[TRAIN] epoch_time: %.2f hours' % ((time.time() - tic) / 3600))
+
+    @torch.no_grad()
+    def validate(self, epoch=0):
+        self.model.eval()
+        tic = time.time()
+        sums, coll = {}, {}
+        for t_step, batch in enumerate(self.test_dataloader):
+            losses, res = self.test_step(batch, t_step + 1, epoch)
+            for k, v in losses.items():
+                sums[k] = sums.get(k, 0) + v
+            for k, v in res.items():
+                coll.setdefault(k, []).append(v)
+        out = {k: v / self.num_test_samples for k, v in sums.items()}
+        if coll and self.is_master_process():
+            out.update(self.evaluate_epoch({k: np.concatenate(v, axis=0) for k, v in coll.items()}))
+        if self.is_master_process():
+            logging.info('[VAL] epoch: %d  val_time: %.1f min  ' % (epoch, (time.time() - tic) / 60) +
+                         ''.join('%s: %.5f  ' % (k, float(v)) for k, v in out.items()))
+        return out
+
+    def test(self, exp_tag, checkpoint):
+        self.base_path = self.setup_experiment(False, exp_tag, checkpoint=checkpoint)
+        return self.validate(0)

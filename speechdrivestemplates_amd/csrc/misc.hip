@@ -335,7 +335,7 @@ __global__ void adam_prep_kernel(AdamState* st, float beta1, float beta2) {
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev,
-                                                   float beta1, float beta2, float eps, float wd,
+                                                   float beta1, float beta2, float eps, float wd, float gscale,
                                                    const AdamState* __restrict__ st) {
     const float lr = lr_dev[0];
     const float step_size = lr / st->bc1, bc2s = st->bc2_sqrt;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         f32x4 pv = *(f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i), mv = *(f32x4*)(m + 4 * i), vv = *(f32x4*)(v + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float gg = gv[e];
+            float gg = gv[e] * gscale;
             if (wd != 0.f) gg += wd * pv[e];
             mv[e] = mv[e] * beta1 + (1.f - beta1) * gg;
             vv[e] = vv[e] * beta2 + (1.f - beta2) * gg * gg;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (nv << 2) + threadIdx.x;
-        float gg = g[i];
+        float gg = g[i] * gscale;
         if (wd != 0.f) gg += wd * p[i];
         const float mm = m[i] * beta1 + (1.f - beta1) * gg;
         const float vv = v[i] * beta2 + (1.f - beta2) * gg * gg;
@@ -546,13 +546,14 @@ extern "C" int sdt_final_metrics_f64(const float* pred, const float* gt, const d
     return SDT_OK;
 }
 extern "C" int sdt_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
-                                 float beta2, float eps, float weight_decay, void* state_dev, void* stream) {
+                                 float beta2, float eps, float weight_decay, float grad_scale, void* state_dev,
+                                 void* stream) {
     SDT_CHECK_ARG(p && g && m && v && lr_dev && state_dev && n > 0, "bad argument");
     SDT_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0, "buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, s, (AdamState*)state_dev, beta1, beta2);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, n, lr_dev, beta1, beta2, eps,
-                       weight_decay, (const AdamState*)state_dev);
+                       weight_decay, grad_scale, (const AdamState*)state_dev);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

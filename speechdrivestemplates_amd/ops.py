@@ -496,8 +496,8 @@ def mel_spectrogram(audio, basis, fb):
     return mel
 
 
-def adam_step(p, g, m, v, lr_dev, state_dev, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+def adam_step(p, g, m, v, lr_dev, state_dev, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     """One torch.optim.Adam step over flat fp32 buffers (voice2pose.py:249-279,302-304)."""
     _req_cuda(p, g, m, v, lr_dev, state_dev)
     check(_lib.load().sdt_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), beta1, beta2, eps, weight_decay,
-                                        _p(state_dev), _stream()))
+                                        grad_scale, _p(state_dev), _stream()))

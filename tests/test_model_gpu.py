@@ -1,0 +1,227 @@
+"""GPU parity of the reference-shaped modules and of Voice2Pose.train_step against
+(a) the fixtures produced by the REFERENCE's own modules (tests/golden/*.npz) and (b) the CPU oracle.
+fp32 tolerances are stated per check; gradient tolerances are calibrated on the reference's own
+fp32-vs-fp64 discrepancy stored in the fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import sdt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def sl(t, n=64):
+    f = t.detach().reshape(-1).double().cpu()
+    step = max(1, f.numel() // n)
+    return np.concatenate([f[::step][:n].numpy(), [f.sum().item(), f.abs().sum().item()]])
+
+
+def relmax(got, ref):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    ref = ref.detach().double().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all()
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def check(name, got, ref, tol):
+    e = relmax(got, ref)
+    print("  %-46s rel-max-err %.3e (tol %.1e)" % (name, e, tol))
+    assert e < tol, "%s: %.3e >= %.1e" % (name, e, tol)
+
+
+@pytest.fixture(scope="module")
+def batch2():
+    return O.make_batch(2, 16, step=0, seed=1)
+
+
+def _to_dev(state, prefix):
+    return {k[len(prefix):]: v.clone() for k, v in state.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("norm", ["IN", "BN"])
+@pytest.mark.parametrize("dim", [None, 32])
+def test_generator_vs_reference_fixture(batch2, golden_modules, norm, dim):
+    from speechdrivestemplates_amd.core.networks import get_model
+    cfg = O.default_cfg(**{"VOICE2POSE.GENERATOR.NORM": norm, "VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION": dim})
+    st = {}
+    O.fill_generator(st, np.random.Generator(np.random.PCG64(3)), "netG", cfg)
+    net = get_model("SequenceGeneratorCNN")(cfg)
+    net.load_state_dict(_to_dev(st, "netG."), strict=True)
+    net.to(DEV).train()
+    mel = O.mel_spectrogram(batch2["audio"]).to(DEV)
+    code = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((2, 32)).astype(np.float32)).to(DEV)
+    out = net(mel, 64, code if dim else None)
+    tag = "G_%s_%s" % (norm, dim)
+    assert out.shape == (2, 64, 2, 121)
+    check(tag + " vs reference", out, golden_modules[tag], 2e-4)
+    if norm == "BN":
+        sd = net.state_dict()
+        check(tag + " running_mean L0", sd["audio_encoder.specgram_encoder_2d.0.0.norm.running_mean"], golden_modules[tag + "/rm0"], 1e-4)
+        check(tag + " running_var decoder.3", sd["decoder.3.norm.running_var"], golden_modules[tag + "/rv_last"], 1e-4)
+        assert int(sd["unet.e3.norm.num_batches_tracked"]) == 1
+    if norm == "IN" and dim == 32:  # variable-length inference (demo path)
+        net.eval()
+        with torch.no_grad():
+            out = net(mel[:, :, :300].contiguous(), 40, code)
+        check(tag + " T=40 vs reference", out, golden_modules[tag + "/T40"], 2e-4)
+        # sub-module API with the reference's logical shapes
+        with torch.no_grad():
+            enc = net.audio_encoder(mel, 64)
+            assert enc.shape == (2, 256, 64)
+            un = net.unet(torch.cat([enc, code.unsqueeze(2).repeat(1, 1, 64)], 1))
+            assert un.shape == (2, 256, 64)
+
+
+def test_discriminator_pose_encoder_autoencoder_vs_reference(batch2, golden_modules):
+    from speechdrivestemplates_amd.core.networks import get_model
+    poses = batch2["poses"].to(DEV)
+    motion = poses[:, 1:] - poses[:, :-1]
+    st = {}
+    O.fill_discriminator(st, np.random.Generator(np.random.PCG64(4)), "netD_pose", O.cfg_named("voice2pose_s2g"))
+    for cfg, tag in ((O.cfg_named("voice2pose_s2g"), "D_leaky"), (O.default_cfg(), "D_relu")):
+        net = get_model("PoseSequenceDiscriminator")(cfg)
+        net.load_state_dict(_to_dev(st, "netD_pose."), strict=True)
+        net.to(DEV).train()
+        check(tag + " vs reference", net(motion), golden_modules[tag], 2e-4)
+    cfg = O.cfg_named("pose2pose")
+    st = {}
+    O.fill_pose_encoder(st, np.random.Generator(np.random.PCG64(5)), "enc", cfg)
+    net = get_model("PoseSeqEncoder")(cfg)
+    net.load_state_dict(_to_dev(st, "enc."), strict=True)
+    net.to(DEV).train()
+    mu, lv = net(poses)
+    check("PoseSeqEncoder mu (train)", mu, golden_modules["PoseEnc/mu"], 5e-4)
+    check("PoseSeqEncoder logvar (train)", lv, golden_modules["PoseEnc/logvar"], 5e-4)
+    net.eval()
+    with torch.no_grad():
+        mu, _ = net(poses)
+    check("PoseSeqEncoder mu (eval, running stats)", mu, golden_modules["PoseEnc_eval/mu"], 5e-4)
+    st = O.make_pose2pose_state(cfg, 16, seed=6)
+    net = get_model("Autoencoder")(cfg)
+    net.load_state_dict(_to_dev(st, "ae."), strict=True)
+    net.to(DEV).train()
+    eps = torch.from_numpy(np.random.Generator(np.random.PCG64(2)).standard_normal((2, 32)).astype(np.float32)).to(DEV)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: eps.clone()
+    try:
+        out, mu, lv = net(poses, 64)
+    finally:
+        torch.randn = real_randn
+    check("Autoencoder out", out, golden_modules["AE/out"], 5e-4)
+    check("Autoencoder mu", mu, golden_modules["AE/mu"], 5e-4)
+
+
+def _make_pipeline(cfg_name, n_clips, code_std):
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
+    from speechdrivestemplates_amd.core.pipelines import get_pipeline
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", cfg_name + ".yaml"))
+    cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DATASET.SYNTHETIC_CLIPS", n_clips, "SYS.LOG_INTERVAL", 10 ** 9])
+    cfg.freeze()
+    sp = np.load(os.path.join(GOLDEN, "speaker_stat_oliver.npz"))
+    gd.register_speaker_stat("oliver",
+                             parted={"mean": sp["parted_mean"], "std": sp["parted_std"], "scale_factor": float(sp["parted_scale"])},
+                             global_={"mean": sp["global_mean"], "std": sp["global_std"], "scale_factor": float(sp["global_scale"])})
+    pipe = get_pipeline(cfg.PIPELINE_TYPE)(cfg)
+    pipe.num_train_samples = n_clips
+    pipe.train_dataset = gd.SyntheticGestureDataset(cfg=cfg, num_clips=n_clips)
+    ocfg = O.cfg_named(cfg_name)
+    st = O.make_voice2pose_state(ocfg, n_clips, seed=0, code_std=code_std)
+    pipe.setup_model(cfg, state_dict={"module." + k: v for k, v in st.items()})
+    pipe.setup_optimizer()
+    pipe.model.train()
+    return pipe, cfg
+
+
+@pytest.mark.parametrize("name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_bp_zero", 0.0), ("voice2pose_s2g", 0.0)])
+def test_train_step_trajectory_vs_reference(golden_traj, name, code_std):
+    cfg_name = name.replace("_zero", "")
+    pipe, cfg = _make_pipeline(cfg_name, 16, code_std)
+    g = {k[len(name) + 1:]: v for k, v in golden_traj.items() if k.startswith(name + "/")}
+    g64 = {k[len("voice2pose_sdt_bp_f64/"):]: v for k, v in golden_traj.items() if k.startswith("voice2pose_sdt_bp_f64/")}
+    for step in range(3):
+        batch = O.make_batch(4, 16, step=step, seed=1)
+        if cfg_name == "voice2pose_s2g":
+            batch["speaker"] = ["oliver"] * 4
+        losses, results = pipe.forward_backward(batch, want_final=True)
+        if step == 0:
+            check(name + " step0 pred vs reference", results["poses_pred_normalized"], g["s0/pred"], 2e-4)
+            grads = {k: p.grad.detach().clone() for k, p in pipe.model.named_parameters() if p.grad is not None}
+            worst = 0.0
+            for k, ref in g.items():
+                if not k.startswith("s0/grad/") or k.startswith("s0/grad/Dstep:"):
+                    continue
+                pk = k[len("s0/grad/"):]
+                got = sl(grads[pk])[:64]
+                # reference fp32 vs reference fp64 on the same 64 samples = the noise floor of this gradient
+                floor = np.abs(ref[:64] - g64["s0/grad/" + pk][:64]).max() if (name == "voice2pose_sdt_bp" and "s0/grad/" + pk in g64) else 0.0
+                scale = max(np.abs(ref[:64]).max(), 1e-12)
+                err = np.abs(got - ref[:64]).max()
+                tol = max(4.0 * floor, 2e-3 * scale)
+                worst = max(worst, err / scale)
+                assert err <= tol, "grad %s: err %.3e > tol %.3e (scale %.3e, ref fp32-vs-fp64 floor %.3e)" % (pk, err, tol, scale, floor)
+            print("  %-46s worst grad-slice rel err %.3e" % (name + " step0 grads vs reference", worst))
+        pipe.optimizer_updates(losses)
+        torch.cuda.synchronize()
+        for k in [x for x in g if x.startswith("s%d/loss/" % step)]:
+            lk = k.split("/")[-1]
+            check("%s s%d %s" % (name, step, lk), losses[lk], g[k], 2e-4)
+        if name == "voice2pose_sdt_bp_zero":
+            assert float(losses["G_clipcode_kl_loss"]) == 0.0 and int(results["kl_valid"]) == 0  # device-side skip
+        check("%s s%d L2_dist" % (name, step), losses["L2_dist"], g["s%d/metric/L2_dist" % step], 1e-4)
+        check("%s s%d lip_sync" % (name, step), losses["lip_sync_error_n"], g["s%d/metric/lip_sync_error_n" % step], 1e-3)
+        check("%s s%d final_pred" % (name, step), sl(results["poses_pred_batch"]), g["s%d/final_pred" % step], 5e-4)
+        for k in ("mu_pred", "mu_gt", "logvar_pred", "logvar_gt"):
+            check("%s s%d %s" % (name, step, k), results[k], g["s%d/%s" % (step, k)], 5e-3)
+    # state after 3 Adam steps: weights (each element moved by <= lr per step; sign-noise on near-zero grads bounds
+    # the achievable agreement at ~2*lr*steps), BN buffers and counters
+    lr, steps = 1e-4, 3
+    sd = pipe.model.state_dict()
+    for k, v in sd.items():
+        ref = g["final/" + k]
+        if not v.is_floating_point():
+            assert int(v) == int(ref), k
+            continue
+        got = sl(v)
+        assert np.abs(got[:64] - ref[:64]).max() <= 2.2 * lr * steps + 2e-3 * np.abs(ref[:64]).max(), k
+        assert abs(got[65] - ref[65]) <= 2e-3 * ref[65] + 1e-6, k  # abs-sum of the whole tensor
+    if "clips_code" in sd:
+        check(name + " clips_code rows after dense Adam", sd["clips_code"][:12], g["final_full/clips_code_rows"], 2e-2)
+        untouched = sd["clips_code"][12:]
+        ref_untouched = O.make_voice2pose_state(O.cfg_named(cfg_name), 16, seed=0, code_std=code_std)["clips_code"][12:]
+        assert torch.equal(untouched.cpu(), ref_untouched), "rows with zero gradient and zero moments must not move"
+
+
+def test_checkpoint_roundtrip_and_flat_buffers():
+    pipe, cfg = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+    optg = pipe.optimizers["optimizerG"]
+    # every generator parameter is a view into the flat buffer, in the kernels' (Cout,taps,Cin) layout
+    w = pipe.model.netG.unet.e2.conv.weight
+    assert w.data_ptr() >= optg.flat_param.data_ptr() and w.data_ptr() < optg.flat_param.data_ptr() + optg.flat_param.numel() * 4
+    assert w.permute(0, 2, 1).is_contiguous() and w.grad.permute(0, 2, 1).is_contiguous()
+    batch = O.make_batch(4, 16, step=0, seed=1)
+    losses, _ = pipe.forward_backward(batch)
+    pipe.optimizer_updates(losses)
+    ckpt = pipe.checkpoint_dict(1, 1)
+    assert set(ckpt) == {"epoch", "step", "model_state_dict", "optimizerG_state_dict", "optimizerClipCode_state_dict"}
+    assert all(k.startswith("module.") for k in ckpt["model_state_dict"])
+    assert ckpt["optimizerG_state_dict"]["state"][0]["exp_avg"].shape == pipe.optimizers["optimizerG"].params[0].shape
+    pipe2, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.0)
+    pipe2.setup_model(cfg, state_dict=ckpt["model_state_dict"])
+    pipe2.optimizers, pipe2.schedulers = {}, {}
+    pipe2.setup_optimizer(checkpoint=ckpt)
+    pipe2.model.train()
+    b1 = O.make_batch(4, 16, step=1, seed=1)
+    l1, _ = pipe.forward_backward(b1)
+    pipe.optimizer_updates(l1)
+    l2, _ = pipe2.forward_backward(b1)
+    pipe2.optimizer_updates(l2)
+    check("resumed run reproduces G_loss", l2["G_loss"], l1["G_loss"], 1e-5)
+    check("resumed run reproduces weights", pipe2.model.netG.decoder[4].weight, pipe.model.netG.decoder[4].weight, 1e-5)

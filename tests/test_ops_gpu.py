@@ -190,8 +190,12 @@ def test_resize_concat(ops, T, D):
     cd = code.detach().float().to(DEV).requires_grad_(True) if D else None
     rd = ops.ResizeConcatFn.apply(xd, cd, T)
     rd.backward(ops.cl(gr.float()).to(DEV))
-    check("resize+concat fwd T%d D%d" % (T, D), ops.cf_view(rd), r, 1e-6)
-    check("resize bwd dx", ops.cf_view(xd.grad), x.grad, 1e-5)
+    # source indices / lambdas are computed in fp32 by the reference too (ATen area_pixel_compute_source_index):
+    # tight against the fp32 reference, looser against fp64 when W/T is not exactly representable
+    r32 = F.interpolate(x.detach().float(), (1, T), mode="bilinear").squeeze(2)
+    check("resize fwd vs fp32 ref T%d" % T, ops.cf_view(rd)[:, :C], r32, 2e-6)
+    check("resize+concat fwd T%d D%d" % (T, D), ops.cf_view(rd), r, 5e-5)
+    check("resize bwd dx", ops.cf_view(xd.grad), x.grad, 5e-5)
     if D:
         check("resize bwd dcode", cd.grad, code.grad, 1e-5)
 
@@ -211,8 +215,8 @@ def test_upsample_add(ops, Ti, To, skip):
     sd = ops.cl(sk.detach().float()).to(DEV).requires_grad_(True) if skip else None
     rd = ops.UpsampleAddFn.apply(pd, sd, To)
     rd.backward(ops.cl(gr.float()).to(DEV))
-    check("upsample+add fwd %d->%d" % (Ti, To), ops.cf_view(rd), r, 1e-6)
-    check("upsample bwd dprev", ops.cf_view(pd.grad), prev.grad, 1e-5)
+    check("upsample+add fwd %d->%d" % (Ti, To), ops.cf_view(rd), r, 5e-6)
+    check("upsample bwd dprev", ops.cf_view(pd.grad), prev.grad, 5e-5)
     if skip:
         check("upsample bwd dskip", ops.cf_view(sd.grad), sk.grad, 1e-6)
 
