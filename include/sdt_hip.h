@@ -53,6 +53,10 @@ int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* 
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);
+/* Which kernel instantiation the two entry points above pick for a geometry (16-B aligned operands assumed):
+ * (BM*1000+BN)*10 + vec4, e.g. 1281281 = conv_taps_kernel<128,128,true>.  Used by bench.py to attribute timings. */
+int sdt_conv_taps_variant(const sdt_conv_geom* g);
+int sdt_conv_dw_variant(const sdt_conv_geom* g);
 /* (Cout,T,Cin) -> (Cin,T,Cout): operand layout for the input-gradient GEMM. */
 int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream);
 /* out[c] += sum_rows x[row, c]  (bias gradient of the k1 head conv, generator.py:103). */

@@ -26,6 +26,8 @@ _G = C.POINTER(ConvGeom)
 SIGNATURES = {
     "sdt_conv_taps_f32": [_p, _p, _p, _p, _G, _p],
     "sdt_conv_dw_f32": [_p, _p, _p, _G, _p],
+    "sdt_conv_taps_variant": [_G],
+    "sdt_conv_dw_variant": [_G],
     "sdt_weight_transpose_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
     "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
@@ -58,6 +60,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so: it must be in the process BEFORE our library is dlopen'ed, otherwise the
+    # loader maps /opt/rocm's copy as well and the two HIP runtimes do not share devices / streams.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libsdt_hip.so not found at %s -- run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "

@@ -390,21 +390,28 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g);
 }
 
+// tile selection: returns BM*1000 + BN (+1 when the 16-B vector loader is usable)
+static int taps_variant(const sdt_conv_geom* g, bool aligned) {
+    const int vec4 = ((g->Cin % 4 == 0) && aligned) ? 1 : 0;
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    if (g->Cout <= 64) return (M >= 128 * 512 ? 128064 : 64064) * 10 + vec4;
+    const int64_t tiles = cdiv64(M, 128) * cdiv(g->Cout, 128);
+    return (tiles >= 512 ? 128128 : 64064) * 10 + vec4;
+}
+extern "C" int sdt_conv_taps_variant(const sdt_conv_geom* g) { return g ? taps_variant(g, true) : SDT_ERR_ARG; }
+
 extern "C" int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
                                  const sdt_conv_geom* g, void* stream) {
     int rc = check_geom(g);
     if (rc) return rc;
     SDT_CHECK_ARG(x && w && y, "null pointer");
-    const bool vec4 = (g->Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)w) % 16 == 0);
-    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    const int var = taps_variant(g, (((uintptr_t)x | (uintptr_t)w) % 16) == 0);
+    const bool vec4 = var % 10;
     hipStream_t s = (hipStream_t)stream;
-    if (g->Cout <= 64) {
-        if (M >= 128 * 512) launch_taps<128, 64>(vec4, x, w, bias, y, *g, s);
-        else launch_taps<64, 64>(vec4, x, w, bias, y, *g, s);
-    } else {
-        const int64_t tiles = cdiv64(M, 128) * cdiv(g->Cout, 128);
-        if (tiles >= 512) launch_taps<128, 128>(vec4, x, w, bias, y, *g, s);
-        else launch_taps<64, 64>(vec4, x, w, bias, y, *g, s);
+    switch (var / 10) {
+        case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, s); break;
+        case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, s); break;
+        default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, s); break;
     }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
@@ -426,18 +433,27 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
         hipLaunchKernelGGL((conv_dw_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
 }
 
+static int dw_variant(const sdt_conv_geom* g, bool aligned) {
+    const int vec4 = ((g->Cin % 4 == 0) && (g->Cout % 4 == 0) && aligned) ? 1 : 0;
+    const bool bigm = g->Cout > 64;
+    const bool bign = vec4 ? g->Cin > 64 : g->ntaps * g->Cin > 64;
+    return ((bigm ? 128 : 64) * 1000 + (bign ? 128 : 64)) * 10 + vec4;
+}
+extern "C" int sdt_conv_dw_variant(const sdt_conv_geom* g) { return g ? dw_variant(g, true) : SDT_ERR_ARG; }
+
 extern "C" int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream) {
     int rc = check_geom(g);
     if (rc) return rc;
     SDT_CHECK_ARG(x && dy && dw, "null pointer");
-    const bool vec4 = (g->Cin % 4 == 0) && (g->Cout % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
+    const int var = dw_variant(g, (((uintptr_t)x | (uintptr_t)dy) % 16) == 0);
+    const bool vec4 = var % 10;
     hipStream_t s = (hipStream_t)stream;
-    const bool bigm = g->Cout > 64;
-    const bool bign = vec4 ? g->Cin > 64 : g->ntaps * g->Cin > 64;
-    if (bigm && bign) launch_dw<128, 128>(vec4, x, dy, dw, *g, s);
-    else if (bigm) launch_dw<128, 64>(vec4, x, dy, dw, *g, s);
-    else if (bign) launch_dw<64, 128>(vec4, x, dy, dw, *g, s);
-    else launch_dw<64, 64>(vec4, x, dy, dw, *g, s);
+    switch (var / 10) {
+        case 128128: launch_dw<128, 128>(vec4, x, dy, dw, *g, s); break;
+        case 128064: launch_dw<128, 64>(vec4, x, dy, dw, *g, s); break;
+        case 64128: launch_dw<64, 128>(vec4, x, dy, dw, *g, s); break;
+        default: launch_dw<64, 64>(vec4, x, dy, dw, *g, s); break;
+    }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

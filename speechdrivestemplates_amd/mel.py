@@ -33,7 +33,7 @@ def htk_filterbank(n_freqs, f_min, f_max, n_mels, sample_rate):
 class _Window(nn.Module):
     def __init__(self, win_length):
         super().__init__()
-        self.register_buffer('window', hann_window_periodic(win_length).float())
+        self.register_buffer('window', torch.hann_window(win_length, periodic=True))  # torchaudio's default window_fn
 
 
 class _MelScale(nn.Module):

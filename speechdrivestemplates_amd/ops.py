@@ -155,6 +155,55 @@ def dx_geoms_1d(B, Wi, Cin, Cout, k, s, p):
     return out
 
 
+class ConvProfiler:
+    """Optional HIP-event timing of every MFMA conv launch (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
+
+    def __init__(self):
+        self.records = []  # (kernel name, role, is_2d, algorithmic flops, algorithmic bytes, start, end)
+
+    @staticmethod
+    def kernel_name(kind, variant):
+        bm, bn, vec = variant // 10 // 1000, variant // 10 % 1000, variant % 10
+        return "%s<%d, %d, %s>" % ("conv_taps_kernel" if kind != "dW" else "conv_dw_kernel", bm, bn, "true" if vec else "false")
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, role, is2d, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0, "roles": {}})
+            us = e0.elapsed_time(e1) * 1e3
+            d["launches"] += 1
+            d["us"] += us
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            r = d["roles"].setdefault(role + ("2d" if is2d else "1d"), [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += us
+            r[2] += flops
+        return out
+
+
+PROFILER = None  # set to a ConvProfiler instance to time conv launches
+
+
+def _conv_launch(kind, is2d, g, call):
+    if PROFILER is None:
+        check(call())
+        return
+    lib = _lib.load()
+    var = lib.sdt_conv_dw_variant(g) if kind == "dW" else lib.sdt_conv_taps_variant(g)
+    m = g.B * g.Ho * g.Wo
+    flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
+    # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, fp32
+    nbytes = 4.0 * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(call())
+    e1.record()
+    PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
+
+
 def conv_forward(x_cl, w, bias, stride, pad):
     """x_cl (B,H,W,Cin)|(B,T,Cin); w logical (Cout,Cin,kh,kw)|(Cout,Cin,k) -> y channels-last."""
     _req_cuda(x_cl, w, bias)
@@ -163,7 +212,8 @@ def conv_forward(x_cl, w, bias, stride, pad):
     g = conv_geom_for(x4.shape, w, stride, pad)
     ws = weight_storage(w)
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
-    check(lib.sdt_conv_taps_f32(_p(x4), _p(ws), _p(bias), _p(y), g, _stream()))
+    st = _stream()
+    _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_f32(_p(x4), _p(ws), _p(bias), _p(y), g, st))
     return y if x_cl.dim() == 4 else y.squeeze(1)
 
 
@@ -185,7 +235,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
         if g is None:  # parity class that no tap reaches: the gradient is zero there
             dx[:, py::(1 if one_d else stride), px::stride].zero_()
             continue
-        check(lib.sdt_conv_taps_f32(_p(gy4), _p(wt), None, _p(dx), g, st))
+        _conv_launch("dX", not one_d, g, lambda g=g: lib.sdt_conv_taps_f32(_p(gy4), _p(wt), None, _p(dx), g, st))
     return dx.squeeze(1) if one_d else dx
 
 
@@ -198,7 +248,8 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
     gws = weight_storage(gw)
     if gws.data_ptr() != gw.data_ptr():
         raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
-    check(lib.sdt_conv_dw_f32(_p(x4), _p(gy4), _p(gws), g, _stream()))
+    st = _stream()
+    _conv_launch("dW", w.dim() == 4, g, lambda: lib.sdt_conv_dw_f32(_p(x4), _p(gy4), _p(gws), g, st))
 
 
 class ConvFn(torch.autograd.Function):
