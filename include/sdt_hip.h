@@ -50,6 +50,14 @@ typedef struct sdt_conv_geom {
 /* nn.Conv2d / nn.Conv1d forward and input-gradient (building_blocks.py:15-22,31-38; ATen conv). */
 int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
                       const sdt_conv_geom* g, void* stream);
+/* Split-K form for launches with too few output tiles to fill the chip (the 1-D stage): slice z of `splitk`
+ * writes its partial sums to partial + z*numel(Y) (no bias); after ALL launches that share the Y tensor (the parity
+ * classes of an input-gradient) sdt_splitk_reduce_f32 sums the slabs in a fixed order (deterministic) and adds bias.
+ * splitk == 1 is sdt_conv_taps_f32.  sdt_conv_taps_splitk_hint returns a suitable slice count for a geometry. */
+int sdt_conv_taps_splitk_hint(const sdt_conv_geom* g);
+int sdt_conv_taps_splitk_f32(const float* x, const float* w, const float* bias, float* y,
+                             const sdt_conv_geom* g, int splitk, float* partial, void* stream);
+int sdt_splitk_reduce_f32(const float* partial, const float* bias, float* y, int64_t n, int cout, int splitk, void* stream);
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);

@@ -10,22 +10,29 @@
 //
 // Replaces the ATen/cuDNN convolution calls made by building_blocks.py:15-22,31-38 (ConvNormRelu),
 // generator.py:103 and discriminator.py:16 (k1 / k3 head convs) in forward and backward.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define BK 32
 #define LDP 36  // LDS pitch of a [row][BK] tile, in floats
+// Byte offset used for masked buffer loads: every tensor handed to the vector loaders is < 2^31 - 64 KiB bytes
+// (checked on the host), so SDT_OOB + (in-row offset) is always past num_records and the load returns zeros.
+#define SDT_OOB 0x80000000u
 
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, bool VEC4>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
-                                                        const sdt_conv_geom g) {
+                                                        const sdt_conv_geom g, const int splitk,
+                                                        float* __restrict__ partial, const size_t ysize) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;
     __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
     __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
     __shared__ int sOut[BM];
     __shared__ int sTap[3 * SDT_MAX_TAPS];
+    __shared__ int sLive[SDT_MAX_TAPS + 1];  // taps that reach at least one in-range input for this tile; [MAX] = count
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -39,6 +46,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
         sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
     }
+    if (tid <= SDT_MAX_TAPS) sLive[tid] = 0;
     if (tid < BM) {
         int m = m0 + tid, off = -1;
         if (m < M) {
@@ -67,33 +75,72 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    int ntl = g.ntaps;
+    if constexpr (VEC4) {
+        // tap culling: a tap whose input coordinates are out of range for EVERY row of this tile contributes only
+        // zeros -- skip its K steps (halves the work of the p=0 (6,3) layer's input gradient; trims padded borders)
+        if (kv == 0) {
+            for (int t = 0; t < g.ntaps; ++t) {
+                const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t];
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    any |= (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                if (any) sLive[t] = 1;  // benign race: every writer stores 1
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < g.ntaps; ++t)
+                if (sLive[t]) sLive[n++] = t;  // in-place compaction (n <= t)
+            sLive[SDT_MAX_TAPS] = n;
+        }
+        __syncthreads();
+        ntl = sLive[SDT_MAX_TAPS];
+    }
 
     const int nkc = (g.Cin + BK - 1) / BK;
     const int Ktot = g.ntaps * g.Cin;
-    const int nsteps = VEC4 ? g.ntaps * nkc : (Ktot + BK - 1) / BK;
+    const int nsteps_all = VEC4 ? ntl * nkc : (Ktot + BK - 1) / BK;
+    // split-K: slice z of the K loop (deterministic: partial tiles go to their own slab, summed by splitk_reduce)
+    const int step0 = (int)(((long)blockIdx.z * nsteps_all) / splitk);
+    const int nsteps = (int)(((long)(blockIdx.z + 1) * nsteps_all) / splitk);
 
+    // VEC4 loader: raw buffer loads with 32-bit byte offsets; masked rows / taps use an out-of-range offset and the
+    // hardware returns zeros (no branches, no 64-bit address arithmetic in the K loop).  Row offsets are rebuilt
+    // only when the tap changes (every Cin/32 steps).
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)g.Cout * g.Tw * g.Cin * 4u), 0x00020000);
+    unsigned aoff[RA], boff[RB];
+    int cur_tl = -1;
     f32x4 ra[RA], rb[RB];
     auto load = [&](int step) {
         if constexpr (VEC4) {
-            const int t = step / nkc;
-            const int c = (step - t * nkc) * BK + kv * 4;
-            const bool cok = c < g.Cin;
-            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+            const int tl = step / nkc;
+            const unsigned cb = (unsigned)((step - tl * nkc) * BK + kv * 4) * 4u;
+            if (tl != cur_tl) {
+                cur_tl = tl;
+                const int t = sLive[tl];
+                const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const int iy = riy[i] + dy, ix = rix[i] + dx;
-                const bool ok = cok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *(const f32x4*)(X + ((size_t)(rbH[i] + iy) * g.Wi + ix) * g.Cin + c);
-                ra[i] = v;
+                for (int i = 0; i < RA; ++i) {
+                    const int iy = riy[i] + dy, ix = rix[i] + dx;
+                    const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                    aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int n = n0 + r0 + 32 * i;
+                    boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
+                }
             }
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && n < g.Cout) v = *(const f32x4*)(W + ((size_t)n * g.Tw + wt) * g.Cin + c);
-                rb[i] = v;
-            }
+            for (int i = 0; i < RA; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(aoff[i] + cb), 0, 0));
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(boff[i] + cb), 0, 0));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -128,8 +175,8 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     const float* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
     const float* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
 
-    load(0);
-    for (int step = 0; step < nsteps; ++step) {
+    if (step0 < nsteps) load(step0);
+    for (int step = step0; step < nsteps; ++step) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
 #pragma unroll
@@ -157,6 +204,10 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     }
 
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (splitk > 1) {
+        Y = partial + (size_t)blockIdx.z * ysize;
+        bias = nullptr;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -218,10 +269,18 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
             ix0 = ox * g.sx;
         }
         int (*R)[BK] = sRow[step & 1];
-        R[0][tid] = offY;
-        R[1][tid] = bH;
-        R[2][tid] = iy0;
-        R[3][tid] = ix0;
+        if constexpr (VEC4) {  // byte offsets for the buffer loads (this block's tap is fixed); masked rows -> SDT_OOB
+            const int iy = iy0 + g.dy[VEC4 ? (int)blockIdx.y / ((g.Cin + BN - 1) / BN) : 0];
+            const int ix = ix0 + g.dx[VEC4 ? (int)blockIdx.y / ((g.Cin + BN - 1) / BN) : 0];
+            const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            R[0][tid] = offY >= 0 ? (int)((unsigned)offY * 4u) : (int)SDT_OOB;
+            R[1][tid] = ok ? (int)((unsigned)(((bH + iy) * g.Wi + ix) * g.Cin) * 4u) : (int)SDT_OOB;
+        } else {
+            R[0][tid] = offY;
+            R[1][tid] = bH;
+            R[2][tid] = iy0;
+            R[3][tid] = ix0;
+        }
     };
 
     const int nva = tid % (BM / 4), rra = tid / (BM / 4);
@@ -229,6 +288,11 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
     const int nsteps = (mend - mbeg + BK - 1) / BK;
     if (nsteps <= 0) return;
 
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)((unsigned)g.B * g.Hy * g.Wy * g.Cout * 4u), 0x00020000);
+    // per-thread column byte offsets; columns past Cout / Cin are masked with SDT_OOB (added to any row offset -> OOB)
+    const unsigned colA = (n0 + 4 * nva) < g.Cout ? (unsigned)(n0 + 4 * nva) * 4u : SDT_OOB;
+    const unsigned colB = (c0 + 4 * nvb) < g.Cin ? (unsigned)(c0 + 4 * nvb) * 4u : SDT_OOB;
     f32x4 ra[RA], rb[RB];
     auto load = [&](int step) {
         int (*R)[BK] = sRow[step & 1];
@@ -239,7 +303,10 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int n = n0 + 4 * nva;
             if constexpr (VEC4) {
-                if (offY >= 0 && n < g.Cout) v = *(const f32x4*)(dY + (size_t)offY + n);
+                // offY is a byte offset or SDT_OOB; SDT_OOB + SDT_OOB wraps to 0, so mask the sum explicitly
+                const unsigned o = ((unsigned)offY | colA) & SDT_OOB ? SDT_OOB : (unsigned)offY + colA;
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)o, 0, 0));
+                (void)n;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -253,10 +320,11 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
             const int bH = R[1][r], iy0 = R[2][r], ix0 = R[3][r];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (VEC4) {
-                const int c = c0 + 4 * nvb;
-                const int iy = iy0 + sTap[tapv], ix = ix0 + sTap[SDT_MAX_TAPS + tapv];
-                if (c < g.Cin && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
-                    v = *(const f32x4*)(X + ((size_t)(bH + iy) * g.Wi + ix) * g.Cin + c);
+                const unsigned xo = (unsigned)bH;  // byte offset of the gathered X row for this block's tap, or SDT_OOB
+                const unsigned o = (xo | colB) & SDT_OOB ? SDT_OOB : xo + colB;
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, 0, 0));
+                (void)iy0;
+                (void)ix0;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -376,43 +444,90 @@ static int check_geom(const sdt_conv_geom* g) {
     SDT_CHECK_ARG((int64_t)g->B * g->Ho * g->Wo < (1ll << 31), "too many output positions");
     SDT_CHECK_ARG((g->Ho - 1) * g->osy + g->ooy < g->Hy && (g->Wo - 1) * g->osx + g->oox < g->Wy, "output grid exceeds Y");
     for (int t = 0; t < g->ntaps; ++t) SDT_CHECK_ARG(g->wt[t] >= 0 && g->wt[t] < g->Tw, "weight tap out of range");
+    const int64_t lim = (1ll << 31) - 65536;  // 32-bit byte offsets + SDT_OOB masking in the buffer-load paths
+    SDT_CHECK_ARG((int64_t)g->B * g->Hi * g->Wi * g->Cin * 4 < lim, "input tensor exceeds 2 GiB (split the batch)");
+    SDT_CHECK_ARG((int64_t)g->B * g->Hy * g->Wy * g->Cout * 4 < lim, "output tensor exceeds 2 GiB (split the batch)");
+    SDT_CHECK_ARG((int64_t)g->Cout * g->Tw * g->Cin * 4 < lim, "weight tensor exceeds 2 GiB");
     return SDT_OK;
 }
 
 template <int BM, int BN>
 static void launch_taps(bool vec4, const float* x, const float* w, const float* bias, float* y,
-                        const sdt_conv_geom& g, hipStream_t s) {
+                        const sdt_conv_geom& g, int splitk, float* partial, hipStream_t s) {
     const int M = g.B * g.Ho * g.Wo;
-    dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN));
+    const size_t ysize = (size_t)g.B * g.Hy * g.Wy * g.Cout;
+    dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), splitk);
     if (vec4)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g);
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g);
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ y, size_t n, int cout, int splitk) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = partial[i];
+        for (int z = 1; z < splitk; ++z) s += partial[(size_t)z * n + i];
+        if (bias != nullptr) s += bias[i % cout];
+        y[i] = s;
+    }
 }
 
 // tile selection: returns BM*1000 + BN (+1 when the 16-B vector loader is usable)
 static int taps_variant(const sdt_conv_geom* g, bool aligned) {
-    const int vec4 = ((g->Cin % 4 == 0) && aligned) ? 1 : 0;
+    const int vec4 = ((g->Cin % BK == 0) && aligned) ? 1 : 0;  // whole 32-channel K chunks: no channel mask in the loop
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    if (g->Cout <= 64) return (M >= 128 * 512 ? 128064 : 64064) * 10 + vec4;
-    const int64_t tiles = cdiv64(M, 128) * cdiv(g->Cout, 128);
-    return (tiles >= 512 ? 128128 : 64064) * 10 + vec4;
+    static const int forced = getenv("SDT_CONV_TILE") ? atoi(getenv("SDT_CONV_TILE")) : 0;  // tuning experiments only
+    if (forced == 64064 || forced == 128064 || forced == 128128) return forced * 10 + vec4;
+    // Measured on MI355X (profiles/r01_tile_sweep.txt): the 64x64 tile (54 VGPR + 16 AGPR -> 7 waves/SIMD) beats the
+    // 128-wide tiles on every layer of the hot path (92-121 vs 55-113 TFLOP/s): the fp32 MFMA is slow enough that LDS
+    // reuse is irrelevant, while occupancy hides the gather latency and the small tile quantises better over 256 CUs.
+    (void)M;
+    return 64064 * 10 + vec4;
 }
 extern "C" int sdt_conv_taps_variant(const sdt_conv_geom* g) { return g ? taps_variant(g, true) : SDT_ERR_ARG; }
 
-extern "C" int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
-                                 const sdt_conv_geom* g, void* stream) {
+// Suggested split of the K loop for launches that cannot fill 256 CUs with output tiles (the 1-D stage:
+// M = B*T <= 2048 rows): enough slices for >= 2 workgroups per CU while keeping >= 4 K-steps per slice.
+extern "C" int sdt_conv_taps_splitk_hint(const sdt_conv_geom* g) {
+    if (!g) return SDT_ERR_ARG;
+    const int var = taps_variant(g, true);
+    const int bm = var / 10 / 1000, bn = var / 10 % 1000;
+    const int64_t tiles = cdiv64((int64_t)g->B * g->Ho * g->Wo, bm) * cdiv(g->Cout, bn);
+    if (tiles >= 192) return 1;
+    const int nsteps = (var % 10) ? g->ntaps * cdiv(g->Cin, BK) : cdiv(g->ntaps * g->Cin, BK);
+    int k = (int)std::min<int64_t>(std::min<int64_t>(cdiv64(512, tiles), nsteps / 4), 16);
+    return std::max(k, 1);
+}
+
+extern "C" int sdt_conv_taps_splitk_f32(const float* x, const float* w, const float* bias, float* y,
+                                        const sdt_conv_geom* g, int splitk, float* partial, void* stream) {
     int rc = check_geom(g);
     if (rc) return rc;
     SDT_CHECK_ARG(x && w && y, "null pointer");
+    SDT_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || partial != nullptr), "bad split-K arguments");
     const int var = taps_variant(g, (((uintptr_t)x | (uintptr_t)w) % 16) == 0);
     const bool vec4 = var % 10;
     hipStream_t s = (hipStream_t)stream;
     switch (var / 10) {
-        case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, s); break;
-        case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, s); break;
-        default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, s); break;
+        case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
+        case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
+        default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
     }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
+                                 const sdt_conv_geom* g, void* stream) {
+    return sdt_conv_taps_splitk_f32(x, w, bias, y, g, 1, nullptr, stream);
+}
+
+extern "C" int sdt_splitk_reduce_f32(const float* partial, const float* bias, float* y, int64_t n, int cout, int splitk,
+                                     void* stream) {
+    SDT_CHECK_ARG(partial && y && n > 0 && cout > 0 && splitk >= 1, "bad argument");
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 256), 2048));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, bias, y, (size_t)n, cout, splitk);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
@@ -423,7 +538,7 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
     const int coltiles = vec4 ? g.ntaps * cdiv(g.Cin, BN) : cdiv(g.ntaps * g.Cin, BN);
     const int ntiles = cdiv(g.Cout, BM);
     int nsplit = cdiv(1536, coltiles * ntiles);
-    nsplit = max(1, min(nsplit, cdiv(M, BK)));
+    nsplit = max(1, min(nsplit, max(1, M / (4 * BK))));  // at least 4 K-steps per workgroup: bounds the atomic traffic
     int rows = cdiv(cdiv(M, nsplit), BK) * BK;
     nsplit = cdiv(M, rows);
     dim3 grid(nsplit, coltiles, ntiles);
@@ -435,9 +550,11 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
 
 static int dw_variant(const sdt_conv_geom* g, bool aligned) {
     const int vec4 = ((g->Cin % 4 == 0) && (g->Cout % 4 == 0) && aligned) ? 1 : 0;
-    const bool bigm = g->Cout > 64;
-    const bool bign = vec4 ? g->Cin > 64 : g->ntaps * g->Cin > 64;
-    return ((bigm ? 128 : 64) * 1000 + (bign ? 128 : 64)) * 10 + vec4;
+    static const int forced = getenv("SDT_DW_TILE") ? atoi(getenv("SDT_DW_TILE")) : 0;  // tuning experiments only
+    if (forced == 64064 || forced == 128064 || forced == 64128 || forced == 128128) return forced * 10 + vec4;
+    // 64x64 everywhere (42 VGPR + 16 AGPR -> 8 waves/SIMD): on par or better than the larger tiles on every layer and
+    // a quarter of the atomic traffic per workgroup (profiles/r01_tile_sweep.txt)
+    return 64064 * 10 + vec4;
 }
 extern "C" int sdt_conv_dw_variant(const sdt_conv_geom* g) { return g ? dw_variant(g, true) : SDT_ERR_ARG; }
 

@@ -257,9 +257,13 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-static int colnorm_rows_per_block(int C) {
+static int colnorm_rows_per_block(int C, int G, int64_t R) {
+    // <= 64 rows per thread (fp32 partials stay accurate); for short row counts shrink the chunk so that the
+    // launch still spreads over >= ~256 workgroups instead of serialising a long dependent loop in a few of them
     const int rpp = 256 / (C >> 2);
-    return rpp * 64;
+    const int64_t want = cdiv64(R, std::max(1, 256 / G));
+    const int64_t rpb = cdiv64(want, rpp) * rpp;
+    return (int)std::min<int64_t>(std::max<int64_t>(rpb, rpp), (int64_t)rpp * 64);
 }
 static int check_colnorm(int G, int64_t R, int C) {
     SDT_CHECK_ARG(G > 0 && R > 0, "non-positive dims");
@@ -275,7 +279,7 @@ extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float
     if (rc) return rc;
     SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = colnorm_rows_per_block(C);
+    const int rpb = colnorm_rows_per_block(C, G, R);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
     hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
     hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
@@ -308,7 +312,7 @@ extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, d
     SDT_CHECK_ARG(dz && y && dy && sums && mean && rstd, "null pointer");
     SDT_CHECK_ARG(!(dgamma || dbeta) || G == 1, "affine gradients need G == 1");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = colnorm_rows_per_block(C);
+    const int rpb = colnorm_rows_per_block(C, G, R);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
     hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
     hipLaunchKernelGGL((colstats_kernel<true>), grid, dim3(256), 0, s, dz, y, mean, rstd, gamma, beta, slope, sums, R, C, rpb);

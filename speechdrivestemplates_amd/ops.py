@@ -213,7 +213,13 @@ def conv_forward(x_cl, w, bias, stride, pad):
     ws = weight_storage(w)
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
     st = _stream()
-    _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_f32(_p(x4), _p(ws), _p(bias), _p(y), g, st))
+    k = lib.sdt_conv_taps_splitk_hint(g)
+    if k > 1:  # too few output tiles for 256 CUs (1-D stage): slice the K loop, then a fixed-order reduce (+bias)
+        part = torch.empty((k,) + tuple(y.shape), device=x_cl.device, dtype=torch.float32)
+        _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_splitk_f32(_p(x4), _p(ws), None, _p(y), g, k, _p(part), st))
+        check(lib.sdt_splitk_reduce_f32(_p(part), _p(bias), _p(y), y.numel(), g.Cout, k, st))
+    else:
+        _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_f32(_p(x4), _p(ws), _p(bias), _p(y), g, st))
     return y if x_cl.dim() == 4 else y.squeeze(1)
 
 
@@ -231,11 +237,18 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
     check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
     dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
     geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, stride, pad) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad)
+    k = 1
+    if all(g is not None for g, _ in geoms):
+        k = max(lib.sdt_conv_taps_splitk_hint(g) for g, _ in geoms)
+    part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
     for g, (py, px) in geoms:
         if g is None:  # parity class that no tap reaches: the gradient is zero there
             dx[:, py::(1 if one_d else stride), px::stride].zero_()
             continue
-        _conv_launch("dX", not one_d, g, lambda g=g: lib.sdt_conv_taps_f32(_p(gy4), _p(wt), None, _p(dx), g, st))
+        _conv_launch("dX", not one_d, g,
+                     lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), st))
+    if k > 1:  # every dX element belongs to exactly one parity class, so each slab is fully written
+        check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
     return dx.squeeze(1) if one_d else dx
 
 

@@ -194,8 +194,10 @@ def test_train_step_trajectory_vs_reference(golden_traj, name, code_std):
             assert int(v) == int(ref), k
             continue
         got = sl(v)
-        assert np.abs(got[:64] - ref[:64]).max() <= 2.2 * lr * steps + 2e-3 * np.abs(ref[:64]).max(), k
-        assert abs(got[65] - ref[65]) <= 2e-3 * ref[65] + 1e-6, k  # abs-sum of the whole tensor
+        # BatchNorm running statistics integrate the (slightly drifting) activations of steps 1-2: 1e-2 relative
+        rel = 1e-2 if ("running_" in k) else 2e-3
+        assert np.abs(got[:-2] - ref[:-2]).max() <= 2.2 * lr * steps + rel * np.abs(ref[:-2]).max(), k
+        assert abs(got[-1] - ref[-1]) <= rel * ref[-1] + 2.2 * lr * steps * v.numel(), k  # abs-sum of the whole tensor
     if "clips_code" in sd:
         # dense Adam moves a touched element by ~(1, 1.67, 2.2)*lr*sign(g): an element whose gradient is at the
         # fp32 noise level may legitimately flip sign between two fp32 implementations, so require agreement on
