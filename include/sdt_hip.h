@@ -94,6 +94,22 @@ int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums
                         float* dbeta, int G, int64_t R, int C, float slope, void* stream);
 
 /*
+ * First audio-encoder block fused for Cin == 1: Conv2d(1,64,k3,s1,p1,bias=False) -> InstanceNorm2d (groups = B) or
+ * training-mode BatchNorm2d (groups = 1) -> LeakyReLU(slope)   (generator.py:16, building_blocks.py:15-26,46).
+ * The statistics of all 64 channels are derived from 9+45 fp64 moments of the mel image, so z (B,H,W,64) is written once
+ * and the raw conv output is never stored; backward recomputes the normalised pre-activation from mel.
+ *   fwd: mom = workspace of 54*B doubles; writes z, mean[groups*64], rstd[groups*64] (+ BN running stats / counter).
+ *   bwd: sums = workspace of 2*groups*64 doubles; dw (64,9) and dgamma/dbeta (nullable) are ACCUMULATED.
+ */
+int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
+                         float slope, void* stream);
+int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, double* sums, float* dw, float* dgamma, float* dbeta,
+                         int B, int H, int W, int groups, float slope, void* stream);
+
+/*
  * Row normalisation over C for each of `rows` rows + LeakyReLU: the reference's InstanceNorm1d
  * applied to the (B,T,C)-permuted tensor (building_blocks.py:50-51) == per-(b,t) LayerNorm, no affine.
  */
@@ -155,10 +171,12 @@ int sdt_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, c
  *   sdt_stft_frames_f32 : audio (B,L) -> hops (B, nhops, 160), hops[b, j] = reflect_pad(audio)[j + 56]
  *   sdt_conv_taps_f32   : X = hops as (B,1,nhops,160), W = windowed DFT basis (514, 3, 160)
  *                         (row 2f = w*cos, 2f+1 = -w*sin of bin f; taps >= 400 samples are zero) -> spec (B,F,514)
- *   sdt_mel_fb_f32      : spec (B,F,2*nfreq) interleaved re/im -> mel (B, nmel, F) = fb^T |spec|^2
+ *   sdt_mel_fb_f32      : spec (B,F,2*nfreq) interleaved re/im -> mel (B, nmel, F) = fb^T |spec|^2 (sparse rows only)
  */
 int sdt_stft_frames_f32(const float* audio, float* hops, int B, int L, int nhops, void* stream);
-int sdt_mel_fb_f32(const float* spec, const float* fb, float* mel, int B, int F, int nfreq, int nmel, void* stream);
+/* bin_lo/bin_hi (nmel ints each, device): [lo,hi) range of non-zero filterbank rows of every mel filter (triangles). */
+int sdt_mel_fb_f32(const float* spec, const float* fb, const int32_t* bin_lo, const int32_t* bin_hi, float* mel, int B, int F,
+                   int nfreq, int nmel, void* stream);
 
 /* dst[idx[b], :] += src[b, :]  -- dense gradient of the clip-code table for `clips_code[clip_indices]` (voice2pose.py:94). */
 int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int B, int D, void* stream);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p],
+    "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
+    "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_rownorm_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "sdt_resize_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -49,7 +51,7 @@ SIGNATURES = {
     "sdt_final_metrics_f64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "sdt_adam_step_f32": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p, _p],
     "sdt_stft_frames_f32": [_p, _p, _i, _i, _i, _p],
-    "sdt_mel_fb_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sdt_mel_fb_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _p],
     "sdt_time_diff_fwd_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_time_diff_bwd_f32": [_p, _p, _i, _i, _i, _p],

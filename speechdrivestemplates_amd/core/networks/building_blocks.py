@@ -39,8 +39,19 @@ class ConvNormRelu(nn.Module):
         self.stride, self.padding = int(stride), int(padding)
         self.slope = ops.LEAKY_SLOPE if leaky else 0.0
 
+    def _is_l0_block(self):
+        c = self.conv
+        return (self.conv_type == '2d' and c.in_channels == 1 and c.out_channels == 64 and tuple(c.kernel_size) == (3, 3)
+                and self.stride == 1 and self.padding == 1 and (self.norm_type == 'IN' or self.training))
+
     def forward_cl(self, x_cl):
         """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last."""
+        if self._is_l0_block():  # single-channel mel image: conv + norm + activation fused, output written once
+            n = self.norm
+            if self.norm_type == 'IN':
+                return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, None, None, None, None, None, x_cl.shape[0], self.slope)
+            return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, n.weight, n.bias, n.running_mean, n.running_var,
+                                       n.num_batches_tracked, 1, self.slope)
         y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
 // spec (B,F,2*nfreq) interleaved re/im -> mel (B,nmel,F); block = 32 frames, 320 threads
 #define MEL_FT 32
 __global__ __launch_bounds__(320) void mel_fb_kernel(const float* __restrict__ spec, const float* __restrict__ fb,
+                                                     const int* __restrict__ bin_lo, const int* __restrict__ bin_hi,
                                                      float* __restrict__ mel, int F, int nfreq, int nmel) {
     extern __shared__ float sP[];  // [MEL_FT][nfreq+1]
     const int b = blockIdx.y, f0 = blockIdx.x * MEL_FT;
@@ -413,14 +414,13 @@ __global__ __launch_bounds__(320) void mel_fb_kernel(const float* __restrict__ s
     float acc[MAXF];
 #pragma unroll
     for (int i = 0; i < MAXF; ++i) acc[i] = 0.f;
-    for (int k = 0; k < nfreq; ++k) {
+    const int k0 = bin_lo[m], k1 = bin_hi[m];  // HTK triangles: a handful of non-zero bins per filter
+    for (int k = k0; k < k1; ++k) {
         const float w = fb[(size_t)k * nmel + m];
-        if (w != 0.f) {
 #pragma unroll
-            for (int i = 0; i < MAXF; ++i) {
-                const int fr = fg + npg * i;
-                if (fr < MEL_FT) acc[i] += w * sP[fr * ldp + k];
-            }
+        for (int i = 0; i < MAXF; ++i) {
+            const int fr = fg + npg * i;
+            if (fr < MEL_FT) acc[i] += w * sP[fr * ldp + k];
         }
     }
 #pragma unroll
@@ -563,12 +563,13 @@ extern "C" int sdt_stft_frames_f32(const float* audio, float* hops, int B, int L
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
-extern "C" int sdt_mel_fb_f32(const float* spec, const float* fb, float* mel, int B, int F, int nfreq, int nmel, void* stream) {
-    SDT_CHECK_ARG(spec && fb && mel && B > 0 && F > 0 && nfreq > 0, "bad argument");
+extern "C" int sdt_mel_fb_f32(const float* spec, const float* fb, const int32_t* bin_lo, const int32_t* bin_hi, float* mel,
+                              int B, int F, int nfreq, int nmel, void* stream) {
+    SDT_CHECK_ARG(spec && fb && bin_lo && bin_hi && mel && B > 0 && F > 0 && nfreq > 0, "bad argument");
     SDT_CHECK_ARG(nmel > 0 && nmel <= 320 && (MEL_FT + 320 / nmel - 1) / (320 / nmel) <= 16, "unsupported mel count");
     const size_t lds = (size_t)MEL_FT * (nfreq + 1) * sizeof(float);
     SDT_CHECK_ARG(lds <= 64 * 1024, "too many frequency bins");
-    hipLaunchKernelGGL(mel_fb_kernel, dim3(cdiv(F, MEL_FT), B), dim3(320), lds, (hipStream_t)stream, spec, fb, mel, F, nfreq, nmel);
+    hipLaunchKernelGGL(mel_fb_kernel, dim3(cdiv(F, MEL_FT), B), dim3(320), lds, (hipStream_t)stream, spec, fb, bin_lo, bin_hi, mel, F, nfreq, nmel);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -51,6 +51,8 @@ class MelSpectrogram(nn.Module):
         self.mel_scale = _MelScale(n_fft // 2 + 1, float(f_min), float(f_max), n_mels, sample_rate)
         self._basis = None
         self._basis_key = None
+        self._bins = None
+        self._bins_key = None
 
     def _dft_basis(self):
         w = self.spectrogram.window
@@ -60,7 +62,15 @@ class MelSpectrogram(nn.Module):
             self._basis_key = key
         return self._basis
 
+    def _fb_bins(self):
+        fb = self.mel_scale.fb
+        key = (fb.data_ptr(), fb._version, fb.device)
+        if self._bins is None or self._bins_key != key:
+            self._bins = ops.fb_bin_ranges(fb)
+            self._bins_key = key
+        return self._bins
+
     @torch.no_grad()
     def forward(self, waveform):
         """(B, L) -> (B, n_mels, 1 + L // hop)."""
-        return ops.mel_spectrogram(waveform, self._dft_basis(), self.mel_scale.fb)
+        return ops.mel_spectrogram(waveform, self._dft_basis(), self.mel_scale.fb, self._fb_bins())

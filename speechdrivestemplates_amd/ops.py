@@ -324,6 +324,44 @@ class ColNormActFn(torch.autograd.Function):
         return dy, None, None, None, None, None, None, None
 
 
+class L0BlockFn(torch.autograd.Function):
+    """Conv2d(1,64,k3,s1,p1) + InstanceNorm2d | BatchNorm2d(train) + LeakyReLU in one pass over the 64-channel output
+    (first block of the audio encoder, generator.py:16).  mel (B,H,W) -> z (B,H,W,64) channels-last."""
+
+    @staticmethod
+    def forward(ctx, mel, w, gamma, beta, rmean, rvar, nbt, groups, slope):
+        _req_cuda(mel, w)
+        lib = _lib.load()
+        mel = mel.contiguous()
+        B, H, W = mel.shape
+        ws = weight_storage(w)
+        z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.float32)
+        mom = torch.empty(54 * B, device=mel.device, dtype=torch.float64)
+        mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
+                                       _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _stream()))
+        ctx.save_for_backward(mel, w, mean, rstd, gamma, beta)
+        ctx.groups, ctx.slope = groups, slope
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        mel, w, mean, rstd, gamma, beta = ctx.saved_tensors
+        lib = _lib.load()
+        gz = gz.contiguous()
+        B, H, W = mel.shape
+        sums = torch.empty(2 * ctx.groups * 64, device=mel.device, dtype=torch.float64)
+        gw = grad_buffer(w)
+        if weight_storage(gw).data_ptr() != gw.data_ptr():
+            raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
+        dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
+        db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
+        check(lib.sdt_l0_block_bwd_f32(_p(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums),
+                                       _p(gw), _p(dg), _p(db), B, H, W, ctx.groups, ctx.slope, _stream()))
+        return None, None, None, None, None, None, None, None, None
+
+
 def colnorm_eval(y, gamma, beta, rmean, rvar, slope):
     lib = _lib.load()
     y = y.contiguous()
@@ -539,9 +577,21 @@ def dft_basis(window):
     return basis.float().reshape(2 * N_FREQ, 3, HOP).contiguous()
 
 
-def mel_spectrogram(audio, basis, fb):
+def fb_bin_ranges(fb):
+    """[lo,hi) of the non-zero rows of every filterbank column (int32 tensors on fb's device)."""
+    nz = (fb.detach().cpu() != 0)
+    n_freq = nz.shape[0]
+    idx = torch.arange(n_freq).unsqueeze(1)
+    lo = torch.where(nz, idx, torch.full_like(idx, n_freq)).min(0).values
+    hi = torch.where(nz, idx + 1, torch.zeros_like(idx)).max(0).values
+    lo = torch.minimum(lo, hi)
+    return lo.to(torch.int32).to(fb.device), hi.to(torch.int32).to(fb.device)
+
+
+def mel_spectrogram(audio, basis, fb, bins=None):
     """audio (B,L) -> power mel (B, n_mels, 1+L//160)  (torchaudio 0.7 MelSpectrogram as set up at voice2pose.py:27-30)."""
     _req_cuda(audio, basis, fb)
+    lo, hi = bins if bins is not None else fb_bin_ranges(fb)
     lib = _lib.load()
     audio = audio.contiguous()
     B, L = audio.shape
@@ -556,7 +606,7 @@ def mel_spectrogram(audio, basis, fb):
     check(lib.sdt_conv_taps_f32(_p(hops), _p(basis), None, _p(spec), g, st))
     nmel = fb.shape[1]
     mel = torch.empty((B, nmel, F), device=audio.device, dtype=torch.float32)
-    check(lib.sdt_mel_fb_f32(_p(spec), _p(fb.contiguous()), _p(mel), B, F, N_FREQ, nmel, st))
+    check(lib.sdt_mel_fb_f32(_p(spec), _p(fb.contiguous()), _p(lo), _p(hi), _p(mel), B, F, N_FREQ, nmel, st))
     return mel
 
 

@@ -125,6 +125,45 @@ def test_instance_norm2d_leaky(ops, shape):
     check("IN2d bwd %s" % (shape,), ops.cf_view(yd.grad), y.grad, 2e-5)
 
 
+@pytest.mark.parametrize("norm", ["IN", "BN"])
+@pytest.mark.parametrize("hw", [(80, 427), (80, 300), (7, 5)])
+def test_fused_first_block(ops, norm, hw):
+    """Conv2d(1,64,k3,p1) + IN2d|BN2d(train) + LeakyReLU fused (stats from mel moments, yhat recomputed in backward)."""
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(H * W)
+    mel = (torch.rand(B, H, W, generator=g, dtype=torch.float64) ** 3) * 40.0  # power-mel like: non-negative, heavy tail
+    w = (torch.randn(64, 1, 3, 3, generator=g, dtype=torch.float64) * (2.0 / 9) ** 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(64, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(64, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm, rv = torch.zeros(64, dtype=torch.float64), torch.ones(64, dtype=torch.float64)
+    y = F.conv2d(mel.unsqueeze(1), w, None, 1, 1)
+    u = F.instance_norm(y, eps=1e-5) if norm == "IN" else F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    z = F.leaky_relu(u, 0.2)
+    gz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(gz)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.detach().float()).to(DEV))
+    if norm == "IN":
+        zd = ops.L0BlockFn.apply(mel.float().to(DEV), wd, None, None, None, None, None, B, 0.2)
+    else:
+        gd, bd = torch.nn.Parameter(gamma.detach().float().to(DEV)), torch.nn.Parameter(beta.detach().float().to(DEV))
+        rmd, rvd = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        zd = ops.L0BlockFn.apply(mel.float().to(DEV), wd, gd, bd, rmd, rvd, nbt, 1, 0.2)
+    zd.backward(ops.cl(gz.float()).to(DEV))
+    tag = "L0 fused %s %s" % (norm, hw)
+    # gradient sums run over up to 6.5 M elements: an element whose pre-activation is within fp32 rounding of the
+    # LeakyReLU kink may take the other slope than in the float64 reference (a 0.8*|dz| change of one term)
+    check(tag + " fwd", ops.cf_view(zd), z, 2e-5)
+    check(tag + " dW", wd.grad, w.grad, 2e-3)
+    if norm == "BN":
+        check(tag + " running_mean", rmd, rm, 1e-5)
+        check(tag + " running_var", rvd, rv, 1e-5)
+        assert int(nbt.item()) == 1
+        check(tag + " dgamma", gd.grad, gamma.grad, 2e-3)
+        check(tag + " dbeta", bd.grad, beta.grad, 2e-3)
+
+
 @pytest.mark.parametrize("slope", [0.2, 0.0])
 @pytest.mark.parametrize("shape", [(4, 64, 256), (4, 2, 64), (2, 40 * 213, 64), (4, 15, 1024)])
 def test_batch_norm_train_act(ops, shape, slope):
