@@ -27,6 +27,34 @@ __device__ __forceinline__ void l0_gather(const float* __restrict__ mel, int H, 
         }
 }
 
+// Sliding 3x3 window along one image row: each step shifts the window one pixel to the right and loads the 3 new
+// right-column values (zero outside the image) -- 3 loads per pixel instead of 9 and no integer division.
+struct L0Window {
+    float nb[L0_T];
+    const float* r0;
+    const float* r1;
+    const float* r2;  // rows y-1, y, y+1 (nullptr when outside the image)
+    int W;
+    __device__ __forceinline__ float at(const float* r, int x) const { return (r != nullptr && (unsigned)x < (unsigned)W) ? r[x] : 0.f; }
+    __device__ __forceinline__ void init(const float* img, int H, int W_, int y, int x) {
+        W = W_;
+        r0 = (y - 1 >= 0) ? img + (size_t)(y - 1) * W : nullptr;
+        r1 = img + (size_t)y * W;
+        r2 = (y + 1 < H) ? img + (size_t)(y + 1) * W : nullptr;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            nb[d] = at(r0, x - 1 + d);
+            nb[3 + d] = at(r1, x - 1 + d);
+            nb[6 + d] = at(r2, x - 1 + d);
+        }
+    }
+    __device__ __forceinline__ void advance(int xnew) {  // window now centred on xnew (= previous centre + 1)
+        nb[0] = nb[1]; nb[1] = nb[2]; nb[2] = at(r0, xnew + 1);
+        nb[3] = nb[4]; nb[4] = nb[5]; nb[5] = at(r1, xnew + 1);
+        nb[6] = nb[7]; nb[7] = nb[8]; nb[8] = at(r2, xnew + 1);
+    }
+};
+
 // grid (chunks, B); mom[b][54] doubles (zeroed by the caller)
 __global__ __launch_bounds__(256) void l0_moments_kernel(const float* __restrict__ mel, double* __restrict__ mom, int H, int W,
                                                          int pix_per_block) {
@@ -125,25 +153,26 @@ __device__ __forceinline__ f32x4 l0_yhat(const L0Thread& t, const float (&nb)[L0
     return y;
 }
 
+// grid (H, B): one image row per workgroup; thread = (segment of the row, channel quad): 16 segments x 16 quads
 __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ mel, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ z, int H, int W, int groups, float slope,
-                                                     int pix_per_block) {
-    const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, pl = tid >> 4;
+                                                     float* __restrict__ z, int H, int W, int groups, float slope) {
+    const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, groups == 1 ? 0 : b, cq);
-    const float* img = mel + (size_t)b * H * W;
-    float* out = z + (size_t)b * H * W * L0_C + 4 * cq;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(H * W, p0 + pix_per_block);
-    for (int p = p0 + pl; p < p1; p += 16) {
-        float nb[L0_T];
-        l0_gather(img, H, W, p / W, p % W, nb);
-        const f32x4 yh = l0_yhat(t, nb);
+    const int len = (W + 15) / 16, x0 = seg * len, x1 = min(W, x0 + len);
+    if (x0 >= x1) return;
+    float* out = z + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
+    L0Window win;
+    win.init(mel + (size_t)b * H * W, H, W, y, x0);
+    for (int x = x0; x < x1; ++x) {
+        if (x > x0) win.advance(x);
+        const f32x4 yh = l0_yhat(t, win.nb);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_fwd(yh[e] * t.ga[e] + t.be[e], slope);
-        *(f32x4*)(out + (size_t)p * L0_C) = o;
+        *(f32x4*)(out + (size_t)x * L0_C) = o;
     }
 }
 
@@ -152,34 +181,54 @@ __global__ __launch_bounds__(256) void l0_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ w, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, double* __restrict__ sums, int H,
-                                                           int W, int groups, float slope, int pix_per_block) {
+                                                           int W, int groups, float slope, int rows_per_block) {
     __shared__ double sS[L0_C], sQ[L0_C];
-    const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, pl = tid >> 4;
+    const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
+    const int y_beg = blockIdx.x * rows_per_block, y_end = min(H, y_beg + rows_per_block);
     const int g = groups == 1 ? 0 : b;
     if (tid < L0_C) sS[tid] = 0.0, sQ[tid] = 0.0;
     __syncthreads();
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, g, cq);
-    const float* img = mel + (size_t)b * H * W;
-    const float* gin = dz + (size_t)b * H * W * L0_C + 4 * cq;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(H * W, p0 + pix_per_block);
+    const int len = (W + 15) / 16, x0 = seg * len, x1 = min(W, x0 + len);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + pl; p < p1; p += 16) {
-        float nb[L0_T];
-        l0_gather(img, H, W, p / W, p % W, nb);
-        const f32x4 yh = l0_yhat(t, nb);
-        const f32x4 gz = *(const f32x4*)(gin + (size_t)p * L0_C);
+    for (int y = y_beg; y < y_end && x0 < x1; ++y) {
+        const float* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
+        L0Window win;
+        win.init(mel + (size_t)b * H * W, H, W, y, x0);
+        for (int xb = x0; xb < x1; xb += 4) {  // 4 gradient vectors in flight per thread (HBM latency hiding)
+            f32x4 gzv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gg = gz[e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
-            s[e] += gg;
-            q[e] += gg * yh[e];
+            for (int j = 0; j < 4; ++j)
+                gzv[j] = (xb + j < x1) ? *(const f32x4*)(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = xb + j;
+                if (x < x1) {
+                    if (x > x0) win.advance(x);
+                    const f32x4 yh = l0_yhat(t, win.nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gg = gzv[j][e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
+                        s[e] += gg;
+                        q[e] += gg * yh[e];
+                    }
+                }
+            }
         }
     }
+    // the 4 segment-lanes of a wave that share a channel quad first (bits 4,5 of the lane id), then LDS / global fp64
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        atomicAdd(&sS[4 * cq + e], (double)s[e]);
-        atomicAdd(&sQ[4 * cq + e], (double)q[e]);
+        double sd = (double)s[e], qd = (double)q[e];
+        sd += __shfl_xor(sd, 16, 64);
+        sd += __shfl_xor(sd, 32, 64);
+        qd += __shfl_xor(qd, 16, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        if ((tid & 48) == 0) {
+            atomicAdd(&sS[4 * cq + e], sd);
+            atomicAdd(&sQ[4 * cq + e], qd);
+        }
     }
     __syncthreads();
     if (tid < L0_C) {
@@ -194,9 +243,11 @@ __global__ __launch_bounds__(256) void l0_dw_kernel(const float* __restrict__ dz
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const double* __restrict__ sums,
                                                     float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    int H, int W, int groups, double n_per_group, float slope, int pix_per_block) {
+                                                    int H, int W, int groups, double n_per_group, float slope,
+                                                    int rows_per_block) {
     __shared__ float sD[L0_C * L0_T];
     const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, pl = tid >> 4;
+    const int y_beg = blockIdx.x * rows_per_block, y_end = min(H, y_beg + rows_per_block);
     const int g = groups == 1 ? 0 : b;
     for (int i = tid; i < L0_C * L0_T; i += 256) sD[i] = 0.f;
     __syncthreads();
@@ -213,25 +264,36 @@ __global__ __launch_bounds__(256) void l0_dw_kernel(const float* __restrict__ dz
             if (dbeta) atomicAdd(&dbeta[4 * cq + e], (float)sg);
         }
     }
-    const float* img = mel + (size_t)b * H * W;
-    const float* gin = dz + (size_t)b * H * W * L0_C + 4 * cq;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(H * W, p0 + pix_per_block);
+    const int len = (W + 15) / 16, x0 = pl * len, x1 = min(W, x0 + len);
     float acc[4][L0_T];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < L0_T; ++k) acc[e][k] = 0.f;
-    for (int p = p0 + pl; p < p1; p += 16) {
-        float nb[L0_T];
-        l0_gather(img, H, W, p / W, p % W, nb);
-        const f32x4 yh = l0_yhat(t, nb);
-        const f32x4 gz = *(const f32x4*)(gin + (size_t)p * L0_C);
+    for (int y = y_beg; y < y_end && x0 < x1; ++y) {
+        const float* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
+        L0Window win;
+        win.init(mel + (size_t)b * H * W, H, W, y, x0);
+        for (int xb = x0; xb < x1; xb += 4) {
+            f32x4 gzv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gg = gz[e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
-            const float dy = t.ga[e] * t.rs[e] * (gg - mg[e] - yh[e] * mgy[e]);
+            for (int j = 0; j < 4; ++j)
+                gzv[j] = (xb + j < x1) ? *(const f32x4*)(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < L0_T; ++k) acc[e][k] = fmaf(dy, nb[k], acc[e][k]);
+            for (int j = 0; j < 4; ++j) {
+                const int x = xb + j;
+                if (x < x1) {
+                    if (x > x0) win.advance(x);
+                    const f32x4 yh = l0_yhat(t, win.nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gg = gzv[j][e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
+                        const float dy = t.ga[e] * t.rs[e] * (gg - mg[e] - yh[e] * mgy[e]);
+#pragma unroll
+                        for (int k = 0; k < L0_T; ++k) acc[e][k] = fmaf(dy, win.nb[k], acc[e][k]);
+                    }
+                }
+            }
         }
     }
     // reduce over the 16 pixel lanes that share a channel quad: lanes tid = pl*16 + cq -> xor over bits 4,5 inside a
@@ -250,7 +312,7 @@ __global__ __launch_bounds__(256) void l0_dw_kernel(const float* __restrict__ dz
 }
 
 // ---------------------------------------------------------------------------------------------
-static int l0_ppb(int HW) { return std::max(256, std::min(2048, cdiv(HW, 16) / 16 * 16)); }
+static int l0_ppb(int HW) { return std::max(1024, std::min(4096, cdiv(HW, 8) / 256 * 256)); }  // moments kernel only
 
 extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -267,7 +329,7 @@ extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, 
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_finalize_kernel, dim3(cdiv(groups * L0_C, 64)), dim3(64), 0, s, mom, w, mean, rstd, running_mean,
                        running_var, num_batches_tracked, B, groups, n, eps, momentum);
-    hipLaunchKernelGGL(l0_fwd_kernel, grid, dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, z, H, W, groups, slope, ppb);
+    hipLaunchKernelGGL(l0_fwd_kernel, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, z, H, W, groups, slope);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
@@ -278,13 +340,16 @@ extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const flo
     SDT_CHECK_ARG(dz && mel && w && mean && rstd && sums && dw, "null pointer");
     SDT_CHECK_ARG(B > 0 && H > 0 && W > 0 && (groups == B || groups == 1), "bad dims (groups must be B or 1)");
     hipStream_t s = (hipStream_t)stream;
-    const int HW = H * W, ppb = l0_ppb(HW);
-    dim3 grid(cdiv(HW, ppb), B);
+    const int HW = H * W;
+    // several image rows per workgroup: ~2 workgroups per CU keeps HBM busy while bounding the number of workgroups
+    // that push their partial sums through the same global atomics
+    const int rpb = std::max(1, (H * B) / 1280);
+    dim3 grid(cdiv(H, rpb), B);
     hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)groups * L0_C, s);
-    hipLaunchKernelGGL(l0_bwd_stats_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, ppb);
+    hipLaunchKernelGGL(l0_bwd_stats_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_dw_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, dw, dgamma, dbeta, H, W,
-                       groups, n, slope, ppb);
+                       groups, n, slope, rpb);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

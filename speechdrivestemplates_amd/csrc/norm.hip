@@ -261,7 +261,8 @@ static int colnorm_rows_per_block(int C, int G, int64_t R) {
     // <= 64 rows per thread (fp32 partials stay accurate); for short row counts shrink the chunk so that the
     // launch still spreads over >= ~256 workgroups instead of serialising a long dependent loop in a few of them
     const int rpp = 256 / (C >> 2);
-    const int64_t want = cdiv64(R, std::max(1, 256 / G));
+    // one group (BatchNorm): every workgroup funnels 2*C fp64 atomics into the same addresses -> fewer, longer workgroups
+    const int64_t want = cdiv64(R, G == 1 ? 64 : std::max(1, 256 / G));
     const int64_t rpb = cdiv64(want, rpp) * rpp;
     return (int)std::min<int64_t>(std::max<int64_t>(rpb, rpp), (int64_t)rpp * 64);
 }
