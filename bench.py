@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 N_CLIPS = 4096
+EVENT_EVERY = 6  # HIP events around every conv launch on every 6th timed step (recording them perturbs the step)
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -98,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
+    ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient kernels on a side stream (measured: no gain)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +116,7 @@ def main():
     from __graft_entry__ import make_pipeline
     from speechdrivestemplates_amd import ops
     B = args.batch
+    ops.OVERLAP_DW = bool(args.overlap_dw)
     pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
     batches = stage_batches(4, B, rank, dev)
 
@@ -132,21 +135,21 @@ def main():
         runner(i)
     prof = None
     if not args.no_kernel_events and not (args.graph and world == 1):
-        prof = ops.ConvProfiler()
+        prof = ops.ConvProfiler(pool=2 * 200 * (args.steps // EVENT_EVERY + 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if prof is not None:  # HIP events on every 4th step of the timed region (recording them costs ~0.7 ms/step)
-            ops.PROFILER = prof if i % 4 == 3 else None
+        if prof is not None:  # sampled: the events serialise the host a little and cost a few % on the steps they cover
+            ops.PROFILER = prof if i % EVENT_EVERY == EVENT_EVERY - 1 else None
         losses = runner(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
-    prof_steps = len([i for i in range(args.steps) if i % 4 == 3])
+    prof_steps = len([i for i in range(args.steps) if i % EVENT_EVERY == EVENT_EVERY - 1])
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -21,7 +21,7 @@
 #define SDT_OOB 0x80000000u
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, bool VEC4>
+template <int BM, int BN, bool VEC4, int PRIO = 0>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         const sdt_conv_geom g, const int splitk,
@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     const int wm = wave >> 1, wn = wave & 1;
     const int M = g.B * g.Ho * g.Wo;
     const int nmb = (M + BM - 1) / BM;
+    if constexpr (PRIO == 2) {  // static per-workgroup priority: de-synchronises the co-resident workgroups' phases
+        switch ((blockIdx.x >> 3) & 3) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            default: break;
+        }
+    }
     const int m0 = xcd_remap(blockIdx.x, nmb) * BM;
     const int n0 = blockIdx.y * BN;
 
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         if (step + 1 < nsteps) load(step + 1);
         // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
         // sub-step (j,e) consumes k = 8j + 4h + e, so each lane feeds 4 MFMAs from one ds_read_b128.
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 a[TM], b[TN];
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
         }
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 
@@ -457,7 +467,12 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
     const int M = g.B * g.Ho * g.Wo;
     const size_t ysize = (size_t)g.B * g.Hy * g.Wy * g.Cout;
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), splitk);
-    if (vec4)
+    static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // tuning experiments
+    if (vec4 && prio == 1)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 2)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 2>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);

@@ -31,6 +31,8 @@ class GradReducer:
         """Start the all-reduce of one optimiser group's gradients (call when its backward has finished)."""
         if self.ws == 1:
             return
+        from . import ops
+        ops.join_side_stream()  # side-stream weight-gradient kernels write into this buffer
         buf = opt.flat_grad
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())

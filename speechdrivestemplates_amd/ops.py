@@ -159,8 +159,16 @@ class ConvProfiler:
     """Optional HIP-event timing of every MFMA conv launch (bench.py's roofline leg).  Events are recorded on the
     stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
 
-    def __init__(self):
+    def __init__(self, pool=0):
         self.records = []  # (kernel name, role, is_2d, algorithmic flops, algorithmic bytes, start, end)
+        # hipEventCreate happens at an event's first record(): warm a pool before the timed region so that recording
+        # inside it is a bare hipEventRecord
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+        for e in self.pool:
+            e.record()
+
+    def event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     @staticmethod
     def kernel_name(kind, variant):
@@ -197,7 +205,7 @@ def _conv_launch(kind, is2d, g, call):
     flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
     # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, fp32
     nbytes = 4.0 * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = PROFILER.event(), PROFILER.event()
     e0.record()
     check(call())
     e1.record()
@@ -265,6 +273,27 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
     _conv_launch("dW", w.dim() == 4, g, lambda: lib.sdt_conv_dw_f32(_p(x4), _p(gy4), _p(gws), g, st))
 
 
+# Weight gradients are off the backward critical path (only the optimiser consumes them): with OVERLAP_DW they are
+# launched on a side HIP stream, concurrently with the input-gradient / normalisation chain on the main stream, so the
+# two fill each other's launch tails and the latency-bound 1-D launches.  join_side_stream() is called before the
+# gradient exchange / optimiser step.
+OVERLAP_DW = False
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
+def join_side_stream():
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    if dev in _SIDE:
+        torch.cuda.current_stream().wait_stream(_SIDE[dev])
+
+
 class ConvFn(torch.autograd.Function):
     """nn.Conv1d/nn.Conv2d (building_blocks.py:15-22,31-38; generator.py:103) on channels-last tensors."""
 
@@ -280,7 +309,15 @@ class ConvFn(torch.autograd.Function):
         x_cl, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
         if w.requires_grad:
-            conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
+            if OVERLAP_DW and PROFILER is None and not torch.cuda.is_current_stream_capturing():
+                side = _side_stream()
+                side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
+                with torch.cuda.stream(side):
+                    conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
+                gy.record_stream(side)  # keep the caching allocator from recycling gy under the side stream
+                x_cl.record_stream(side)
+            else:
+                conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
         if bias is not None and bias.requires_grad:
             gb = grad_buffer(bias)
             check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))

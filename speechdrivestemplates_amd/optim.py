@@ -62,6 +62,7 @@ class FlatAdam:
 
     def step(self):
         g = self.param_groups[0]
+        ops.join_side_stream()  # weight-gradient kernels may still be running on the side stream (ops.OVERLAP_DW)
         self.sync_lr()
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.state_dev,
                       g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.grad_scale)
