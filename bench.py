@@ -154,7 +154,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(losses["G_loss"].detach())
+    final_loss = float(losses["G_loss" if "G_loss" in losses else "loss"].detach())
     assert final_loss == final_loss and final_loss < 10.0, "training diverged: G_loss=%r" % final_loss
 
     if rank == 0:

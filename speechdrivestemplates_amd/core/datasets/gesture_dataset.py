@@ -102,6 +102,12 @@ class SyntheticGestureDataset(PoseTransforms, Dataset):
         self.cfg = cfg.DATASET
         self.speaker, self.split, self.seed = speaker or 'synthetic', split, seed
         self.num_clips = int(num_clips if num_clips is not None else getattr(self.cfg, 'SYNTHETIC_CLIPS', 4096))
+        if self.speaker not in SPEAKERS_STAT_121:  # s2g's parted->global re-normalisation looks statistics up by name
+            rng = np.random.Generator(np.random.PCG64([seed, 7]))
+            K2 = 2 * self.cfg.NUM_LANDMARKS
+            register_speaker_stat(self.speaker,
+                                  parted={'scale_factor': 1.0, 'mean': rng.standard_normal(K2) * 20.0, 'std': rng.uniform(2.0, 30.0, K2)},
+                                  global_={'scale_factor': 1.0, 'mean': rng.standard_normal(K2) * 60.0, 'std': rng.uniform(5.0, 80.0, K2)})
         per_frame = self.cfg.AUDIO_SR / self.cfg.FPS  # parse_audio_length, audio_processing.py:5-11
         self.num_frames = int(self.cfg.AUDIO_LENGTH / per_frame)
         self.audio_length = int(self.num_frames * per_frame)

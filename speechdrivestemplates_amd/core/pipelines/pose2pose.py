@@ -57,7 +57,7 @@ class Pose2Pose(Trainer):
             self.schedulers['scheduler'] = _MultiStepLR(opt, [E - 10, E - 2], 0.1, last_epoch)
         self.reducer = dp.GradReducer(self.optimizers.values())
 
-    def train_step(self, batch, t_step, global_step, epoch):
+    def forward_backward(self, batch, want_final=False):
         dev = self.model.clip_code_mu.device
         losses, results = self.model(batch)
         stat = batch['speaker_stat']
@@ -71,8 +71,16 @@ class Pose2Pose(Trainer):
         opt = self.optimizers['optimizer']
         opt.zero_grad()
         losses['loss'].backward()
+        return losses, results
+
+    def optimizer_updates(self, losses):
+        opt = self.optimizers['optimizer']
         self.reducer.all_reduce([opt])
         opt.step()
+
+    def train_step(self, batch, t_step, global_step, epoch):
+        losses, _ = self.forward_backward(batch)
+        self.optimizer_updates(losses)
         self.last_losses = losses
         if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
             if self.cfg.SYS.DISTRIBUTED:
