@@ -538,6 +538,9 @@ class OracleVoice2Pose:
 
     def train_step(self, batch, stats_s2g=None):
         losses, results = voice2pose_forward(self.state, batch, self.cfg, True, stats_s2g)
+        return self._finish_step(losses, results, batch)
+
+    def _finish_step(self, losses, results, batch):
         hier = self.cfg.DATASET.HIERARCHICAL_POSE
         fin_p = get_final_results(results["poses_pred_batch"].detach(), batch["speaker_stat"], hier)
         fin_g = get_final_results(results["poses_gt_batch"].detach(), batch["speaker_stat"], hier)
@@ -554,4 +557,29 @@ class OracleVoice2Pose:
             losses["D_pose_gan_loss"].backward()
             self.opt["optimizerD_pose"].step()
         results["final_pred"], results["final_gt"] = fin_p, fin_g
+        return {k: v.detach() for k, v in losses.items()}, results
+
+
+class OraclePose2Pose:
+    """Pose2Pose.train_step (pose2pose.py:124-149) on an oracle-held state; ``eps`` is the reparameterisation noise."""
+
+    def __init__(self, cfg, state, lr=None):
+        self.cfg, self.state = cfg, state
+        for k, v in state.items():
+            if k.startswith("ae.") and v.is_floating_point() and not k.endswith(_NON_PARAM_SUFFIX):
+                v.requires_grad_(True)
+        self.opt = torch.optim.Adam([v for k, v in state.items() if k.startswith("ae.") and v.requires_grad],
+                                    lr=cfg.TRAIN.LR if lr is None else lr, weight_decay=cfg.TRAIN.WD)
+
+    def train_step(self, batch, eps):
+        losses, results = pose2pose_forward(self.state, batch, self.cfg, eps, True)
+        fin_p = get_final_results(results["poses_pred_batch"].detach(), batch["speaker_stat"], self.cfg.DATASET.HIERARCHICAL_POSE)
+        fin_g = get_final_results(results["poses_gt_batch"].detach(), batch["speaker_stat"], self.cfg.DATASET.HIERARCHICAL_POSE)
+        losses.update(evaluate_step(fin_p, fin_g))
+        idx = batch["clip_index"]
+        self.state["clip_code_mu"][idx] = results["clip_code_mu"].detach()  # pose2pose.py:135-137
+        self.state["clip_code_logvar"][idx] = results["clip_code_logvar"].detach()
+        self.opt.zero_grad()
+        losses["loss"].backward()
+        self.opt.step()
         return {k: v.detach() for k, v in losses.items()}, results

@@ -88,6 +88,14 @@ def run_reference_model(cfg_name, B, n_clips, steps, code_std, dtype=torch.float
     import core.datasets.speakers_stat as SS
     cfg = O.cfg_named(cfg_name)
     st0 = O.make_voice2pose_state(cfg, n_clips, seed=0, dtype=dtype, code_std=code_std)
+    ext = None
+    if cfg.VOICE2POSE.GENERATOR.CLIP_CODE.EXTERNAL_CODE:  # sdt_vae: fixed codes come from a pose-VAE checkpoint file
+        import tempfile
+        ext = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((n_clips, 32)).astype(np.float32))
+        f = tempfile.NamedTemporaryFile(suffix=".pth", delete=False)
+        torch.save({"model_state_dict": {"module.clip_code_mu": ext, "module.clip_code_logvar": torch.zeros_like(ext)}}, f.name)
+        cfg.VOICE2POSE.POSE_ENCODER.AE_CHECKPOINT = f.name
+        st0.pop("clips_code")
     model = Voice2PoseModel(cfg, None, n_clips)
     if dtype == torch.float64:
         model = model.double()
@@ -137,10 +145,59 @@ def run_reference_model(cfg_name, B, n_clips, steps, code_std, dtype=torch.float
         if step == 0:
             for k, g in grads.items():
                 out[f"s0/grad/{k}"] = sl(g)
+    if ext is not None:
+        os.unlink(cfg.VOICE2POSE.POSE_ENCODER.AE_CHECKPOINT)
+        assert torch.equal(model.clips_code, ext)
     for k, v in model.state_dict().items():
         out[f"final/{k}"] = sl(v) if v.is_floating_point() else np.array(v.item())
     if "clips_code" in model.state_dict():
         out["final_full/clips_code_rows"] = model.state_dict()["clips_code"][: 3 * B].numpy()
+    return out
+
+
+def run_reference_pose2pose(B, n_clips, steps):
+    """Replays pose2pose.py:124-149 around the imported Pose2PoseModel (reparameterisation noise injected)."""
+    from core.pipelines.pose2pose import Pose2PoseModel
+    cfg = O.cfg_named("pose2pose")
+    st0 = O.make_pose2pose_state(cfg, n_clips, seed=0)
+    model = Pose2PoseModel(cfg, None, n_clips)
+    st0["mel_transfm.spectrogram.window"] = O.mel_window()
+    st0["mel_transfm.mel_scale.fb"] = O.mel_filterbank()
+    r = model.load_state_dict(clone_state(st0), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    model.train()
+    ds = ref_dataset(True)
+    opt = torch.optim.Adam(model.ae.parameters(), lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
+    out = {}
+    real_randn = torch.randn
+    for step in range(steps):
+        batch = O.make_batch(B, n_clips, step=step, seed=1)
+        eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((B, 32)).astype(np.float32))
+        torch.randn = lambda *a, **k: eps.clone()
+        try:
+            losses, results = model(batch)
+        finally:
+            torch.randn = real_randn
+        fin_p = ds.get_final_results(results["poses_pred_batch"].detach(), batch["speaker_stat"])
+        fin_g = ds.get_final_results(results["poses_gt_batch"].detach(), batch["speaker_stat"])
+        metrics = O.evaluate_step(fin_p, fin_g)
+        idx = batch["clip_index"]
+        model.clip_code_mu[idx] = results["clip_code_mu"].detach()
+        model.clip_code_logvar[idx] = results["clip_code_logvar"].detach()
+        opt.zero_grad()
+        losses["loss"].backward(retain_graph=True)
+        if step == 0:
+            for k, p in model.named_parameters():
+                out[f"s0/grad/{k}"] = sl(p.grad)
+        opt.step()
+        for k, v in losses.items():
+            out[f"s{step}/loss/{k}"] = np.array(v.item())
+        for k, v in metrics.items():
+            out[f"s{step}/metric/{k}"] = np.array(v.item())
+        out[f"s{step}/pred"] = sl(results["poses_pred_batch"])
+        out[f"s{step}/mu"] = results["clip_code_mu"].detach().numpy()
+    for k, v in model.state_dict().items():
+        out[f"final/{k}"] = sl(v) if v.is_floating_point() else np.array(v.item())
     return out
 
 
@@ -239,12 +296,16 @@ def main():
     # ---- (3) full model: losses, grads, 3-step Adam trajectories -------------------------------
     traj = {}
     for name, Bm, code_std in (("voice2pose_sdt_bp", 4, 0.5), ("voice2pose_sdt_bp_zero", 4, 0.0),
-                               ("voice2pose_s2g", 4, 0.0)):
+                               ("voice2pose_s2g", 4, 0.0), ("voice2pose_sdt_vae", 4, 0.0)):
         cfg_name = name.replace("_zero", "")
         res = run_reference_model(cfg_name, Bm, 16, 3, code_std)
         for k, v in res.items():
             traj[f"{name}/{k}"] = v
         print(name, {k: float(v) for k, v in res.items() if "/loss/" in k})
+    res = run_reference_pose2pose(4, 16, 3)
+    for k, v in res.items():
+        traj[f"pose2pose/{k}"] = v
+    print("pose2pose", {k: float(v) for k, v in res.items() if "/loss/" in k})
     # fp64 reference run of the same sdt_bp trajectory: sets the tolerance floor
     res = run_reference_model("voice2pose_sdt_bp", 4, 16, 1, 0.5, dtype=torch.float64)
     for k, v in res.items():

@@ -111,12 +111,20 @@ def _stats_s2g():
     return parted, glob
 
 
-@pytest.mark.parametrize("name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_bp_zero", 0.0), ("voice2pose_s2g", 0.0)])
+def _v2p_state(cfg, code_std):
+    st = O.make_voice2pose_state(cfg, 16, seed=0, code_std=code_std)
+    if cfg.VOICE2POSE.GENERATOR.CLIP_CODE.EXTERNAL_CODE:  # sdt_vae: fixed codes (seed 9), as in make_golden.py
+        st["clips_code"] = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((16, 32)).astype(np.float32))
+    return st
+
+
+@pytest.mark.parametrize("name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_bp_zero", 0.0), ("voice2pose_s2g", 0.0),
+                                           ("voice2pose_sdt_vae", 0.0)])
 def test_train_trajectory(golden_traj, name, code_std):
     torch.manual_seed(0)
     cfg_name = name.replace("_zero", "")
     cfg = O.cfg_named(cfg_name)
-    st = O.make_voice2pose_state(cfg, 16, seed=0, code_std=code_std)
+    st = _v2p_state(cfg, code_std)
     eng = O.OracleVoice2Pose(cfg, st)
     stats = _stats_s2g() if cfg_name == "voice2pose_s2g" else None
     g = {k[len(name) + 1:]: v for k, v in golden_traj.items() if k.startswith(name + "/")}
@@ -126,7 +134,7 @@ def test_train_trajectory(golden_traj, name, code_std):
             # capture grads of the G backward before the optimiser consumes them
             losses, results = O.voice2pose_forward(st, batch, cfg, True, stats)
             # undo the BN running-stat side effects of this probing forward by rebuilding the engine
-            st = O.make_voice2pose_state(cfg, 16, seed=0, code_std=code_std)
+            st = _v2p_state(cfg, code_std)
             eng = O.OracleVoice2Pose(cfg, st)
         losses, results = eng.train_step(batch, stats)
         want = {k.split("/")[-1] for k in g if k.startswith(f"s{step}/loss/")}
@@ -141,13 +149,38 @@ def test_train_trajectory(golden_traj, name, code_std):
             close(results[k].numpy(), g[f"s{step}/{k}"], 2e-3, 2e-4)
     # weights after 3 Adam steps (dense Adam on the code table included), BN buffers, counters
     for k, v in st.items():
+        if f"final/{k}" not in g:  # external codes are a plain attribute, not part of the reference state_dict
+            assert k == "clips_code" and cfg.VOICE2POSE.GENERATOR.CLIP_CODE.EXTERNAL_CODE
+            continue
         ref = g[f"final/{k}"]
         if v.is_floating_point():
             close(sl(v), ref, 2e-3, 2e-5)
         else:
             assert int(v) == int(ref), k
-    if "clips_code" in st:
+    if "final_full/clips_code_rows" in g:
         close(st["clips_code"][:12].detach().numpy(), g["final_full/clips_code_rows"], 2e-3, 2e-6)
+
+
+def test_pose2pose_trajectory(golden_traj):
+    cfg = O.cfg_named("pose2pose")
+    st = O.make_pose2pose_state(cfg, 16, seed=0)
+    eng = O.OraclePose2Pose(cfg, st)
+    g = {k[len("pose2pose/"):]: v for k, v in golden_traj.items() if k.startswith("pose2pose/")}
+    for step in range(3):
+        batch = O.make_batch(4, 16, step=step, seed=1)
+        eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((4, 32)).astype(np.float32))
+        losses, results = eng.train_step(batch, eps)
+        for k in ("reg_loss", "kl_loss", "loss"):
+            close(losses[k].item(), g[f"s{step}/loss/{k}"], 2e-5, 1e-6)
+        close(losses["L2_dist"].item(), g[f"s{step}/metric/L2_dist"], 2e-5, 1e-6)
+        close(sl(results["poses_pred_batch"]), g[f"s{step}/pred"], 2e-3, 2e-5)
+        close(results["clip_code_mu"].detach().numpy(), g[f"s{step}/mu"], 2e-3, 2e-4)
+    for k, v in st.items():
+        ref = g[f"final/{k}"]
+        if v.is_floating_point():
+            close(sl(v), ref, 2e-3, 2e-5)
+        else:
+            assert int(v) == int(ref), k
 
 
 def test_kl_skip_on_zero_codes(golden_traj):
