@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
+    ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient kernels on a side stream (measured: no gain)")
     args = ap.parse_args()
 
@@ -117,6 +118,7 @@ def main():
     from speechdrivestemplates_amd import ops
     B = args.batch
     ops.OVERLAP_DW = bool(args.overlap_dw)
+    ops.OVERLAP_AUX = not args.no_overlap_aux
     pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
     batches = stage_batches(4, B, rank, dev)
 

@@ -127,12 +127,17 @@ class Voice2PoseModel(nn.Module):
         losses['G_loss'] = g_loss
 
         if cfg.VOICE2POSE.POSE_ENCODER.NAME is not None:  # FGD features, off the loss path (voice2pose.py:160-176)
-            with torch.no_grad():
+            # These 14 small conv+BN launches are latency-bound and feed only results_dict: with ops.OVERLAP_AUX they
+            # run on a side stream, concurrently with the MFMA-bound backward pass that follows on the main stream
+            # (ops.join_side_stream() before the optimiser step / before the results are read).
+            side = ops.side_stream_scope(self.training and torch.is_grad_enabled())
+            with side, torch.no_grad():
                 if cfg.DATASET.HIERARCHICAL_POSE:
-                    e_pred, e_gt = poses_pred, poses_gt
+                    e_pred, e_gt = poses_pred.detach(), poses_gt
                 else:
                     e_pred = dataset.transform_normalized_parted2global(poses_pred.detach().clone(), speaker)
                     e_gt = dataset.transform_normalized_parted2global(poses_gt.clone(), speaker)
+                side.uses(e_pred, e_gt)
                 mu_pred, logvar_pred = self.pose_encoder(e_pred)
                 mu_gt, logvar_gt = self.pose_encoder(e_gt)
             results.update(mu_pred=mu_pred, mu_gt=mu_gt, logvar_pred=logvar_pred, logvar_gt=logvar_gt)

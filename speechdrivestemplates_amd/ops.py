@@ -288,6 +288,37 @@ def _side_stream():
     return _SIDE[dev]
 
 
+OVERLAP_AUX = False
+
+
+class side_stream_scope:
+    """``with side_stream_scope(enabled):`` runs the body on the side stream (after everything queued on the main
+    stream so far) when OVERLAP_AUX is on and ``enabled``; otherwise it is a no-op."""
+
+    def __init__(self, enabled=True):
+        self.on = bool(enabled and OVERLAP_AUX and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing())
+        self.ctx = None
+
+    def __enter__(self):
+        if self.on:
+            self.side = _side_stream()
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def uses(self, *tensors):
+        if self.on:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.side)  # produced on the main stream, consumed here
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def join_side_stream():
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
     if dev in _SIDE:

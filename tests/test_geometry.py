@@ -158,3 +158,18 @@ def test_ops_refuse_cpu_tensors():
     x = torch.zeros(1, 4, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.RowNormActFn.apply(x, 0.2)
+
+
+def test_fgd_matches_closed_form():
+    """FGD of two Gaussians with diagonal covariances has a closed form; also symmetric and zero on identical sets."""
+    import numpy as np
+    from speechdrivestemplates_amd.fgd import compute_fgd
+    rng = np.random.default_rng(0)
+    n, d = 200000, 6
+    s1, s2 = np.array([1.0, 0.5, 2.0, 1.5, 0.7, 1.1]), np.array([0.8, 0.9, 1.0, 2.0, 0.6, 1.4])
+    m = np.array([0.3, -0.2, 0.0, 0.5, 0.1, -0.4])
+    a, b = rng.standard_normal((n, d)) * s1, rng.standard_normal((n, d)) * s2 + m
+    exact = (m ** 2).sum() + ((s1 - s2) ** 2).sum()
+    got = compute_fgd(a, b)
+    assert abs(got - exact) < 0.03 * exact, (got, exact)
+    assert abs(compute_fgd(a, b) - compute_fgd(b, a)) < 1e-9 and abs(compute_fgd(a, a)) < 1e-8

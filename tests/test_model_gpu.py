@@ -292,3 +292,58 @@ def test_checkpoint_roundtrip_and_flat_buffers():
     pipe2.optimizer_updates(l2)
     check("resumed run reproduces G_loss", l2["G_loss"], l1["G_loss"], 1e-5)
     check("resumed run reproduces weights", pipe2.model.netG.decoder[4].weight, pipe.model.netG.decoder[4].weight, 1e-5)
+
+
+def test_aux_stream_overlap_is_bit_identical():
+    """ops.OVERLAP_AUX runs the no-grad pose-encoder passes on a side stream: results, BN buffers and weights after
+    two steps must equal the single-stream run exactly (same kernels, same order per stream, deterministic split-K)."""
+    from speechdrivestemplates_amd import ops
+    outs = []
+    for flag in (False, True):
+        ops.OVERLAP_AUX = flag
+        try:
+            pipe, _ = _make_pipeline("voice2pose_sdt_vae", 16, 0.0)  # no atomically-accumulated code-table gradient
+            for step in range(2):
+                losses, results = pipe.forward_backward(O.make_batch(4, 16, step=step, seed=1))
+                pipe.optimizer_updates(losses)
+            torch.cuda.synchronize()
+            outs.append((results["mu_pred"].clone(), results["logvar_gt"].clone(), losses["G_reg_loss"].clone(),
+                         pipe.model.pose_encoder.blocks[3].norm.running_var.clone(), results["poses_pred_normalized"].clone()))
+        finally:
+            ops.OVERLAP_AUX = False
+    for a, b in zip(*outs):
+        # weight gradients use fp32 atomics (order-dependent in the last bit), so allow 1e-6 on anything downstream of them
+        check("overlap vs single stream", b, a, 2e-5)
+
+
+def test_validate_loop_and_fgd():
+    """Row f-1: eval-mode test_step over a small synthetic validation set + epoch-level FGD (voice2pose.py:333-384,432-446,
+    trainer.py:407-427, core/utils/fgd.py)."""
+    from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
+    from speechdrivestemplates_amd.fgd import compute_fgd
+    pipe, cfg = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+    pipe.test_dataset = gd.SyntheticGestureDataset(cfg=cfg, num_clips=8, split='val')
+    pipe.test_dataloader = torch.utils.data.DataLoader(pipe.test_dataset, batch_size=4, shuffle=False)
+    pipe.num_test_samples, pipe.num_test_batches = 8, 2
+    # one training step first so that BN running statistics of the pose encoder are not the init values
+    losses, _ = pipe.forward_backward(O.make_batch(4, 16, step=0, seed=1))
+    pipe.optimizer_updates(losses)
+    out = pipe.validate(epoch=1)
+    for k in ("G_reg_loss", "G_loss", "L2_dist", "lip_sync_error_n", "FGD_mu", "FGD_mu_logvar"):
+        assert k in out and np.isfinite(float(out[k])), (k, out.get(k))
+    assert not pipe.model.training  # validate() leaves the model in eval mode like the reference (trainer.py:409)
+    # eval forward against the oracle in eval mode (running-stat BN, random code rows replaced by fixed ones)
+    pipe.model.eval()
+    batch = O.make_batch(4, 16, step=5, seed=1)
+    st = {k: v.detach().cpu().clone() for k, v in pipe.model.state_dict().items()}
+    torch.manual_seed(3)
+    with torch.no_grad():
+        _, res = pipe.model(batch, pipe.test_dataset)
+    code = res["condition_code"].cpu()
+    mel = O.mel_spectrogram(batch["audio"])
+    ref = O.generator(st, "netG", mel, 64, code, O.cfg_named("voice2pose_sdt_bp"), False)
+    check("eval-mode prediction vs oracle", res["poses_pred_batch"], ref, 2e-4)
+    mu_ref, _ = O.pose_seq_encoder(st, "pose_encoder", batch["poses"], O.cfg_named("voice2pose_sdt_bp"), False)
+    check("eval-mode pose-encoder features vs oracle", res["mu_gt"], mu_ref, 5e-4)
+    a, b = np.random.default_rng(0).standard_normal((200, 32)), np.random.default_rng(1).standard_normal((200, 32)) + 0.1
+    assert abs(compute_fgd(a, a)) < 1e-6 and compute_fgd(a, b) > 0.1
