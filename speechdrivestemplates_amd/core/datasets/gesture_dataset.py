@@ -4,6 +4,8 @@ consumes (:107-119) and the pose transforms that run inside every train/test ste
 Round-1 scope: the transforms (torch, device-agnostic; the per-step fused float64 version is the
 ``sdt_final_metrics_f64`` kernel) and a seeded synthetic dataset with the reference's field layout.  The
 on-disk csv/npz reader of the reference (:85-105,124-145) is a "next" row."""
+import os
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -80,18 +82,90 @@ class PoseTransforms:
         return self.normalize_poses(poses, stat_g)
 
 
+_KEEP_137 = list(range(0, 8)) + [15, 16] + list(range(25, 137))  # OpenPose-137 -> 122: drop lower body (:131-136)
+_DROP_ROOT = [0] + list(range(2, 122))                            # 122 -> 121: remove the root joint (:138-145)
+
+
+def crop_pad_audio(wav, audio_length):
+    """core/utils/audio_processing.py:14-19."""
+    if len(wav) > audio_length:
+        return wav[:audio_length]
+    if len(wav) < audio_length:
+        return np.pad(wav, [0, audio_length - len(wav)], mode='constant', constant_values=0)
+    return wav
+
+
+def parse_audio_length(audio_length, sr, fps):
+    """core/utils/audio_processing.py:5-11 -- (68267, 16000, 15) -> (68266, 64)."""
+    per_frame = sr / fps
+    num_frames = int(audio_length / per_frame)
+    return int(num_frames * per_frame), num_frames
+
+
 class GestureDataset(PoseTransforms, Dataset):
-    """Transform-only stand-in with the reference's class name: it carries cfg.DATASET and the pose
-    transforms; reading processed_137.csv / clip npz files is not implemented in this round."""
+    """On-disk clips in the reference's format (gesture_dataset.py:14-119): ``<root>/<speaker>/processed_137.csv``
+    with columns dataset,start,end,interval_id,pose_fn,audio_fn,video_fn,speaker and one npz per clip holding
+    ``pose (>=64,3,137)`` (x, y, confidence in pixels) and ``audio``.  ``__getitem__`` reproduces :85-119: crop/pad the
+    audio to 68266 samples, 137 -> 122 -> 121 keypoints relative to the root joint, hierarchical ("parted") offsets,
+    normalisation with the speaker's statistics.  Speaker statistics are data: register them with
+    ``register_speaker_stat`` / ``load_speaker_stats`` (the reference hard-codes them in speakers_stat.py).
+    ``root_dir=None`` gives a transform-only instance (what Voice2PoseModel.forward needs of a dataset)."""
 
     def __init__(self, root_dir=None, speaker=None, split='train', cfg=None, demo_input=None):
         self.cfg = cfg.DATASET
         self.speaker, self.split = speaker, split
-        if root_dir is not None:
-            raise NotImplementedError('on-disk GestureDataset reading is a next-round item; use SyntheticGestureDataset')
+        self.clips = None
+        if root_dir is None:
+            return
+        assert speaker is not None, 'The speaker is "None"!'
+        self.root_dir = os.path.join(root_dir, speaker)
+        if split == 'demo':
+            raise NotImplementedError('demo input (wav via librosa) is outside the training hot path')
+        if split not in ('train', 'val'):
+            raise NotImplementedError(split)
+        csv_path = os.path.join(self.root_dir, 'processed_137.csv')
+        if not os.path.exists(csv_path):
+            raise FileNotFoundError('No csv file: %s' % csv_path)
+        import pandas as pd
+        clips = pd.read_csv(csv_path)
+        self.clips = clips[clips['dataset'] == ('train' if split == 'train' else 'dev')]
+        if self.cfg.SUBSET is not None:
+            self.clips = self.clips[:self.cfg.SUBSET]
 
     def __len__(self):
-        return 0
+        return 0 if self.clips is None else len(self.clips)
+
+    def remove_unuesd_kp(self, poses):
+        assert poses.shape[-1] == 137
+        return poses[..., :, _KEEP_137]
+
+    def absolute_to_relative(self, poses):
+        poses[..., :2, :] = poses[..., :2, :] - poses[..., :2, self.root_node, None]
+        return poses[..., :, _DROP_ROOT]
+
+    def __getitem__(self, idx):
+        clip = self.clips.iloc[idx]
+        speaker = clip['speaker']
+        arr = np.load(os.path.join(self.root_dir, clip['pose_fn']))
+        audio_length, num_frames = parse_audio_length(self.cfg.AUDIO_LENGTH, self.cfg.AUDIO_SR, self.cfg.FPS)
+        audio = crop_pad_audio(arr['audio'], audio_length)
+        p = torch.Tensor(arr['pose'][:self.cfg.NUM_FRAMES, ...])
+        p = self.absolute_to_relative(self.remove_unuesd_kp(p))
+        if self.cfg.HIERARCHICAL_POSE:
+            p = self.global_to_parted(p)
+        poses, score = p[:, :2, :], p[:, 2:, :].repeat(1, 2, 1)
+        stat = self.get_speaker_stat(speaker, poses.shape[-1], parted=self.cfg.HIERARCHICAL_POSE)
+        return {'speaker': speaker, 'audio': audio, 'num_frames': num_frames, 'clip_index': idx,
+                'poses': self.normalize_poses(poses, stat), 'poses_score': score, 'speaker_stat': stat,
+                'anchors': {'hand_root_l': HAND_ROOT_L, 'hand_root_r': HAND_ROOT_R, 'head_root': HEAD_ROOT}}
+
+
+def load_speaker_stats(npz_path, name):
+    """Register statistics stored as {parted,global}_{mean,std,scale} arrays (see tests/golden/speaker_stat_oliver.npz)."""
+    sp = np.load(npz_path)
+    register_speaker_stat(name,
+                          parted={'mean': sp['parted_mean'], 'std': sp['parted_std'], 'scale_factor': float(sp['parted_scale'])},
+                          global_={'mean': sp['global_mean'], 'std': sp['global_std'], 'scale_factor': float(sp['global_scale'])})
 
 
 class SyntheticGestureDataset(PoseTransforms, Dataset):
