@@ -266,6 +266,19 @@ class Voice2Pose(Trainer):
         keep = ('mu_pred', 'mu_gt', 'logvar_pred', 'logvar_gt', 'condition_code')
         return batch_losses, {k: v.detach().cpu().numpy() for k, v in results.items() if k in keep and v is not None}
 
+    @torch.no_grad()
+    def demo_step(self, batch, t_step=0, epoch=0, extra_id=None, interpolation_coeff=None):
+        """Variable-length inference from raw audio (voice2pose.py:386-410 without the video writer): batch['audio'] is
+        (1, L) with L cropped to a whole number of 1/15 s frames, batch['num_frames'] = L // (16000/15) (up to 360 for the
+        reference's 24 s demo limit); returns de-normalised global poses (1, T, 2, 121) in float64."""
+        self.model.eval()
+        results = self.model(batch, self.test_dataset, return_loss=False, interpolation_coeff=interpolation_coeff)
+        results['poses_pred_batch'] = self.test_dataset.get_final_results(results['poses_pred_batch'].detach(), batch['speaker_stat'])
+        if self.is_master_process() and self.cfg.TEST.SAVE_NPZ and self.base_path is not None:
+            self.save_results('DEMO', t_step, epoch, self.base_path,
+                              {k: v.detach().cpu().numpy() for k, v in results.items() if torch.is_tensor(v)}, extra_id=extra_id)
+        return results
+
     def evaluate_step(self, results_dict):
         """L2 distance and normalised lip-sync error (voice2pose.py:412-430) on final (de-normalised) poses."""
         p, g = results_dict['poses_pred_batch'], results_dict['poses_gt_batch']

@@ -316,6 +316,37 @@ def test_aux_stream_overlap_is_bit_identical():
         check("overlap vs single stream", b, a, 2e-5)
 
 
+def test_demo_step_variable_length():
+    """Row f-4: 24 s of audio -> 360 frames through the same kernels (T != 64), code picked by DEMO.CODE_INDEX with
+    interpolation towards CODE_INDEX_B (voice2pose.py:107-117,386-410), checked against the oracle in eval mode."""
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
+    from speechdrivestemplates_amd.core.pipelines import get_pipeline
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "voice2pose_sdt_bp.yaml"))
+    cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DEMO.CODE_INDEX", 3, "DEMO.CODE_INDEX_B", 5, "TEST.SAVE_NPZ", False])
+    cfg.freeze()
+    pipe = get_pipeline("Voice2Pose")(cfg)
+    pipe.num_train_samples = 16
+    pipe.test_dataset = gd.SyntheticGestureDataset(cfg=cfg, num_clips=16, split="val")
+    ocfg = O.cfg_named("voice2pose_sdt_bp")
+    st = O.make_voice2pose_state(ocfg, 16, seed=0, code_std=0.5)
+    pipe.setup_model(cfg, state_dict={"module." + k: v for k, v in st.items()})
+    L = int(360 * 16000 / 15)
+    rng = np.random.Generator(np.random.PCG64(21))
+    audio = torch.from_numpy((0.1 * rng.standard_normal((1, L))).astype(np.float32))
+    stat = {"scale_factor": torch.tensor([1.1]), "mean": torch.from_numpy(rng.standard_normal((1, 242)) * 20.0),
+            "std": torch.from_numpy(rng.uniform(2.0, 30.0, (1, 242)))}
+    batch = {"audio": audio, "speaker": ["synthetic"], "clip_index": torch.tensor([0]), "num_frames": torch.tensor([360]),
+             "speaker_stat": stat}
+    res = pipe.demo_step(batch, interpolation_coeff=0.25)
+    assert res["poses_pred_batch"].shape == (1, 360, 2, 121) and res["poses_pred_batch"].dtype == torch.float64
+    code = st["clips_code"][3:4] * 0.75 + st["clips_code"][5:6] * 0.25
+    pred = O.generator(st, "netG", O.mel_spectrogram(audio), 360, code, ocfg, False)
+    ref = O.get_final_results(pred, stat, True)
+    check("demo T=360 final poses vs oracle", res["poses_pred_batch"], ref, 2e-4)
+
+
 def test_validate_loop_and_fgd():
     """Row f-1: eval-mode test_step over a small synthetic validation set + epoch-level FGD (voice2pose.py:333-384,432-446,
     trainer.py:407-427, core/utils/fgd.py)."""
