@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
-        __syncthreads();
-        if (step + 1 < nsteps) load(step + 1);
+        if constexpr (PRIO != 4) __syncthreads();
+        if constexpr (PRIO != 3) {
+            if (step + 1 < nsteps) load(step + 1);
+        }
         // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
         // sub-step (j,e) consumes k = 8j + 4h + e, so each lane feeds 4 MFMAs from one ds_read_b128.
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        if constexpr (PRIO != 4) __syncthreads();
     }
 
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -472,6 +474,10 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 2)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 2>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 3)  // ablation: no global loads in the K loop (wrong results, timing only)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 3>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 4)  // ablation: no barriers (wrong results, timing only)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 4>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
