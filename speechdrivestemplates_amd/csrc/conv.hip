@@ -46,8 +46,14 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
             default: break;
         }
     }
-    const int m0 = xcd_remap(blockIdx.x, nmb) * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid over (m-tile, n-tile) pairs.  Each XCD (private 4 MiB L2) gets a contiguous range of pairs with the
+    // n-tile index fastest: the workgroups that share an A tile (same m-tile, different n-tiles) and the m-tiles that
+    // share input rows across vertical taps run on the same XCD close in time, so A is fetched into that L2 once
+    // (measured before this ordering: L2-miss traffic 9-16x the input bytes on the Cout=256 layers).
+    const int nnb = (g.Cout + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, nmb * nnb);
+    const int m0 = (lin / nnb) * BM;
+    const int n0 = (lin % nnb) * BN;
 
     if (tid < g.ntaps) {
         sTap[tid] = g.dy[tid];
@@ -256,12 +262,18 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int M = g.B * g.Ho * g.Wo;
-    const int mbeg = blockIdx.x * rows_per_split;
-    const int mend = min(M, mbeg + rows_per_split);
-    const int n0 = blockIdx.z * BM;
+    // 1-D grid over (row range, column tile, n tile); an XCD gets a contiguous range with the row range slowest, so
+    // every workgroup that reads the same dY / X rows runs on the same XCD at about the same time (L2 reuse)
     const int ncb = (g.Cin + BN - 1) / BN;
-    const int tapv = VEC4 ? (int)blockIdx.y / ncb : 0;
-    const int c0 = VEC4 ? ((int)blockIdx.y % ncb) * BN : (int)blockIdx.y * BN;  // scalar path: flattened (tap,c)
+    const int ncol = VEC4 ? g.ntaps * ncb : (g.ntaps * g.Cin + BN - 1) / BN;
+    const int nnt = (g.Cout + BM - 1) / BM;
+    const int lin = xcd_remap(blockIdx.x, (int)gridDim.x);
+    const int bx = lin / (ncol * nnt), by = (lin / nnt) % ncol, bz = lin % nnt;
+    const int mbeg = bx * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    const int n0 = bz * BM;
+    const int tapv = VEC4 ? by / ncb : 0;
+    const int c0 = VEC4 ? (by % ncb) * BN : by * BN;  // scalar path: flattened (tap,c)
     const int Ktot = g.ntaps * g.Cin;
 
     if (tid < g.ntaps) {
@@ -282,8 +294,8 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
         }
         int (*R)[BK] = sRow[step & 1];
         if constexpr (VEC4) {  // byte offsets for the buffer loads (this block's tap is fixed); masked rows -> SDT_OOB
-            const int iy = iy0 + g.dy[VEC4 ? (int)blockIdx.y / ((g.Cin + BN - 1) / BN) : 0];
-            const int ix = ix0 + g.dx[VEC4 ? (int)blockIdx.y / ((g.Cin + BN - 1) / BN) : 0];
+            const int iy = iy0 + g.dy[tapv];
+            const int ix = ix0 + g.dx[tapv];
             const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
             R[0][tid] = offY >= 0 ? (int)((unsigned)offY * 4u) : (int)SDT_OOB;
             R[1][tid] = ok ? (int)((unsigned)(((bH + iy) * g.Wi + ix) * g.Cin) * 4u) : (int)SDT_OOB;
@@ -468,7 +480,7 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
                         const sdt_conv_geom& g, int splitk, float* partial, hipStream_t s) {
     const int M = g.B * g.Ho * g.Wo;
     const size_t ysize = (size_t)g.B * g.Hy * g.Wy * g.Cout;
-    dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), splitk);
+    dim3 grid(cdiv(M, BM) * cdiv(g.Cout, BN), 1, splitk);
     static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // tuning experiments
     if (vec4 && prio == 1)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
@@ -562,7 +574,7 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
     nsplit = max(1, min(nsplit, max(1, M / (4 * BK))));  // at least 4 K-steps per workgroup: bounds the atomic traffic
     int rows = cdiv(cdiv(M, nsplit), BK) * BK;
     nsplit = cdiv(M, rows);
-    dim3 grid(nsplit, coltiles, ntiles);
+    dim3 grid(nsplit * coltiles * ntiles);
     if (vec4)
         hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
     else
