@@ -183,6 +183,15 @@ def main():
                                "event_sampled_steps": prof_steps,
                                "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
                                "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6}
+            # HBM-side traffic cannot be read from inside the process: cite the committed rocprofv3 PMC measurement of this
+            # same command (two separate --pmc passes, gfx950 x2 correction on FETCH_SIZE; profiles/README.md)
+            tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_bench.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("dominant_kernel", "") == name:
+                    out["roofline"]["traffic"] = tj["traffic_mb_per_launch"] * 1e6
+                    out["roofline"]["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, fabric side, upper bound on HBM)"
+                    out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic_bench.json"
             tot_us = sum(v["us"] for v in summ.values())
             tot_fl = sum(v["flops"] for v in summ.values())
             out["conv_kernels"] = {k: {"launches_per_step": v["launches"] / prof_steps, "ms_per_step": v["us"] / prof_steps / 1e3,

@@ -13,10 +13,6 @@ from torch import nn
 from . import ops
 
 
-def hann_window_periodic(n):
-    return 0.5 - 0.5 * torch.cos(2.0 * math.pi * torch.arange(n, dtype=torch.float64) / n)
-
-
 def htk_filterbank(n_freqs, f_min, f_max, n_mels, sample_rate):
     """Triangular HTK-mel filters, (n_freqs, n_mels), fp32 arithmetic like torchaudio 0.7 create_fb_matrix."""
     freqs = torch.linspace(0, sample_rate // 2, n_freqs)

@@ -173,7 +173,10 @@ class ConvProfiler:
     @staticmethod
     def kernel_name(kind, variant):
         bm, bn, vec = variant // 10 // 1000, variant // 10 % 1000, variant % 10
-        return "%s<%d, %d, %s>" % ("conv_taps_kernel" if kind != "dW" else "conv_dw_kernel", bm, bn, "true" if vec else "false")
+        if kind == "dW":
+            return "conv_dw_kernel<%d, %d, %s>" % (bm, bn, "true" if vec else "false")
+        # as rocprofv3 prints it: the 4th template argument is the (experiment-only) priority/ablation mode, 0 in production
+        return "conv_taps_kernel<%d, %d, %s, 0>" % (bm, bn, "true" if vec else "false")
 
     def summary(self):
         torch.cuda.synchronize()

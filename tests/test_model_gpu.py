@@ -316,6 +316,36 @@ def test_aux_stream_overlap_is_bit_identical():
         check("overlap vs single stream", b, a, 2e-5)
 
 
+def test_hipgraph_replay_matches_eager():
+    """graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
+    from speechdrivestemplates_amd.graph import GraphedStep
+    runs = []
+    for use_graph in (False, True):
+        pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+        dev = pipe.model._device()
+        gs = GraphedStep(pipe, warmup=1)
+        hist = []
+        for step in range(4):
+            b = O.make_batch(4, 16, step=step, seed=1)
+            b = {k: (v.to(dev) if torch.is_tensor(v) and k != "num_frames" else v) for k, v in b.items()}
+            b["speaker_stat"] = {k: v.to(dev) for k, v in b["speaker_stat"].items()}
+            if use_graph:
+                losses = gs.run(b)
+            else:
+                losses, _ = pipe.forward_backward(b)
+                pipe.optimizer_updates(losses)
+            torch.cuda.synchronize()
+            hist.append((float(losses["G_loss"]), float(losses["L2_dist"])))
+        runs.append((hist, pipe.model.netG.decoder[4].weight.detach().clone(), int(pipe.optimizers["optimizerG"].state_dev[0])))
+    (h0, w0, s0), (h1, w1, s1) = runs
+    assert s0 == s1 == 4
+    for (a, b), (c, d) in zip(h0, h1):
+        assert abs(a - c) <= 2e-5 * abs(a) and abs(b - d) <= 2e-5 * abs(b), (h0, h1)
+    # weight-gradient atomics make the two runs differ in the last bits; Adam's sign-like early steps amplify that to at
+    # most 2*lr per step and element
+    assert (w1 - w0).abs().max().item() <= 2 * 1e-4 * 4
+
+
 def test_demo_step_variable_length():
     """Row f-4: 24 s of audio -> 360 frames through the same kernels (T != 64), code picked by DEMO.CODE_INDEX with
     interpolation towards CODE_INDEX_B (voice2pose.py:107-117,386-410), checked against the oracle in eval mode."""
