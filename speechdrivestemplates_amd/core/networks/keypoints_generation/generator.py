@@ -79,6 +79,12 @@ class SequenceGeneratorCNN(nn.Module):
         """mel (B,80,F), code (B,D)|None -> poses (B,num_frames,2,K), generator.py:106-117."""
         num_frames = int(num_frames)
         feat = self.audio_encoder.encode_cl(x)
+        hook = getattr(self, 'post_encoder_grad_hook', None)
+        if hook is not None and feat.requires_grad:
+            # fires in backward once the gradient w.r.t. the encoder output exists, i.e. when every U-Net / decoder
+            # weight-gradient kernel has been enqueued: the data-parallel exchange of those gradients starts here and
+            # overlaps the (much longer) Conv2d backward (dp.GradReducer)
+            feat.register_hook(hook)
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
         h = self.unet.forward_cl(h)

@@ -196,6 +196,18 @@ class Voice2Pose(Trainer):
         if code.DIMENSION is not None and not code.EXTERNAL_CODE and code.TRAIN:
             add('optimizerClipCode', [self.model.clips_code], cfg.TRAIN.LR * code.LR_SCALING)
         self.reducer = dp.GradReducer(self.optimizers.values())
+        if self.reducer.active:  # early bucket: everything of netG behind the audio encoder (U-Net + decoder, ~14 MB)
+            optg = self.optimizers['optimizerG']
+            names = [n for n, p in self.model.netG.named_parameters() if p.requires_grad]
+            first = next((i for i, n in enumerate(names) if not n.startswith('audio_encoder.')), None)
+            if first is not None and all(not n.startswith('audio_encoder.') for n in names[first:]):
+                lo, reducer = optg.offsets[first], self.reducer
+
+                def _launch_late_layers(grad, _optg=optg, _lo=lo, _r=reducer):
+                    _r.launch(_optg, _lo, None)
+                    return None
+
+                self.model.netG.post_encoder_grad_hook = _launch_late_layers
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, batch, want_final=False):

@@ -8,6 +8,8 @@ group -- 28.3 MB for the sdt_bp generator -- issued on a side stream as soon as 
 complete, and the 1/world_size is folded into the Adam kernel (``grad_scale``).  xGMI is point-to-point
 (7 links/GPU): few large messages keep every link busy; there is nothing to gain from DDP's many small buckets.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,20 +22,29 @@ class GradReducer:
     def __init__(self, optimizers, overlap=True):
         self.optimizers = list(optimizers)
         self.ws = world_size()
+        # SDT_DP_FORCE=1 exercises the whole exchange path on a single rank (a 1-rank all-reduce); used by the tests
+        self.active = self.ws > 1 or (os.environ.get("SDT_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+        self._launched = {}  # id(opt) -> list of (lo, hi) ranges of flat_grad already in flight this step
         for opt in self.optimizers:
             opt.grad_scale = 1.0 / self.ws
         self.comm_stream = None
-        if self.ws > 1 and overlap and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
+        if self.active and overlap and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
             self.comm_stream = torch.cuda.Stream()
         self._pending = []
 
-    def launch(self, opt):
-        """Start the all-reduce of one optimiser group's gradients (call when its backward has finished)."""
-        if self.ws == 1:
+    def launch(self, opt, lo=0, hi=None):
+        """Start the summing all-reduce of ``opt.flat_grad[lo:hi]`` (call as soon as that range's backward kernels have
+        been enqueued): it runs on the communication stream, behind everything queued on the main stream so far and
+        concurrently with whatever backward work follows."""
+        if not self.active:
             return
         from . import ops
         ops.join_side_stream()  # side-stream weight-gradient kernels write into this buffer
-        buf = opt.flat_grad
+        hi = opt.flat_grad.numel() if hi is None else hi
+        if hi <= lo:
+            return
+        self._launched.setdefault(id(opt), []).append((lo, hi))
+        buf = opt.flat_grad[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -50,8 +61,15 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def all_reduce(self, opts=None):
+        """Exchange whatever part of each group's gradients has not been launched early, then wait for all of it."""
         for opt in (opts if opts is not None else self.optimizers):
-            self.launch(opt)
+            early = sorted(self._launched.pop(id(opt), []))
+            pos, n = 0, opt.flat_grad.numel()
+            for lo, hi in early + [(n, n)]:
+                if lo > pos:
+                    self.launch(opt, pos, lo)
+                pos = max(pos, hi)
+            self._launched.pop(id(opt), None)
         self.wait()
 
 

@@ -316,6 +316,54 @@ def test_aux_stream_overlap_is_bit_identical():
         check("overlap vs single stream", b, a, 2e-5)
 
 
+@pytest.mark.parametrize("name,code_std,tol", [("voice2pose_sdt_vae", 0.0, 2e-5), ("voice2pose_sdt_bp", 0.5, 1e-3)])
+def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
+    """The bucketed, backward-overlapped all-reduce path (dp.GradReducer + the post-encoder hook) exercised over RCCL with
+    a 1-rank process group (SDT_DP_FORCE): the exchange must cover every gradient element exactly once and leave the
+    training trajectory unchanged."""
+    import torch.distributed as dist
+    from speechdrivestemplates_amd import dp
+    hist = {}
+    for forced in (False, True):
+        if forced:
+            os.environ["SDT_DP_FORCE"] = "1"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        try:
+            pipe, _ = _make_pipeline(name, 16, code_std)
+            assert pipe.reducer.active == forced
+            if forced:
+                assert pipe.model.netG.post_encoder_grad_hook is not None
+                calls = []
+                orig = pipe.reducer.launch
+
+                def spy(opt, lo=0, hi=None, _orig=orig, _calls=calls, _optg=pipe.optimizers["optimizerG"]):
+                    if opt is _optg:
+                        _calls.append((lo, opt.flat_grad.numel() if hi is None else hi))
+                    return _orig(opt, lo, hi)
+
+                pipe.reducer.launch = spy
+            out = []
+            for step in range(2):
+                losses, results = pipe.forward_backward(O.make_batch(4, 16, step=step, seed=1))
+                pipe.optimizer_updates(losses)
+                torch.cuda.synchronize()
+                out.append(float(losses["G_loss"]))
+            hist[forced] = (out, pipe.model.netG.unet.e0.conv.weight.detach().clone())
+            if forced:
+                n = pipe.optimizers["optimizerG"].flat_grad.numel()
+                per_step = calls[:len(calls) // 2]
+                assert len(per_step) == 2 and per_step[0][1] == n and per_step[1] == (0, per_step[0][0]), per_step  # late layers first
+                assert 0 < per_step[0][0] < n
+        finally:
+            if forced:
+                os.environ.pop("SDT_DP_FORCE", None)
+                dist.destroy_process_group()
+    for a, b in zip(hist[False][0], hist[True][0]):
+        assert abs(a - b) <= tol * abs(a), hist
+    assert torch.isfinite(hist[True][1]).all()
+
+
 def test_hipgraph_replay_matches_eager():
     """graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
     from speechdrivestemplates_amd.graph import GraphedStep
