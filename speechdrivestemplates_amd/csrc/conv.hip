@@ -185,18 +185,30 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr bool TWO_ACC = (PRIO == 5 || PRIO == 6);  // experiment: even/odd k sub-steps into separate accumulators
+    f32x16 acc2[TWO_ACC ? TM : 1][TWO_ACC ? TN : 1];
+    if constexpr (TWO_ACC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
 
     const float* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
     const float* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
 
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
+        if (!(PRIO == 7 || PRIO == 8) || step == step0) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
+            for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
+            for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
+        }
         if constexpr (PRIO != 4) __syncthreads();
-        if constexpr (PRIO != 3) {
+        if constexpr (PRIO != 3 && PRIO != 6 && PRIO != 7 && PRIO != 8) {
             if (step + 1 < nsteps) load(step + 1);
         }
         // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
@@ -206,21 +218,33 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j) {
             f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a[tm] = *(const f32x4*)(pa + tm * 32 * LDP + j * 8);
+            for (int tm = 0; tm < TM; ++tm) a[tm] = (PRIO == 8 && step != step0) ? ra[tm] : *(const f32x4*)(pa + tm * 32 * LDP + j * 8);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[tn] = *(const f32x4*)(pb + tn * 32 * LDP + j * 8);
+            for (int tn = 0; tn < TN; ++tn) b[tn] = (PRIO == 8 && step != step0) ? rb[tn] : *(const f32x4*)(pb + tn * 32 * LDP + j * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn) {
+                        if (TWO_ACC && (e & 1))
+                            acc2[TWO_ACC ? tm : 0][TWO_ACC ? tn : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc2[TWO_ACC ? tm : 0][TWO_ACC ? tn : 0], 0, 0, 0);
+                        else
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+                    }
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if constexpr (PRIO != 4) __syncthreads();
     }
 
+    if constexpr (TWO_ACC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+    }
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (splitk > 1) {
         Y = partial + (size_t)blockIdx.z * ysize;
@@ -490,6 +514,14 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 3>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 4)  // ablation: no barriers (wrong results, timing only)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 4>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 5)  // experiment: two accumulators per 32x32 sub-tile
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 5>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 6)  // ablation: two accumulators, no global loads
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 6>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 7)  // ablation: no global loads, no LDS stores
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 7>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 8)  // ablation: no global loads, no LDS traffic at all (MFMA + prologue/epilogue only)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 8>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
