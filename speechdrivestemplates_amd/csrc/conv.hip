@@ -201,14 +201,14 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
-        if (!(PRIO == 7 || PRIO == 8) || step == step0) {
+        if (!(PRIO == 7 || PRIO == 8 || PRIO == 9) || step == step0) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
 #pragma unroll
             for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
         }
-        if constexpr (PRIO != 4) __syncthreads();
-        if constexpr (PRIO != 3 && PRIO != 6 && PRIO != 7 && PRIO != 8) {
+        if (PRIO != 4 && (PRIO != 9 || step == step0)) __syncthreads();
+        if constexpr (PRIO != 3 && PRIO != 6 && PRIO != 7 && PRIO != 8 && PRIO != 9) {
             if (step + 1 < nsteps) load(step + 1);
         }
         // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j) {
             f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a[tm] = (PRIO == 8 && step != step0) ? ra[tm] : *(const f32x4*)(pa + tm * 32 * LDP + j * 8);
+            for (int tm = 0; tm < TM; ++tm) a[tm] = ((PRIO == 8 || PRIO == 9) && step != step0) ? ra[tm] : *(const f32x4*)(pa + tm * 32 * LDP + j * 8);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[tn] = (PRIO == 8 && step != step0) ? rb[tn] : *(const f32x4*)(pb + tn * 32 * LDP + j * 8);
+            for (int tn = 0; tn < TN; ++tn) b[tn] = ((PRIO == 8 || PRIO == 9) && step != step0) ? rb[tn] : *(const f32x4*)(pb + tn * 32 * LDP + j * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     }
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        if constexpr (PRIO != 4) __syncthreads();
+        if (PRIO != 4 && (PRIO != 9 || step == step0)) __syncthreads();
     }
 
     if constexpr (TWO_ACC) {
@@ -522,6 +522,8 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 7>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 8)  // ablation: no global loads, no LDS traffic at all (MFMA + prologue/epilogue only)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 8>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
