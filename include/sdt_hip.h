@@ -185,6 +185,17 @@ int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, i
 int sdt_time_diff_fwd_f32(const float* x, float* y, int B, int T, int C, void* stream);
 int sdt_time_diff_bwd_f32(const float* dy, float* dx, int B, int T, int C, void* stream);
 
+/* Batch assembly from a clip store resident in HBM -- the device-side form of GestureDataset.__getitem__ + collate
+ * (core/datasets/gesture_dataset.py:85-119): for every b, clip = idx[b]:
+ *   raw (N, Tstore, 3, 137) OpenPose x / y / confidence  -> first T frames, 137 -> 122 -> 121 keypoints (:124-145),
+ *   relative to the root joint, optionally hierarchical ("parted": head / hand offsets, :157-165), then
+ *   (x - mean) / std with fp32 statistics (242,) (:167-176);  poses (B,T,2,121), score (B,T,2,121) = confidence twice.
+ * Same fp32 operation order as the reference's torch code -> bit-identical results.
+ *   sdt_rows_gather_f32: dst[b, :] = src[idx[b], :]   (the cropped / zero-padded audio rows, n_cols % 4 == 0 not required) */
+int sdt_clip_poses_prepare_f32(const float* raw, const int64_t* idx, const float* mean, const float* std, float* poses,
+                               float* score, int N, int Tstore, int B, int T, int hierarchical, void* stream);
+int sdt_rows_gather_f32(const float* src, const int64_t* idx, float* dst, int N, int B, int64_t n_cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ SIGNATURES = {
     "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _p],
     "sdt_time_diff_fwd_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_time_diff_bwd_f32": [_p, _p, _i, _i, _i, _p],
+    "sdt_clip_poses_prepare_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sdt_rows_gather_f32": [_p, _p, _p, _i, _i, _i64, _p],
 }
 
 _lib = None

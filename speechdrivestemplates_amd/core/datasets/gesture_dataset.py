@@ -160,6 +160,58 @@ class GestureDataset(PoseTransforms, Dataset):
                 'anchors': {'hand_root_l': HAND_ROOT_L, 'hand_root_r': HAND_ROOT_R, 'head_root': HEAD_ROOT}}
 
 
+class DeviceClipStore(PoseTransforms):
+    """A speaker's clips resident in HBM + batch assembly on the GPU ("GPU-side batched version to remove
+    the DataLoader bottleneck").  The reference reads one npz per sample in DataLoader worker processes and collates on
+    the host (gesture_dataset.py:85-119, trainer.py:77); an MI355X holds the whole dataset instead -- 379 KB per clip
+    (64x3x137 pose + 68266 audio samples, fp32), i.e. ~11 GB for 30k clips of 288 GB -- and ``batch(indices)`` is two
+    kernel launches (ops.clip_poses_prepare, ops.rows_gather) producing the model's batch dict on the device,
+    bit-identical to ``default_collate([dataset[i] for i in indices])``.  One speaker per store, like the reference."""
+
+    def __init__(self, dataset, device='cuda', indices=None):
+        self.cfg = dataset.cfg
+        self.speaker = dataset.speaker
+        idx = range(len(dataset)) if indices is None else indices
+        audio_length, self.num_frames = parse_audio_length(self.cfg.AUDIO_LENGTH, self.cfg.AUDIO_SR, self.cfg.FPS)
+        poses, audio = [], []
+        for i in idx:  # one pass over the files, at start-up
+            clip = dataset.clips.iloc[i]
+            assert clip['speaker'] == self.speaker, 'one speaker per store'
+            arr = np.load(os.path.join(dataset.root_dir, clip['pose_fn']))
+            poses.append(torch.Tensor(arr['pose'][:self.cfg.NUM_FRAMES, ...]))  # fp32 like :95
+            audio.append(torch.from_numpy(np.ascontiguousarray(crop_pad_audio(arr['audio'], audio_length), dtype=np.float32)))
+        self.raw_poses = torch.stack(poses).contiguous().to(device)   # (N, T, 3, 137)
+        self.audio = torch.stack(audio).contiguous().to(device)       # (N, 68266)
+        stat = self.get_speaker_stat(self.speaker, self.cfg.NUM_LANDMARKS, parted=self.cfg.HIERARCHICAL_POSE)
+        self.stat = stat
+        to32 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float32, device=device)  # noqa: E731  (:174-176)
+        self._mean32, self._std32 = to32(stat['mean']), to32(stat['std'])
+        self._mean64 = torch.tensor(np.asarray(stat['mean'], dtype=np.float64), device=device)
+        self._std64 = torch.tensor(np.asarray(stat['std'], dtype=np.float64), device=device)
+        self._scale64 = torch.tensor(float(stat['scale_factor']), dtype=torch.float64, device=device)
+
+    def __len__(self):
+        return self.raw_poses.shape[0]
+
+    def batch(self, indices):
+        """indices: int64 tensor / sequence of clip positions in the store -> the collated sample dict, on the device."""
+        from ... import ops
+        dev = self.raw_poses.device
+        idx = torch.as_tensor(indices, dtype=torch.int64).to(dev)
+        if idx.numel() == 0 or int(idx.min()) < 0 or int(idx.max()) >= len(self):
+            raise IndexError('clip index out of range')
+        B = idx.numel()
+        poses, score = ops.clip_poses_prepare(self.raw_poses, idx, self._mean32, self._std32, self.num_frames,
+                                              self.cfg.HIERARCHICAL_POSE)
+        return {'speaker': [self.speaker] * B, 'audio': ops.rows_gather(self.audio, idx),
+                'num_frames': torch.full((B,), self.num_frames, dtype=torch.int64), 'clip_index': idx,
+                'poses': poses, 'poses_score': score,
+                'speaker_stat': {'scale_factor': self._scale64.expand(B), 'mean': self._mean64.expand(B, -1),
+                                 'std': self._std64.expand(B, -1)},
+                'anchors': {'hand_root_l': torch.full((B,), HAND_ROOT_L), 'hand_root_r': torch.full((B,), HAND_ROOT_R),
+                            'head_root': torch.full((B,), HEAD_ROOT)}}
+
+
 def load_speaker_stats(npz_path, name):
     """Register statistics stored as {parted,global}_{mean,std,scale} arrays (see tests/golden/speaker_stat_oliver.npz)."""
     sp = np.load(npz_path)

@@ -579,6 +579,68 @@ extern "C" int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, fl
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// Device-side GestureDataset.__getitem__ for a batch of clips (gesture_dataset.py:85-119).  One workgroup per
+// (clip, frame): the 3x137 raw frame goes through LDS, thread k produces keypoint k of the 121-point layout.
+__device__ __forceinline__ int kp121_to_137(int k) {
+    const int j = k == 0 ? 0 : k + 1;               // 122 -> 121 drops the root joint (index 1)
+    return j < 8 ? j : (j < 10 ? j + 7 : j + 15);   // 137 -> 122 keeps 0-7, 15, 16, 25-136
+}
+__global__ __launch_bounds__(128) void clip_poses_prepare_kernel(const float* __restrict__ raw, const int64_t* __restrict__ idx,
+                                                                 const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                                 float* __restrict__ poses, float* __restrict__ score,
+                                                                 int N, int Tstore, int T, int hier) {
+    __shared__ float fr[3 * 137];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int64_t clip = idx[b];
+    if (clip < 0 || clip >= N) return;  // host validates; never dereference a bad index
+    const float* src = raw + ((size_t)clip * Tstore + t) * (3 * 137);
+    for (int i = threadIdx.x; i < 3 * 137; i += 128) fr[i] = src[i];
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k >= 121) return;
+    const int s = kp121_to_137(k);
+    int part = -1;  // root of this keypoint's part in the 121 layout
+    if (hier) {
+        if (k >= 9 && k < 79 && k != 39) part = 39;
+        else if (k >= 79 && k < 100) part = 6;
+        else if (k >= 100) part = 3;
+    }
+    const size_t o = ((size_t)b * T + t) * 242;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float root = fr[c * 137 + 1];
+        float v = fr[c * 137 + s] - root;
+        if (part >= 0) v = v - (fr[c * 137 + kp121_to_137(part)] - root);
+        poses[o + c * 121 + k] = __fdiv_rn(v - mean[c * 121 + k], stdv[c * 121 + k]);
+        score[o + c * 121 + k] = fr[2 * 137 + s];
+    }
+}
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int N, int64_t n_cols) {
+    const int b = blockIdx.y;
+    const int64_t r = idx[b];
+    if (r < 0 || r >= N) return;
+    const float* s = src + (size_t)r * n_cols;
+    float* d = dst + (size_t)b * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_cols; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+extern "C" int sdt_clip_poses_prepare_f32(const float* raw, const int64_t* idx, const float* mean, const float* stdv, float* poses,
+                                          float* score, int N, int Tstore, int B, int T, int hierarchical, void* stream) {
+    SDT_CHECK_ARG(raw && idx && mean && stdv && poses && score, "null pointer");
+    SDT_CHECK_ARG(N > 0 && B > 0 && T > 0 && Tstore >= T && B <= 65535, "bad sizes (stored clips must hold at least T frames)");
+    hipLaunchKernelGGL(clip_poses_prepare_kernel, dim3(T, B), dim3(128), 0, (hipStream_t)stream, raw, idx, mean, stdv, poses, score,
+                       N, Tstore, T, hierarchical);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_rows_gather_f32(const float* src, const int64_t* idx, float* dst, int N, int B, int64_t n_cols, void* stream) {
+    SDT_CHECK_ARG(src && idx && dst && N > 0 && B > 0 && B <= 65535 && n_cols > 0, "bad argument");
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n_cols, 256), 64), B), dim3(256), 0, (hipStream_t)stream,
+                       src, idx, dst, N, n_cols);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
 extern "C" int sdt_time_diff_fwd_f32(const float* x, float* y, int B, int T, int C, void* stream) {
     SDT_CHECK_ARG(x && y && B > 0 && T > 1 && C > 0, "bad argument");
     hipLaunchKernelGGL(time_diff_fwd_kernel, dim3(ew_grid((int64_t)B * (T - 1) * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, C);

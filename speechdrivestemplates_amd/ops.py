@@ -616,6 +616,30 @@ class TimeDiffFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # no-grad ops
 # --------------------------------------------------------------------------------------------
+def clip_poses_prepare(raw_store, idx, mean, std, num_frames, hierarchical):
+    """Device-side GestureDataset.__getitem__ + collate for a batch of stored clips (gesture_dataset.py:85-119):
+    raw_store (N,Tstore,3,137) fp32, idx (B,) int64, mean/std (242,) fp32 -> poses, score (B,num_frames,2,121)."""
+    _req_cuda(raw_store, idx, mean, std)
+    assert raw_store.dim() == 4 and raw_store.shape[2:] == (3, 137) and raw_store.is_contiguous() and raw_store.dtype == torch.float32
+    assert idx.dtype == torch.int64 and mean.numel() == 242 and std.numel() == 242
+    N, Tstore = raw_store.shape[:2]
+    B = idx.numel()
+    poses = torch.empty((B, num_frames, 2, 121), device=raw_store.device, dtype=torch.float32)
+    score = torch.empty_like(poses)
+    check(_lib.load().sdt_clip_poses_prepare_f32(_p(raw_store), _p(idx.contiguous()), _p(mean.contiguous()), _p(std.contiguous()),
+                                                 _p(poses), _p(score), N, Tstore, B, num_frames, int(bool(hierarchical)), _stream()))
+    return poses, score
+
+
+def rows_gather(src, idx):
+    """dst[b] = src[idx[b]] for a (N, n_cols) fp32 store (the batch's audio rows)."""
+    _req_cuda(src, idx)
+    assert src.dim() == 2 and src.is_contiguous() and src.dtype == torch.float32 and idx.dtype == torch.int64
+    dst = torch.empty((idx.numel(), src.shape[1]), device=src.device, dtype=torch.float32)
+    check(_lib.load().sdt_rows_gather_f32(_p(src), _p(idx.contiguous()), _p(dst), src.shape[0], idx.numel(), src.shape[1], _stream()))
+    return dst
+
+
 def final_metrics(pred, gt, mean, std, scale, hierarchical, want_final=True):
     """get_final_results x2 + evaluate_step in float64 (gesture_dataset.py:193-220, voice2pose.py:412-430).
     pred/gt (B,T,2,K) fp32; mean/std (B,2K) f64; scale (B,) f64 -> (final_pred, final_gt, metrics[2])."""

@@ -48,3 +48,69 @@ def test_missing_csv_and_unknown_speaker(tmp_path):
         get_dataset("GestureDataset")(str(tmp_path), "nobody", "train", get_cfg_defaults())
     with pytest.raises(KeyError):
         get_dataset("NoSuchDataset")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hier", [True, False])
+def test_device_clip_store_matches_reference_dataset(tmp_path, hier):
+    """Row f-3, device side: batches assembled on the GPU from an HBM-resident clip store are bit-identical to the
+    reference GestureDataset's samples (the committed fixture) and to the host reader + default_collate."""
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import get_dataset
+    from speechdrivestemplates_amd.core.datasets.gesture_dataset import DeviceClipStore, load_speaker_stats
+    g = dict(np.load(os.path.join(GOLDEN, "dataset_clips.npz")))
+    write_synthetic_speaker(str(tmp_path), "oliver", n=5, seed=11)
+    load_speaker_stats(os.path.join(GOLDEN, "speaker_stat_oliver.npz"), "oliver")
+    cfg = get_cfg_defaults()
+    cfg.merge_from_list(["DATASET.HIERARCHICAL_POSE", hier])
+    ds = get_dataset("GestureDataset")(str(tmp_path), "oliver", "train", cfg)
+    store = DeviceClipStore(ds)
+    assert len(store) == len(ds)
+    order = list(reversed(range(len(ds)))) + [0, 0]  # permuted, with a repeated clip
+    got = store.batch(order)
+    want = torch.utils.data.default_collate([ds[i] for i in order])
+    for k in ("poses", "poses_score", "audio"):
+        assert got[k].is_cuda and got[k].dtype == torch.float32
+        assert torch.equal(got[k].cpu(), want[k].float()), k
+    assert torch.equal(got["clip_index"].cpu(), want["clip_index"]) and torch.equal(got["num_frames"], want["num_frames"])
+    for k in ("mean", "std", "scale_factor"):
+        assert got["speaker_stat"][k].dtype == torch.float64
+        assert torch.equal(got["speaker_stat"][k].cpu(), want["speaker_stat"][k]), k
+    assert got["speaker"] == want["speaker"]
+    for j, i in enumerate(order):  # and directly against what the reference's own dataset class produced
+        np.testing.assert_array_equal(got["poses"][j].cpu().numpy(), g["%s/train/%d/poses" % (hier, i)])
+    with pytest.raises(IndexError):
+        store.batch([len(ds)])
+
+
+@pytest.mark.gpu
+def test_train_step_from_device_clip_store(tmp_path):
+    """A batch assembled by DeviceClipStore drives the train step exactly like the host-collated one."""
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import get_dataset
+    from speechdrivestemplates_amd.core.datasets.gesture_dataset import DeviceClipStore, load_speaker_stats
+    from speechdrivestemplates_amd.core.pipelines import get_pipeline
+    write_synthetic_speaker(str(tmp_path), "oliver", n=5, seed=11)
+    load_speaker_stats(os.path.join(GOLDEN, "speaker_stat_oliver.npz"), "oliver")
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "voice2pose_sdt_bp.yaml"))
+    cfg.merge_from_list(["SYS.LOG_INTERVAL", 10 ** 9])
+    ds = get_dataset("GestureDataset")(str(tmp_path), "oliver", "train", cfg)
+    store = DeviceClipStore(ds)
+    out = []
+    for src in ("host", "device"):
+        torch.manual_seed(0)
+        pipe = get_pipeline(cfg.PIPELINE_TYPE)(cfg)
+        pipe.num_train_samples, pipe.train_dataset = len(ds), ds
+        pipe.setup_model(cfg)
+        pipe.setup_optimizer()
+        pipe.model.train()
+        idx = [2, 0, 1]
+        batch = store.batch(idx) if src == "device" else torch.utils.data.default_collate([ds[i] for i in idx])
+        losses, results = pipe.forward_backward(batch)
+        pipe.optimizer_updates(losses)
+        torch.cuda.synchronize()
+        out.append((losses["G_reg_loss"].detach().clone(), losses["L2_dist"].detach().clone(), results["poses_pred_batch"].detach().clone()))
+    (reg_a, l2_a, pred_a), (reg_b, l2_b, pred_b) = out
+    assert torch.equal(reg_a, reg_b) and torch.equal(pred_a, pred_b)
+    assert abs(float(l2_a) - float(l2_b)) <= 1e-12 * abs(float(l2_a))  # float64 atomics: summation order only
