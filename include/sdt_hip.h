@@ -75,7 +75,9 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
  *   G=B, R=H*W  -> nn.InstanceNorm2d            (building_blocks.py:26)
  *   G=1, R=B*HW -> nn.BatchNorm{1,2}d, training (building_blocks.py:24,39)
  * followed by LeakyReLU(slope) (slope = 0 -> ReLU)  (building_blocks.py:46).
- * sums: workspace of 2*G*C doubles (zeroed by the call).  num_batches_tracked (nullable) is the
+ * sums: workspace of 2*G*C doubles that MUST BE ZERO ON ENTRY (fp64 atomics accumulate into it; the call leaves it
+ * dirty -- callers carve it from a region zeroed once per step instead of paying a memset per layer).
+ * num_batches_tracked (nullable) is the
  * BatchNorm int64 counter, incremented on the device.  gamma/beta/running_* may be NULL (IN).
  * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
  * momentum (unbiased variance), as nn.BatchNorm does in training mode.
@@ -98,6 +100,7 @@ int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums
  * training-mode BatchNorm2d (groups = 1) -> LeakyReLU(slope)   (generator.py:16, building_blocks.py:15-26,46).
  * The statistics of all 64 channels are derived from 9+45 fp64 moments of the mel image, so z (B,H,W,64) is written once
  * and the raw conv output is never stored; backward recomputes the normalised pre-activation from mel.
+ *   (both workspaces MUST BE ZERO ON ENTRY and are left dirty, like sdt_colnorm_*'s)
  *   fwd: mom = workspace of 54*B doubles; writes z, mean[groups*64], rstd[groups*64] (+ BN running stats / counter).
  *   bwd: sums = workspace of 2*groups*64 doubles; dw (64,9) and dgamma/dbeta (nullable) are ACCUMULATED.
  */
@@ -150,7 +153,7 @@ int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* go
 /*
  * GestureDataset.get_final_results x2 + Voice2Pose.evaluate_step (gesture_dataset.py:193-220,
  * voice2pose.py:412-430), float64 like the reference: final_* (B,T,2,K) f64 (nullable),
- * metrics[0]=L2_dist, metrics[1]=lip_sync_error_n.  work: >= 2*B*T + 4 doubles.
+ * metrics[0]=L2_dist, metrics[1]=lip_sync_error_n.  work: >= 2*B*T + 4 doubles, the first 4 ZERO ON ENTRY.
  */
 int sdt_final_metrics_f64(const float* pred, const float* gt, const double* mean, const double* std,
                           const double* scale, int hierarchical, int B, int T, int K,

@@ -59,6 +59,7 @@ class Pose2Pose(Trainer):
 
     def forward_backward(self, batch, want_final=False):
         dev = self.model.clip_code_mu.device
+        ops.begin_step(dev)
         losses, results = self.model(batch)
         stat = batch['speaker_stat']
         _, _, metrics = ops.final_metrics(results['poses_pred_batch'].detach(), results['poses_gt_batch'], stat['mean'].to(dev),

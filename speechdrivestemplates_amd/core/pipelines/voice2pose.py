@@ -214,6 +214,7 @@ class Voice2Pose(Trainer):
         """Forward, per-step metrics and both backward passes (voice2pose.py:288-301,306-308) -- everything of a
         train step up to (not including) the gradient exchange and the optimiser updates."""
         dev = self.model._device()
+        ops.begin_step(dev)
         losses, results = self.model(batch, self.train_dataset)
         stat = batch['speaker_stat']
         fin_p, fin_g, metrics = ops.final_metrics(

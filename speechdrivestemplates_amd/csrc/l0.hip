@@ -324,7 +324,6 @@ extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, 
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W, ppb = l0_ppb(HW);
     dim3 grid(cdiv(HW, ppb), B);
-    hipMemsetAsync(mom, 0, sizeof(double) * (size_t)B * L0_NMOM, s);
     hipLaunchKernelGGL(l0_moments_kernel, grid, dim3(256), 0, s, mel, mom, H, W, ppb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_finalize_kernel, dim3(cdiv(groups * L0_C, 64)), dim3(64), 0, s, mom, w, mean, rstd, running_mean,
@@ -345,7 +344,6 @@ extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const flo
     // that push their partial sums through the same global atomics
     const int rpb = std::max(1, (H * B) / 1280);
     dim3 grid(cdiv(H, rpb), B);
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)groups * L0_C, s);
     hipLaunchKernelGGL(l0_bwd_stats_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_dw_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, dw, dgamma, dbeta, H, W,

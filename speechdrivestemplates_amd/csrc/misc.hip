@@ -538,7 +538,6 @@ extern "C" int sdt_final_metrics_f64(const float* pred, const float* gt, const d
     SDT_CHECK_ARG(B > 0 && T > 0 && K > 0 && K <= 128, "bad dims (K <= 128)");
     SDT_CHECK_ARG(!hierarchical || K == 121, "hierarchical poses need the 121-keypoint layout");
     hipStream_t s = (hipStream_t)stream;
-    hipMemsetAsync(work, 0, 4 * sizeof(double), s);
     hipLaunchKernelGGL(final_metrics_kernel, dim3(B * T), dim3(128), 0, s, pred, gt, mean, stdv, scale, hierarchical, T, K,
                        final_pred, final_gt, work, B * T);
     hipLaunchKernelGGL(final_metrics_reduce_kernel, dim3(1), dim3(256), 0, s, work, B, T, K, metrics);

@@ -282,7 +282,6 @@ extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float
     hipStream_t s = (hipStream_t)stream;
     const int rpb = colnorm_rows_per_block(C, G, R);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
     hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rpb);
     hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
@@ -315,7 +314,6 @@ extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, d
     hipStream_t s = (hipStream_t)stream;
     const int rpb = colnorm_rows_per_block(C, G, R);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)G * C, s);
     hipLaunchKernelGGL((colstats_kernel<true>), grid, dim3(256), 0, s, dz, y, mean, rstd, gamma, beta, slope, sums, R, C, rpb);
     hipLaunchKernelGGL(colnorm_apply_bwd_kernel, grid, dim3(256), 0, s, dz, y, dy, sums, mean, rstd, gamma, beta, dgamma,
                        dbeta, R, C, rpb, slope);

@@ -73,6 +73,46 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class _ZeroArena:
+    """fp64 accumulator workspaces that must be zero on entry (colnorm / L0 / metrics, see include/sdt_hip.h).  One
+    region per device is zeroed once per train step (``begin_step``) and handed out in bump-pointer slices, replacing
+    ~30 tiny memset launches per step.  A slice is never handed out twice between two ``begin_step`` calls, so memory
+    not yet handed out is always zero; when the region is exhausted (or outside a train step loop) ``take`` falls back
+    to a fresh ``torch.zeros``."""
+    SIZE = 1 << 19  # doubles (4 MiB)
+
+    def __init__(self):
+        self.buf, self.off = {}, {}
+
+    def begin_step(self, dev):
+        key = (dev.type, dev.index)
+        if key not in self.buf:
+            self.buf[key] = torch.zeros(self.SIZE, device=dev, dtype=torch.float64)
+        elif self.off[key]:
+            self.buf[key][:self.off[key]].zero_()
+        self.off[key] = 0
+
+    def take(self, n, dev):
+        key = (dev.type, dev.index)
+        n_al = (n + 31) & ~31
+        if key not in self.buf or self.off[key] + n_al > self.SIZE:
+            return torch.zeros(n, device=dev, dtype=torch.float64)
+        o = self.off[key]
+        self.off[key] = o + n_al
+        return self.buf[key][o:o + n]
+
+
+_ARENA = _ZeroArena()
+
+
+def begin_step(dev=None):
+    """Recycle the zero-workspace region; call once at the start of a train step, on the main stream, when no kernel of
+    the previous step can still be using its workspaces (i.e. after the side stream has been joined)."""
+    if not torch.cuda.is_current_stream_capturing():
+        join_side_stream()
+    _ARENA.begin_step(torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -370,7 +410,7 @@ class ColNormActFn(torch.autograd.Function):
         C = y.shape[-1]
         R = y.numel() // C // groups
         z = torch.empty_like(y)
-        sums = torch.empty(2 * groups * C, device=y.device, dtype=torch.float64)
+        sums = _ARENA.take(2 * groups * C, y.device)
         mean = torch.empty(groups * C, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
@@ -387,7 +427,7 @@ class ColNormActFn(torch.autograd.Function):
         C = y.shape[-1]
         R = y.numel() // C // ctx.groups
         dy = torch.empty_like(y)
-        sums = torch.empty(2 * ctx.groups * C, device=y.device, dtype=torch.float64)
+        sums = _ARENA.take(2 * ctx.groups * C, y.device)
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
         check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
@@ -407,7 +447,7 @@ class L0BlockFn(torch.autograd.Function):
         B, H, W = mel.shape
         ws = weight_storage(w)
         z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.float32)
-        mom = torch.empty(54 * B, device=mel.device, dtype=torch.float64)
+        mom = _ARENA.take(54 * B, mel.device)
         mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
@@ -422,7 +462,7 @@ class L0BlockFn(torch.autograd.Function):
         lib = _lib.load()
         gz = gz.contiguous()
         B, H, W = mel.shape
-        sums = torch.empty(2 * ctx.groups * 64, device=mel.device, dtype=torch.float64)
+        sums = _ARENA.take(2 * ctx.groups * 64, mel.device)
         gw = grad_buffer(w)
         if weight_storage(gw).data_ptr() != gw.data_ptr():
             raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
@@ -649,7 +689,7 @@ def final_metrics(pred, gt, mean, std, scale, hierarchical, want_final=True):
     dev = pred.device
     fp = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
     fg = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
-    work = torch.empty(2 * B * T + 4, device=dev, dtype=torch.float64)
+    work = _ARENA.take(2 * B * T + 4, dev)
     metrics = torch.empty(2, device=dev, dtype=torch.float64)
     check(_lib.load().sdt_final_metrics_f64(_p(pred), _p(gt), _p(mean.contiguous()), _p(std.contiguous()), _p(scale.contiguous()),
                                             1 if hierarchical else 0, B, T, K, _p(fp), _p(fg), _p(work), _p(metrics), _stream()))
