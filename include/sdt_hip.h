@@ -67,6 +67,16 @@ int sdt_conv_taps_variant(const sdt_conv_geom* g);
 int sdt_conv_dw_variant(const sdt_conv_geom* g);
 /* (Cout,T,Cin) -> (Cin,T,Cout): operand layout for the input-gradient GEMM. */
 int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+/* The same transposition for many layers in ONE launch (all mirrors of an optimiser group are refreshed right after its
+ * Adam step).  table: device array of n_layers descriptors; tile_begin = running sum of
+ * ceil(cin/32)*ceil(cout/32)*taps over the preceding layers, total_tiles = that sum over all layers. */
+typedef struct sdt_wt_desc {
+    const float* w; /* (cout, taps, cin) */
+    float* wt;      /* (cin, taps, cout) */
+    int32_t cout, taps, cin, tile_begin;
+} sdt_wt_desc;
+int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int total_tiles, void* stream);
+
 /* out[c] += sum_rows x[row, c]  (bias gradient of the k1 head conv, generator.py:103). */
 int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream);
 

@@ -19,6 +19,12 @@ class ConvGeom(C.Structure):
                  "ntaps", "Tw")] + [("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wt", C.c_int32 * MAX_TAPS)]
 
 
+class WtDesc(C.Structure):
+    """Mirror of ``sdt_wt_desc`` (include/sdt_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32),
+                ("tile_begin", C.c_int32)]
+
+
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _G = C.POINTER(ConvGeom)
 
@@ -32,6 +38,7 @@ SIGNATURES = {
     "sdt_conv_taps_variant": [_G],
     "sdt_conv_dw_variant": [_G],
     "sdt_weight_transpose_f32": [_p, _p, _i, _i, _i, _p],
+    "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
     "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],

@@ -472,6 +472,31 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt_wt_desc* __restrict__ table, int n_layers) {
+    __shared__ float tile[32][33];
+    const int bid = blockIdx.x;
+    int l = 0;
+    while (l + 1 < n_layers && table[l + 1].tile_begin <= bid) ++l;  // <= a few dozen layers
+    const sdt_wt_desc d = table[l];
+    const int nci = (d.cin + 31) >> 5, nco = (d.cout + 31) >> 5;
+    int rem = bid - d.tile_begin;
+    const int ci0 = (rem % nci) * 32;
+    rem /= nci;
+    const int co0 = (rem % nco) * 32, t = rem / nco;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + ty + 8 * i, ci = ci0 + tx;
+        tile[ty + 8 * i][tx] = (co < d.cout && ci < d.cin) ? d.w[((size_t)co * d.taps + t) * d.cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = ci0 + ty + 8 * i, co = co0 + tx;
+        if (ci < d.cin && co < d.cout) d.wt[((size_t)ci * d.taps + t) * d.cout + co] = tile[tx][ty + 8 * i];
+    }
+}
+
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                       int64_t rows, int C, int rows_per_block) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -646,6 +671,13 @@ extern "C" int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int
     SDT_CHECK_ARG(w && wt && cout > 0 && taps > 0 && cin > 0, "bad argument");
     dim3 grid(cdiv(cin, 32), cdiv(cout, 32), taps);
     hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, cout, taps, cin);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int total_tiles, void* stream) {
+    SDT_CHECK_ARG(table && n_layers > 0 && total_tiles > 0, "bad argument");
+    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, n_layers);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -274,6 +274,68 @@ def conv_forward(x_cl, w, bias, stride, pad):
     return y if x_cl.dim() == 4 else y.squeeze(1)
 
 
+class WeightMirrors:
+    """(Cin,taps,Cout) mirrors of a set of conv weights -- the B operand of the input-gradient GEMM -- refreshed by ONE
+    batched launch for the whole optimiser group instead of one transposition per layer per backward pass.
+    ``lookup`` serves a mirror only while it is provably current: the owning group has not been stepped since the last
+    refresh (optim.FlatAdam.step calls ``mark_dirty``; the first lookup afterwards refreshes all mirrors of the group)
+    and the parameter's autograd version counter is unchanged (``load_state_dict`` / in-place edits bump it).  Code
+    that writes weights through ``.data`` or raw pointers must call ``mark_dirty`` itself."""
+    _by_ptr = {}
+    dirty = True
+
+    def __init__(self, params):
+        import ctypes as C
+        self.entries, descs, tiles = [], [], 0
+        for p in params:
+            if p.dim() not in (3, 4):
+                continue
+            ws = weight_storage(p.data)
+            if ws.data_ptr() != p.data_ptr():
+                continue  # not in the kernel layout: conv_input_grad transposes it per call
+            cout, taps, cin = ws.shape
+            wt = torch.empty((cin, taps, cout), device=p.device, dtype=torch.float32)
+            descs.append(_lib.WtDesc(ws.data_ptr(), wt.data_ptr(), cout, taps, cin, tiles))
+            tiles += ((cin + 31) // 32) * ((cout + 31) // 32) * taps
+            self.entries.append([p, wt, -1])
+        self.total_tiles = tiles
+        if descs:
+            arr = (_lib.WtDesc * len(descs))(*descs)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = raw.to(self.entries[0][0].device)
+            import weakref
+            me = weakref.ref(self)
+            for i, e in enumerate(self.entries):
+                WeightMirrors._by_ptr[e[0].data_ptr()] = (me, i)  # weak: a dead optimiser's mirrors are dropped
+
+    def refresh(self):
+        if not self.entries:
+            return
+        check(_lib.load().sdt_weight_transpose_batched_f32(_p(self.table), len(self.entries), self.total_tiles, _stream()))
+        for e in self.entries:
+            e[2] = e[0]._version
+        self.dirty = False
+
+    def mark_dirty(self):
+        self.dirty = True
+
+    @staticmethod
+    def lookup(w):
+        hit = WeightMirrors._by_ptr.get(w.data_ptr())
+        if hit is None:
+            return None
+        owner = hit[0]()
+        if owner is None:
+            del WeightMirrors._by_ptr[w.data_ptr()]
+            return None
+        p, wt, version = owner.entries[hit[1]]
+        if p.data_ptr() != w.data_ptr() or p.shape != w.shape:
+            return None
+        if owner.dirty or version != p._version:
+            owner.refresh()
+        return wt
+
+
 def conv_input_grad(gy_cl, w, x_shape, stride, pad):
     """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights (one per output parity class)."""
     lib = _lib.load()
@@ -282,10 +344,12 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
     B, Hi, Wi, Cin = (x_shape[0], 1, x_shape[1], x_shape[2]) if one_d else x_shape
     Cout = w.shape[0]
     kh, kw = _ksize(w)
-    ws = weight_storage(w)
-    wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
     st = _stream()
-    check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
+    wt = WeightMirrors.lookup(w)
+    if wt is None:
+        ws = weight_storage(w)
+        wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
+        check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
     dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
     geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, stride, pad) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad)
     k = 1

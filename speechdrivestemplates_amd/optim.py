@@ -49,6 +49,7 @@ class FlatAdam:
         self._lr_host = float(lr)
         self.state_dev = torch.zeros(2, device=dev, dtype=torch.int64)  # {int64 step; float bc1; float bc2_sqrt}
         self.grad_scale = 1.0
+        self.mirrors = ops.WeightMirrors(self.params)  # transposed conv weights for the input-gradient kernels
 
     # -- torch.optim.Optimizer surface used by the reference -------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -66,6 +67,7 @@ class FlatAdam:
         self.sync_lr()
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.state_dev,
                       g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.grad_scale)
+        self.mirrors.mark_dirty()  # the next backward pass refreshes all mirrors in one launch
 
     def _per_param(self, flat, i):
         p, off = self.params[i], self.offsets[i]

@@ -345,6 +345,49 @@ def test_adam_matches_torch(ops):
     check("Adam params after 4 steps", pd[:n], pr, 1e-6)
 
 
+def test_weight_mirrors_stay_current(ops):
+    """The batched (Cin,taps,Cout) weight mirrors behind conv_input_grad: refreshed after an optimiser step, after a
+    torch-level in-place edit (version counter), and dropped with their optimiser."""
+    from speechdrivestemplates_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(21)
+    ws = [torch.nn.Parameter(ops.to_weight_layout((torch.randn(shape, generator=g) * 0.1).to(DEV)))
+          for shape in [(64, 32, 3, 3), (96, 64, 4), (40, 36, 3)]]
+    opt = FlatAdam(ws, lr=1e-2)
+    xs = [(2, 9, 11, 32), (2, 16, 64), (2, 13, 36)]
+
+    def dx_all():
+        out = []
+        for w, xs_ in zip(ws, xs):
+            x = torch.randn(xs_, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+            y = ops.conv_forward(x, w, None, 1, 1)
+            out.append((ops.conv_input_grad(torch.ones_like(y), w, x.shape, 1, 1), w.detach().clone(), x.shape, y.shape))
+        return out
+
+    def check_all(tag):
+        for dx, w, xshape, yshape in dx_all():
+            conv_t = F.conv_transpose2d if w.dim() == 4 else F.conv_transpose1d
+            gy = torch.ones(yshape, dtype=torch.float64).movedim(-1, 1)
+            ref = conv_t(gy, w.double().cpu(), stride=1, padding=1).movedim(1, -1)
+            check(tag, dx, ref, 1e-5)
+
+    check_all("dX, fresh mirrors")
+    assert not opt.mirrors.dirty and ops.WeightMirrors.lookup(ws[0]) is not None
+    for w in ws:
+        w.grad.copy_(torch.randn(w.shape, generator=g).to(DEV))
+    opt.step()  # raw-pointer update of the weights
+    assert opt.mirrors.dirty
+    check_all("dX after an Adam step")
+    with torch.no_grad():
+        ws[1].copy_(torch.randn(ws[1].shape, generator=g).to(DEV) * 0.1)  # what load_state_dict does
+    check_all("dX after an in-place edit")
+    ptr = ws[0].data_ptr()
+    del opt
+    import gc
+    gc.collect()
+    assert ops.WeightMirrors.lookup(ws[0]) is None and ptr not in ops.WeightMirrors._by_ptr
+    check_all("dX without mirrors")
+
+
 def test_mel_frontend(ops):
     from oracle import sdt_oracle as O
     batch = O.make_batch(3, 16, step=0, seed=1)
