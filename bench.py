@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--config", default="voice2pose_sdt_bp")
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="product arithmetic of the forward / input-gradient conv kernels (experiments; the metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
@@ -122,6 +124,7 @@ def main():
     B = args.batch
     ops.OVERLAP_DW = bool(args.overlap_dw)
     ops.OVERLAP_AUX = not args.no_overlap_aux
+    ops.set_conv_math(args.conv_math)
     pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
     batches = stage_batches(4, B, rank, dev)
 
@@ -167,7 +170,8 @@ def main():
             "metric": "training clips/sec (64-frame, 137-kpt) voice2pose_sdt_bp",
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math,
+            "data": "synthetic",
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),

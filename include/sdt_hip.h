@@ -67,6 +67,16 @@ int sdt_conv_taps_variant(const sdt_conv_geom* g);
 int sdt_conv_dw_variant(const sdt_conv_geom* g);
 /* (Cout,T,Cin) -> (Cin,T,Cout): operand layout for the input-gradient GEMM. */
 int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+/* Multiplication arithmetic of sdt_conv_taps(_splitk)_f32 for geometries with Cin % 32 == 0 (process-wide switch; tensors
+ * stay fp32 in HBM and accumulation stays fp32 in every mode):
+ *   SDT_MATH_F32    exact fp32 products on v_mfma_f32_32x32x2_f32 (default; what every parity claim refers to)
+ *   SDT_MATH_BF16   operands rounded to bf16 (v_mfma_f32_32x32x16_bf16) -- BASELINE config 4's precision
+ *   SDT_MATH_BF16X3 2-piece split, 3 bf16 products per fp32 product (~16 significant bits)
+ *   SDT_MATH_BF16X6 exact 3-piece split of the 24-bit significand, 6 bf16 products (dropped terms < 2^-23 |ab|) */
+enum { SDT_MATH_F32 = 0, SDT_MATH_BF16 = 1, SDT_MATH_BF16X3 = 3, SDT_MATH_BF16X6 = 6 };
+int sdt_set_conv_math(int mode);
+int sdt_get_conv_math(void);
+
 /* The same transposition for many layers in ONE launch (all mirrors of an optimiser group are refreshed right after its
  * Adam step).  table: device array of n_layers descriptors; tile_begin = running sum of
  * ceil(cin/32)*ceil(cout/32)*taps over the preceding layers, total_tiles = that sum over all layers. */

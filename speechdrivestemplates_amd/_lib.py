@@ -39,6 +39,7 @@ SIGNATURES = {
     "sdt_conv_dw_variant": [_G],
     "sdt_weight_transpose_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],
+    "sdt_set_conv_math": [_i],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
     "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
@@ -102,6 +103,7 @@ def load():
         fn.restype = C.c_int
     lib.sdt_last_error.restype = C.c_char_p
     lib.sdt_abi_version.restype = C.c_int
+    lib.sdt_get_conv_math.restype = C.c_int
     if lib.sdt_abi_version() != 1:
         raise ImportError("libsdt_hip.so ABI version mismatch")
     _lib = lib

@@ -266,6 +266,240 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv_taps on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 in HBM, fp32 accumulate.
+//   NS = 1: operands rounded to bf16 (RNE)                      -> "bf16" math (BASELINE config 4)
+//   NS = 3: x = x1 + x2 (+ dropped x3), terms a1b1 + a1b2 + a2b1 -> ~16 significant bits ("bf16x3")
+//   NS = 6: x = x1 + x2 + x3 EXACTLY (three 8-bit pieces of the 24-bit significand, split by truncation), terms
+//           a1b1 | a1b2 a2b1 a2b2 a1b3 a3b1 (dropped: < 2^-23 |ab|) -> fp32-equivalent products ("bf16x6")
+// The split happens when the register-staged global tile is written to LDS; LDS holds one [row][32] bf16 image per
+// piece (pitch 40 elements = 80 B: conflict-free ds_read_b128).  The large term and the correction terms go to
+// separate accumulators and are added once at the end.  Same tap table, loaders, culling and epilogue as
+// conv_taps_kernel; 64x64 tile, Cin % 32 == 0 only.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define LDPB 40  // LDS pitch of a [row][32] bf16 tile, in elements
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {  // {bf16 trunc(lo), bf16 trunc(hi)} in one dword
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+template <int NS>
+__device__ __forceinline__ void split_store(const f32x4 v, __bf16* __restrict__ dst, const int plane_stride) {
+    constexpr int NP = NS == 1 ? 1 : (NS == 3 ? 2 : 3);
+    if constexpr (NS == 1) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];  // round to nearest even
+        *(bf16x4*)dst = h;
+    } else {
+        f32x4 r = v;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            u32x2 w;
+            w[0] = pack_hi16(r[0], r[1]);
+            w[1] = pack_hi16(r[2], r[3]);
+            *(u32x2*)(dst + p * plane_stride) = w;
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = r[e] - trunc_bf16(r[e]);  // exact
+            }
+        }
+    }
+}
+
+template <int NS, int BM = 64, int BN = 64>
+__global__ __launch_bounds__(256) void conv_taps_bf_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ Y,
+                                                           const sdt_conv_geom g, const int splitk,
+                                                           float* __restrict__ partial, const size_t ysize) {
+    constexpr int RA = BM / 32, RB = BN / 32, TM = BM / 64, TN = BN / 64;
+    constexpr int NP = NS == 1 ? 1 : (NS == 3 ? 2 : 3);
+    constexpr int PLANEA = BM * LDPB, PLANEB = BN * LDPB;
+    __shared__ __attribute__((aligned(16))) __bf16 sA[NP * PLANEA];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[NP * PLANEB];
+    __shared__ int sOut[BM];
+    __shared__ int sTap[3 * SDT_MAX_TAPS];
+    __shared__ int sLive[SDT_MAX_TAPS + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = g.B * g.Ho * g.Wo;
+    const int nmb = (M + BM - 1) / BM;
+    const int nnb = (g.Cout + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, nmb * nnb);
+    const int m0 = (lin / nnb) * BM;
+    const int n0 = (lin % nnb) * BN;
+
+    if (tid < g.ntaps) {
+        sTap[tid] = g.dy[tid];
+        sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
+        sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
+    }
+    if (tid <= SDT_MAX_TAPS) sLive[tid] = 0;
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            off = ((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout;
+        }
+        sOut[tid] = off;
+    }
+    const int kv = tid & 7, r0 = tid >> 3;
+    int rbH[RA], riy[RA], rix[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            rbH[i] = b * g.Hi;
+            riy[i] = oy * g.sy;
+            rix[i] = ox * g.sx;
+        } else {
+            rbH[i] = 0;
+            riy[i] = -(1 << 20);
+            rix[i] = 0;
+        }
+    }
+    __syncthreads();
+    if (kv == 0) {  // tap culling, as in conv_taps_kernel
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                any |= (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+            if (any) sLive[t] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < g.ntaps; ++t)
+            if (sLive[t]) sLive[n++] = t;
+        sLive[SDT_MAX_TAPS] = n;
+    }
+    __syncthreads();
+    const int ntl = sLive[SDT_MAX_TAPS];
+    const int nkc = g.Cin / BK;
+    const int nsteps_all = ntl * nkc;
+    const int step0 = (int)(((long)blockIdx.z * nsteps_all) / splitk);
+    const int nsteps = (int)(((long)(blockIdx.z + 1) * nsteps_all) / splitk);
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)g.Cout * g.Tw * g.Cin * 4u), 0x00020000);
+    unsigned aoff[RA], boff[RB];
+    int cur_tl = -1;
+    f32x4 ra[RA], rb[RB];
+    auto load = [&](int step) {
+        const int tl = step / nkc;
+        const unsigned cb = (unsigned)((step - tl * nkc) * BK + kv * 4) * 4u;
+        if (tl != cur_tl) {
+            cur_tl = tl;
+            const int t = sLive[tl];
+            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int iy = riy[i] + dy, ix = rix[i] + dx;
+                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(aoff[i] + cb), 0, 0));
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(boff[i] + cb), 0, 0));
+    };
+
+    f32x16 acc[TM][TN], accl[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, accl[i][j][r] = 0.f;
+
+    const __bf16* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDPB + (lane >> 5) * 8;
+    const __bf16* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDPB + (lane >> 5) * 8;
+
+    if (step0 < nsteps) load(step0);
+    for (int step = step0; step < nsteps; ++step) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) split_store<NS>(ra[i], &sA[(r0 + 32 * i) * LDPB + kv * 4], PLANEA);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) split_store<NS>(rb[i], &sB[(r0 + 32 * i) * LDPB + kv * 4], PLANEB);
+        __syncthreads();
+        if (step + 1 < nsteps) load(step + 1);
+        // MFMA k-slot e of lane half h <-> k = 16j + 8h + e for A and B alike
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 a[TM][NP], b[TN][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm][p] = *(const bf16x8*)(pa + p * PLANEA + tm * 32 * LDPB + j * 16);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[tn][p] = *(const bf16x8*)(pb + p * PLANEB + tn * 32 * LDPB + j * 16);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], acc[tm][tn], 0, 0, 0);
+                    if constexpr (NS >= 3) {
+                        accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][NP > 1 ? 1 : 0], accl[tm][tn], 0, 0, 0);
+                        accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 1 ? 1 : 0], b[tn][0], accl[tm][tn], 0, 0, 0);
+                    }
+                    if constexpr (NS == 6) {
+                        accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 1 ? 1 : 0], b[tn][NP > 1 ? 1 : 0], accl[tm][tn], 0, 0, 0);
+                        accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][NP > 2 ? 2 : 0], accl[tm][tn], 0, 0, 0);
+                        accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 2 ? 2 : 0], b[tn][0], accl[tm][tn], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
+    }
+
+    if (splitk > 1) {
+        Y = partial + (size_t)blockIdx.z * ysize;
+        bias = nullptr;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+            const bool nok = n < g.Cout;
+            const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int off = sOut[row];
+                if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight gradient.  GEMM with the reduction over output positions m; operands are m-major in HBM
 // (dY rows are Cout-contiguous, X rows Cin-contiguous) so LDS tiles are [k=m][row] and MFMA operands
@@ -524,12 +758,28 @@ static int check_geom(const sdt_conv_geom* g) {
     return SDT_OK;
 }
 
+static int g_conv_math = SDT_MATH_F32;
+extern "C" int sdt_set_conv_math(int mode) {
+    SDT_CHECK_ARG(mode == SDT_MATH_F32 || mode == SDT_MATH_BF16 || mode == SDT_MATH_BF16X3 || mode == SDT_MATH_BF16X6, "unknown math mode");
+    g_conv_math = mode;
+    return SDT_OK;
+}
+extern "C" int sdt_get_conv_math(void) { return g_conv_math; }
+
 template <int BM, int BN>
 static void launch_taps(bool vec4, const float* x, const float* w, const float* bias, float* y,
                         const sdt_conv_geom& g, int splitk, float* partial, hipStream_t s) {
     const int M = g.B * g.Ho * g.Wo;
     const size_t ysize = (size_t)g.B * g.Hy * g.Wy * g.Cout;
     dim3 grid(cdiv(M, BM) * cdiv(g.Cout, BN), 1, splitk);
+    if (vec4 && g_conv_math != SDT_MATH_F32) {
+        switch (g_conv_math) {
+            case SDT_MATH_BF16: hipLaunchKernelGGL((conv_taps_bf_kernel<1, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+            case SDT_MATH_BF16X3: hipLaunchKernelGGL((conv_taps_bf_kernel<3, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+            default: hipLaunchKernelGGL((conv_taps_bf_kernel<6, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+        }
+        return;
+    }
     static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // tuning experiments
     if (vec4 && prio == 1)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
@@ -570,7 +820,7 @@ static int taps_variant(const sdt_conv_geom* g, bool aligned) {
     const int vec4 = ((g->Cin % BK == 0) && aligned) ? 1 : 0;  // whole 32-channel K chunks: no channel mask in the loop
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
     static const int forced = getenv("SDT_CONV_TILE") ? atoi(getenv("SDT_CONV_TILE")) : 0;  // tuning experiments only
-    if (forced == 64064 || forced == 128064 || forced == 128128) return forced * 10 + vec4;
+    if (forced == 64064 || forced == 64128 || forced == 128064 || forced == 128128) return forced * 10 + vec4;
     // Measured on MI355X (profiles/r01_tile_sweep.txt): the 64x64 tile (54 VGPR + 16 AGPR -> 7 waves/SIMD) beats the
     // 128-wide tiles on every layer of the hot path (92-121 vs 55-113 TFLOP/s): the fp32 MFMA is slow enough that LDS
     // reuse is irrelevant, while occupancy hides the gather latency and the small tile quantises better over 256 CUs.
@@ -603,6 +853,7 @@ extern "C" int sdt_conv_taps_splitk_f32(const float* x, const float* w, const fl
     hipStream_t s = (hipStream_t)stream;
     switch (var / 10) {
         case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
+        case 64128: launch_taps<64, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
         case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
         default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
     }

@@ -274,6 +274,18 @@ def conv_forward(x_cl, w, bias, stride, pad):
     return y if x_cl.dim() == 4 else y.squeeze(1)
 
 
+CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+
+
+def set_conv_math(mode):
+    """Multiplication arithmetic of the forward / input-gradient conv kernels (include/sdt_hip.h: sdt_set_conv_math):
+    'f32' (default, exact fp32 MFMA), 'bf16', 'bf16x3', 'bf16x6'.  Returns the previous mode's name."""
+    lib = _lib.load()
+    prev = lib.sdt_get_conv_math()
+    check(lib.sdt_set_conv_math(CONV_MATH[mode]))
+    return {v: k for k, v in CONV_MATH.items()}[prev]
+
+
 class WeightMirrors:
     """(Cin,taps,Cout) mirrors of a set of conv weights -- the B operand of the input-gradient GEMM -- refreshed by ONE
     batched launch for the whole optimiser group instead of one transposition per layer per backward pass.

@@ -69,6 +69,35 @@ def test_conv2d(ops, case):
     check(tag + " dW accumulate", wd.grad, 2 * wr.grad, 5e-5)
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 3e-6), ("bf16x6", 3e-6), ("bf16x3", 1e-4), ("bf16", 1.5e-2)])
+def test_conv_math_modes(ops, mode, tol):
+    """Opt-in product arithmetic of the forward / input-gradient kernels (sdt_set_conv_math): fp32 in and out in every
+    mode; 'bf16x6' (exact 3-piece split of both operands, 6 bf16 MFMA products) must be as accurate as the exact-fp32
+    MFMA kernel; 'bf16' is BASELINE config 4's precision.  Error is max|d| / max|ref| against float64."""
+    g = torch.Generator().manual_seed(77)
+    cases = [(2, 20, 53, 128, 256, 3, 3, 1, 1), (2, 21, 40, 64, 64, 4, 4, 2, 1), (3, 1, 64, 256, 256, 1, 3, 1, 1)]
+    prev = ops.set_conv_math(mode)
+    try:
+        assert prev == "f32"
+        for B, Hi, Wi, Cin, Cout, kh, kw, s, p in cases:
+            x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+            w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+            xr = x.clone().requires_grad_(True)
+            y = F.conv2d(xr, w, None, s, p)
+            gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+            y.backward(gy)
+            wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+            xd = ops.cl(x.float()).to(DEV)
+            yd = ops.conv_forward(xd, wd, None, s, p)
+            dxd = ops.conv_input_grad(ops.cl(gy.float()).to(DEV), wd, xd.shape, s, p)
+            check("%s fwd" % mode, ops.cf_view(yd), y, tol)
+            check("%s dX" % mode, ops.cf_view(dxd), xr.grad, tol)
+    finally:
+        ops.set_conv_math("f32")
+    with pytest.raises(KeyError):
+        ops.set_conv_math("fp8")
+
+
 CONV1D = [  # (tag, B, T, Cin, Cout, k, s, p, bias)
     ("e0 288->256 k3", 4, 64, 288, 256, 3, 1, 1, False),
     ("e2 256->256 k4s2", 4, 64, 256, 256, 4, 2, 1, False),

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--roles", default="fwd,dX,dW")
+    ap.add_argument("--math", default="f32", help="f32 | bf16 | bf16x3 | bf16x6 (forward / input-gradient kernels)")
     a = ap.parse_args()
     B = a.batch
     roles = a.roles.split(",")
@@ -44,6 +45,12 @@ def main():
             if role == "dX" and name == "L0":
                 continue
             fn = fns[role]
+            err = ""
+            if a.math != "f32" and role != "dW":
+                ref = fn()
+                ops.set_conv_math(a.math)
+                got = fn()
+                err = "  max|d|/max|ref| vs f32 kernel %.2e" % ((got - ref).abs().max() / ref.abs().max()).item()
             fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +60,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
-            print("%-14s %-3s  %8.1f us  %6.1f TFLOP/s  (%.1f GFLOP, out %s)" % (name, role, us, flops / us / 1e6, flops / 1e9, tuple(y.shape)), flush=True)
+            ops.set_conv_math("f32")
+            print("%-14s %-3s  %8.1f us  %6.1f TFLOP/s  (%.1f GFLOP, out %s)%s" % (name, role, us, flops / us / 1e6, flops / 1e9, tuple(y.shape), err), flush=True)
 
 
 if __name__ == "__main__":
