@@ -122,15 +122,17 @@ int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums
  * and the raw conv output is never stored; backward recomputes the normalised pre-activation from mel.
  *   (both workspaces MUST BE ZERO ON ENTRY and are left dirty, like sdt_colnorm_*'s)
  *   fwd: mom = workspace of 54*B doubles; writes z, mean[groups*64], rstd[groups*64] (+ BN running stats / counter).
- *   bwd: sums = workspace of 2*groups*64 doubles; dw (64,9) and dgamma/dbeta (nullable) are ACCUMULATED.
+ *   bwd: mom = the moments fwd left in its workspace (read-only); sums = workspace of 11*groups*64 doubles;
+ *        dw (64,9) and dgamma/dbeta (nullable) are ACCUMULATED.  One pass over dz: the weight gradient is assembled
+ *        from 11 sums per (group, channel) and the mel moments.
  */
 int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
                          float slope, void* stream);
 int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, double* sums, float* dw, float* dgamma, float* dbeta,
-                         int B, int H, int W, int groups, float slope, void* stream);
+                         const float* gamma, const float* beta, const double* mom, double* sums, float* dw, float* dgamma,
+                         float* dbeta, int B, int H, int W, int groups, float slope, void* stream);
 
 /*
  * Row normalisation over C for each of `rows` rows + LeakyReLU: the reference's InstanceNorm1d

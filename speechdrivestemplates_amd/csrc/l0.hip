@@ -10,7 +10,8 @@
 //     never stored;
 //   * in backward the normalised pre-activation is recomputed from the mel image (36 FMAs per 4 channels) instead of
 //     being re-read: statistics of the incoming gradient and the weight gradient each read dz once.
-// Forward: l0_moments -> l0_finalize -> l0_fwd (1 write of 280 MB).  Backward: l0_bwd_stats (1 read) -> l0_dw (1 read).
+// Forward: l0_moments -> l0_finalize -> l0_fwd (1 write of 280 MB).  Backward: l0_bwd_sums (THE one read of the gradient)
+// -> l0_bwd_finalize: the weight gradient is assembled from 11 sums per channel and the forward pass's mel moments.
 #include "common.h"
 
 #define L0_C 64
@@ -176,22 +177,32 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
     }
 }
 
-// sums[g][c][2] doubles (zeroed by the caller): sum g, sum g*yhat with g = dz * act'(gamma*yhat+beta)
-__global__ __launch_bounds__(256) void l0_bwd_stats_kernel(const float* __restrict__ dz, const float* __restrict__ mel,
-                                                           const float* __restrict__ w, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, double* __restrict__ sums, int H,
-                                                           int W, int groups, float slope, int rows_per_block) {
-    __shared__ double sS[L0_C], sQ[L0_C];
+#define L0_NSUM 11  // per (group, channel): sum g, sum g*yhat, sum g*x_t (9 taps)   with g = dz * act'(gamma*yhat+beta)
+
+// Backward, the ONLY pass over dz.  With dy = gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)) the weight gradient
+//   dW[c][t] = sum_pos dy*x_t = gamma*rstd*( sum g*x_t - mean(g)*sum x_t - mean(g*yhat)*sum yhat*x_t )
+// needs, besides three sums over the gradient, only  sum x_t  and  sum yhat*x_t = rstd*(sum_u w[c][u] R[u][t] - mean*S_t),
+// i.e. the first/second moments of the mel image that the forward pass already computed.
+// sums[g][c][11] doubles (zero on entry).  grid (row chunks, B).
+__global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const float* __restrict__ dz, const float* __restrict__ mel,
+                                                          const float* __restrict__ w, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, double* __restrict__ sums, int H,
+                                                          int W, int groups, float slope, int rows_per_block) {
+    __shared__ double sS[L0_C * L0_NSUM];
     const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
     const int y_beg = blockIdx.x * rows_per_block, y_end = min(H, y_beg + rows_per_block);
     const int g = groups == 1 ? 0 : b;
-    if (tid < L0_C) sS[tid] = 0.0, sQ[tid] = 0.0;
+    for (int i = tid; i < L0_C * L0_NSUM; i += 256) sS[i] = 0.0;
     __syncthreads();
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, g, cq);
     const int len = (W + 15) / 16, x0 = seg * len, x1 = min(W, x0 + len);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    float acc[4][L0_NSUM];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < L0_NSUM; ++k) acc[e][k] = 0.f;
     for (int y = y_beg; y < y_end && x0 < x1; ++y) {
         const float* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
         L0Window win;
@@ -210,105 +221,64 @@ __global__ __launch_bounds__(256) void l0_bwd_stats_kernel(const float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gg = gzv[j][e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
-                        s[e] += gg;
-                        q[e] += gg * yh[e];
+                        acc[e][0] += gg;
+                        acc[e][1] = fmaf(gg, yh[e], acc[e][1]);
+#pragma unroll
+                        for (int k = 0; k < L0_T; ++k) acc[e][2 + k] = fmaf(gg, win.nb[k], acc[e][2 + k]);
                     }
                 }
             }
         }
     }
-    // the 4 segment-lanes of a wave that share a channel quad first (bits 4,5 of the lane id), then LDS / global fp64
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        double sd = (double)s[e], qd = (double)q[e];
-        sd += __shfl_xor(sd, 16, 64);
-        sd += __shfl_xor(sd, 32, 64);
-        qd += __shfl_xor(qd, 16, 64);
-        qd += __shfl_xor(qd, 32, 64);
-        if ((tid & 48) == 0) {
-            atomicAdd(&sS[4 * cq + e], sd);
-            atomicAdd(&sQ[4 * cq + e], qd);
-        }
-    }
-    __syncthreads();
-    if (tid < L0_C) {
-        atomicAdd(&sums[((size_t)g * L0_C + tid) * 2], sS[tid]);
-        atomicAdd(&sums[((size_t)g * L0_C + tid) * 2 + 1], sQ[tid]);
-    }
-}
-
-// dW[c][t] += sum_pos dy[c] * x_t  with dy = gamma*rstd*(g - mean_g - yhat*mean_gy); dgamma/dbeta accumulated (BN)
-__global__ __launch_bounds__(256) void l0_dw_kernel(const float* __restrict__ dz, const float* __restrict__ mel,
-                                                    const float* __restrict__ w, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, const double* __restrict__ sums,
-                                                    float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    int H, int W, int groups, double n_per_group, float slope,
-                                                    int rows_per_block) {
-    __shared__ float sD[L0_C * L0_T];
-    const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, pl = tid >> 4;
-    const int y_beg = blockIdx.x * rows_per_block, y_end = min(H, y_beg + rows_per_block);
-    const int g = groups == 1 ? 0 : b;
-    for (int i = tid; i < L0_C * L0_T; i += 256) sD[i] = 0.f;
-    __syncthreads();
-    L0Thread t;
-    l0_setup(t, w, mean, rstd, gamma, beta, g, cq);
-    f32x4 mg, mgy;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const double sg = sums[((size_t)g * L0_C + 4 * cq + e) * 2], sgy = sums[((size_t)g * L0_C + 4 * cq + e) * 2 + 1];
-        mg[e] = (float)(sg / n_per_group);
-        mgy[e] = (float)(sgy / n_per_group);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && pl == 0) {
-            if (dgamma) atomicAdd(&dgamma[4 * cq + e], (float)sgy);
-            if (dbeta) atomicAdd(&dbeta[4 * cq + e], (float)sg);
-        }
-    }
-    const int len = (W + 15) / 16, x0 = pl * len, x1 = min(W, x0 + len);
-    float acc[4][L0_T];
+    // the 4 segment-lanes of a wave that share a channel quad (bits 4,5 of the lane id), then LDS / global fp64 atomics
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int k = 0; k < L0_T; ++k) acc[e][k] = 0.f;
-    for (int y = y_beg; y < y_end && x0 < x1; ++y) {
-        const float* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
-        L0Window win;
-        win.init(mel + (size_t)b * H * W, H, W, y, x0);
-        for (int xb = x0; xb < x1; xb += 4) {
-            f32x4 gzv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                gzv[j] = (xb + j < x1) ? *(const f32x4*)(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = xb + j;
-                if (x < x1) {
-                    if (x > x0) win.advance(x);
-                    const f32x4 yh = l0_yhat(t, win.nb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gg = gzv[j][e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
-                        const float dy = t.ga[e] * t.rs[e] * (gg - mg[e] - yh[e] * mgy[e]);
-#pragma unroll
-                        for (int k = 0; k < L0_T; ++k) acc[e][k] = fmaf(dy, win.nb[k], acc[e][k]);
-                    }
-                }
-            }
-        }
-    }
-    // reduce over the 16 pixel lanes that share a channel quad: lanes tid = pl*16 + cq -> xor over bits 4,5 inside a
-    // wave, then LDS atomics across the 4 waves
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = 0; k < L0_T; ++k) {
+        for (int k = 0; k < L0_NSUM; ++k) {
             float v = acc[e][k];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if ((tid & 48) == 0) atomicAdd(&sD[(4 * cq + e) * L0_T + k], v);
+            if ((tid & 48) == 0) atomicAdd(&sS[(4 * cq + e) * L0_NSUM + k], (double)v);
         }
     __syncthreads();
-    for (int i = tid; i < L0_C * L0_T; i += 256) atomicAdd(&dW[i], sD[i]);
+    for (int i = tid; i < L0_C * L0_NSUM; i += 256) atomicAdd(&sums[(size_t)g * L0_C * L0_NSUM + i], sS[i]);
+}
+
+// thread = (channel, tap): dW[c][t] += sum_groups gamma*rstd*(T - S1/n*S_t - S2/n*Q_t); dgamma += S2, dbeta += S1 (BN)
+__global__ __launch_bounds__(64) void l0_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
+                                                             const float* __restrict__ w, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             float* __restrict__ dW, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int B, int groups, double n_per_group) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (t >= L0_T) return;
+    double wv[L0_T];
+    for (int u = 0; u < L0_T; ++u) wv[u] = (double)w[c * L0_T + u];
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    double dw = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        // moments of this group: first S_u and second R[u][t] (upper-triangular storage, index as in l0_moments_kernel)
+        double S_t = 0.0, wR = 0.0;
+        const int b0 = groups == 1 ? 0 : g, b1 = groups == 1 ? B : g + 1;
+        for (int b = b0; b < b1; ++b) {
+            const double* M = mom + (size_t)b * L0_NMOM;
+            S_t += M[t];
+            for (int u = 0; u < L0_T; ++u) {
+                const int lo = u < t ? u : t, hi = u < t ? t : u;
+                const int idx = L0_T + lo * L0_T - lo * (lo - 1) / 2 + (hi - lo);  // row lo starts after rows 0..lo-1 (9, 8, ... entries)
+                wR += wv[u] * M[idx];
+            }
+        }
+        const double mu = (double)mean[(size_t)g * L0_C + c], rs = (double)rstd[(size_t)g * L0_C + c];
+        const double Q_t = rs * (wR - mu * S_t);
+        const double* sg = sums + ((size_t)g * L0_C + c) * L0_NSUM;
+        dw += ga * rs * (sg[2 + t] - sg[0] / n_per_group * S_t - sg[1] / n_per_group * Q_t);
+        if (t == 0) {
+            if (dgamma) dgamma[c] += (float)sg[1];
+            if (dbeta) dbeta[c] += (float)sg[0];
+        }
+    }
+    dW[c * L0_T + t] += (float)dw;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,9 +304,9 @@ extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, 
 }
 
 extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, double* sums, float* dw, float* dgamma,
-                                    float* dbeta, int B, int H, int W, int groups, float slope, void* stream) {
-    SDT_CHECK_ARG(dz && mel && w && mean && rstd && sums && dw, "null pointer");
+                                    const float* gamma, const float* beta, const double* mom, double* sums, float* dw,
+                                    float* dgamma, float* dbeta, int B, int H, int W, int groups, float slope, void* stream) {
+    SDT_CHECK_ARG(dz && mel && w && mean && rstd && mom && sums && dw, "null pointer");
     SDT_CHECK_ARG(B > 0 && H > 0 && W > 0 && (groups == B || groups == 1), "bad dims (groups must be B or 1)");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
@@ -344,10 +314,10 @@ extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const flo
     // that push their partial sums through the same global atomics
     const int rpb = std::max(1, (H * B) / 1280);
     dim3 grid(cdiv(H, rpb), B);
-    hipLaunchKernelGGL(l0_bwd_stats_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
+    hipLaunchKernelGGL(l0_bwd_sums_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
-    hipLaunchKernelGGL(l0_dw_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, dw, dgamma, dbeta, H, W,
-                       groups, n, slope, rpb);
+    hipLaunchKernelGGL(l0_bwd_finalize_kernel, dim3(L0_C), dim3(64), 0, s, sums, mom, w, mean, rstd, gamma, dw, dgamma, dbeta, B,
+                       groups, n);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

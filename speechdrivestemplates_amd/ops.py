@@ -523,28 +523,28 @@ class L0BlockFn(torch.autograd.Function):
         B, H, W = mel.shape
         ws = weight_storage(w)
         z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.float32)
-        mom = _ARENA.take(54 * B, mel.device)
+        mom = torch.zeros(54 * B, device=mel.device, dtype=torch.float64)  # kept for backward: not from the per-step arena
         mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
                                        _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _stream()))
-        ctx.save_for_backward(mel, w, mean, rstd, gamma, beta)
+        ctx.save_for_backward(mel, w, mean, rstd, gamma, beta, mom)
         ctx.groups, ctx.slope = groups, slope
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        mel, w, mean, rstd, gamma, beta = ctx.saved_tensors
+        mel, w, mean, rstd, gamma, beta, mom = ctx.saved_tensors
         lib = _lib.load()
         gz = gz.contiguous()
         B, H, W = mel.shape
-        sums = _ARENA.take(2 * ctx.groups * 64, mel.device)
+        sums = _ARENA.take(11 * ctx.groups * 64, mel.device)
         gw = grad_buffer(w)
         if weight_storage(gw).data_ptr() != gw.data_ptr():
             raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
-        check(lib.sdt_l0_block_bwd_f32(_p(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums),
+        check(lib.sdt_l0_block_bwd_f32(_p(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mom), _p(sums),
                                        _p(gw), _p(dg), _p(db), B, H, W, ctx.groups, ctx.slope, _stream()))
         return None, None, None, None, None, None, None, None, None
 
