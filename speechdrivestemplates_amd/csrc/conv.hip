@@ -505,7 +505,34 @@ __global__ __launch_bounds__(256) void conv_taps_bf_kernel(const float* __restri
 // (dY rows are Cout-contiguous, X rows Cin-contiguous) so LDS tiles are [k=m][row] and MFMA operands
 // are read with conflict-free ds_read_b32.  grid = (m-splits, column tiles, Cout tiles); partial
 // products are accumulated into dW with fp32 global atomics.
-template <int BM, int BN, bool VEC4>
+// NS > 0 (VEC4 only): the products run on the bf16 MFMA; each wave splits the fp32 fragments it reads from LDS into
+// 1 / 2 / 3 bf16 pieces (see conv_taps_bf_kernel) -- 8 consecutive m per lane and k-slot, gathered with ds_read_b32.
+template <int NS>
+__device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&out)[NS == 1 ? 1 : (NS == 3 ? 2 : 3)]) {
+    constexpr int NP = NS == 1 ? 1 : (NS == 3 ? 2 : 3);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (NS == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[0][e] = (__bf16)v[e];
+    } else {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            u32x4 w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = pack_hi16(r[2 * q], r[2 * q + 1]);
+            out[p] = __builtin_bit_cast(bf16x8, w);
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = r[e] - trunc_bf16(r[e]);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool VEC4, int NS = 0>
 __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW, const sdt_conv_geom g,
                                                       const int rows_per_split) {
@@ -624,12 +651,16 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
     };
 
     f32x16 acc[TM][TN];
+    f32x16 accl[NS >= 3 ? TM : 1][NS >= 3 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NS >= 3) accl[i][j][r] = 0.f;
+            }
 
     if (tid < BK) decode(0);
     __syncthreads();
@@ -644,6 +675,44 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
         if (step + 1 < nsteps && tid < BK) decode(step + 1);
         __syncthreads();
         if (step + 1 < nsteps) load(step + 1);
+        if constexpr (NS > 0) {
+            constexpr int NP = NS == 1 ? 1 : (NS == 3 ? 2 : 3);
+            const float* qa = sA + wm * (BM / 2) + (lane & 31) + 8 * (lane >> 5) * BM;
+            const float* qb = sB + wn * (BN / 2) + (lane & 31) + 8 * (lane >> 5) * BN;
+#pragma unroll
+            for (int j = 0; j < BK / 16; ++j) {  // MFMA k-slot e of lane half h <-> tile row m = 16j + 8h + e
+                bf16x8 a[TM][NP], b[TN][NP];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = qa[(16 * j + e) * BM + tm * 32];
+                    split_frag<NS>(v, a[tm]);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = qb[(16 * j + e) * BN + tn * 32];
+                    split_frag<NS>(v, b[tn]);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], acc[tm][tn], 0, 0, 0);
+                        if constexpr (NS >= 3) {
+                            accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][NP > 1 ? 1 : 0], accl[tm][tn], 0, 0, 0);
+                            accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 1 ? 1 : 0], b[tn][0], accl[tm][tn], 0, 0, 0);
+                        }
+                        if constexpr (NS == 6) {
+                            accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 1 ? 1 : 0], b[tn][NP > 1 ? 1 : 0], accl[tm][tn], 0, 0, 0);
+                            accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][NP > 2 ? 2 : 0], accl[tm][tn], 0, 0, 0);
+                            accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][NP > 2 ? 2 : 0], b[tn][0], accl[tm][tn], 0, 0, 0);
+                        }
+                    }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -657,7 +726,16 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
+        }
         __syncthreads();
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
     }
 
 #pragma unroll
@@ -824,7 +902,7 @@ static int taps_variant(const sdt_conv_geom* g, bool aligned) {
     // Measured on MI355X (profiles/r01_tile_sweep.txt): the 64x64 tile (54 VGPR + 16 AGPR -> 7 waves/SIMD) beats the
     // 128-wide tiles on every layer of the hot path (92-121 vs 55-113 TFLOP/s): the fp32 MFMA is slow enough that LDS
     // reuse is irrelevant, while occupancy hides the gather latency and the small tile quantises better over 256 CUs.
-    (void)M;
+    // (also in the bf16 modes: larger tiles win some isolated layers but lose 3 % over the whole step)
     return 64064 * 10 + vec4;
 }
 extern "C" int sdt_conv_taps_variant(const sdt_conv_geom* g) { return g ? taps_variant(g, true) : SDT_ERR_ARG; }
@@ -885,7 +963,13 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
     int rows = cdiv(cdiv(M, nsplit), BK) * BK;
     nsplit = cdiv(M, rows);
     dim3 grid(nsplit * coltiles * ntiles);
-    if (vec4)
+    if (vec4 && g_conv_math == SDT_MATH_BF16)
+        hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
+    else if (vec4 && g_conv_math == SDT_MATH_BF16X3)
+        hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true, 3>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
+    else if (vec4 && g_conv_math == SDT_MATH_BF16X6)
+        hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true, 6>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
+    else if (vec4)
         hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
     else
         hipLaunchKernelGGL((conv_dw_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, dy, dw, g, rows);

@@ -364,6 +364,31 @@ def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
     assert torch.isfinite(hist[True][1]).all()
 
 
+@pytest.mark.parametrize("mode,tol_pred,tol_loss", [("bf16", 4e-2, 2e-2), ("bf16x6", 2e-4, 3e-3)])
+def test_conv_math_modes_train_steps(golden_traj, mode, tol_pred, tol_loss):
+    """BASELINE config 4 asks for bf16: the opt-in 'bf16' conv arithmetic (operands rounded to bf16, fp32 accumulate,
+    everything else fp32) must track the reference trajectory within bf16 tolerances; 'bf16x6' (fp32-equivalent
+    products on the bf16 MFMA) within the fp32 tolerances of the default path."""
+    from speechdrivestemplates_amd import ops
+    ops.set_conv_math(mode)
+    try:
+        pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+        g = golden_traj
+        for step in range(3):
+            losses, results = pipe.forward_backward(O.make_batch(4, 16, step=step, seed=1))
+            pipe.optimizer_updates(losses)
+            ref_loss = float(g["voice2pose_sdt_bp/s%d/loss/G_loss" % step])
+            got_loss = float(losses["G_loss"].detach())
+            assert abs(got_loss - ref_loss) <= tol_loss * abs(ref_loss), (mode, step, got_loss, ref_loss)
+            if step == 0:
+                ref = torch.from_numpy(g["voice2pose_sdt_bp/s0/pred"])
+                got = results["poses_pred_normalized"].detach().cpu()
+                err = ((got - ref).abs().max() / ref.abs().max()).item()
+                assert err <= tol_pred, (mode, err)
+    finally:
+        ops.set_conv_math("f32")
+
+
 def test_hipgraph_replay_matches_eager():
     """graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
     from speechdrivestemplates_amd.graph import GraphedStep
