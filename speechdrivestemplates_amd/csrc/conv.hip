@@ -279,7 +279,13 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 // conv_taps_kernel; 64x64 tile, Cin % 32 == 0 only.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#define LDPB 40  // LDS pitch of a [row][32] bf16 tile, in elements
+#define LDPB 32  // a [row][32] bf16 LDS tile has 64-byte rows, no padding: the four 16-byte chunks of row r are stored at
+                 // chunk position c ^ ((r >> 2) & 3), which makes both the 8-byte stores (two rows fill one 128-byte bank
+                 // window) and the ds_read_b128 fragment reads (16 rows -> 16 distinct slots of the 256-byte window)
+                 // conflict-free (the padded 80-byte pitch measured SQ_LDS_BANK_CONFLICT ~ 90 % of the LDS cycles)
+__device__ __forceinline__ int bf_tile_off(int row, int k8) {  // element offset of the 8-byte unit k8 (0..7) of a row
+    return row * LDPB + (((k8 >> 1) ^ ((row >> 2) & 3)) << 3) + ((k8 & 1) << 2);
+}
 
 __device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {  // {bf16 trunc(lo), bf16 trunc(hi)} in one dword
     return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
@@ -431,15 +437,19 @@ __global__ __launch_bounds__(256) void conv_taps_bf_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, accl[i][j][r] = 0.f;
 
-    const __bf16* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDPB + (lane >> 5) * 8;
-    const __bf16* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDPB + (lane >> 5) * 8;
+    // fragment read offsets for the two k16 blocks of a step: logical chunk 2j + h of row (.. + lane&31)
+    const int fsw = (lane >> 2) & 3, fh = lane >> 5;
+    const int foff[2] = {((fh ^ fsw) << 3), (((2 + fh) ^ fsw) << 3)};
+    const __bf16* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDPB;
+    const __bf16* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDPB;
+    const int wofs = bf_tile_off(r0, kv);  // (row + 32 i) keeps (row >> 2) & 3: the same swizzle for every i
 
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) split_store<NS>(ra[i], &sA[(r0 + 32 * i) * LDPB + kv * 4], PLANEA);
+        for (int i = 0; i < RA; ++i) split_store<NS>(ra[i], &sA[wofs + 32 * i * LDPB], PLANEA);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) split_store<NS>(rb[i], &sB[(r0 + 32 * i) * LDPB + kv * 4], PLANEB);
+        for (int i = 0; i < RB; ++i) split_store<NS>(rb[i], &sB[wofs + 32 * i * LDPB], PLANEB);
         __syncthreads();
         if (step + 1 < nsteps) load(step + 1);
         // MFMA k-slot e of lane half h <-> k = 16j + 8h + e for A and B alike
@@ -449,9 +459,9 @@ __global__ __launch_bounds__(256) void conv_taps_bf_kernel(const float* __restri
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) a[tm][p] = *(const bf16x8*)(pa + p * PLANEA + tm * 32 * LDPB + j * 16);
+                for (int tm = 0; tm < TM; ++tm) a[tm][p] = *(const bf16x8*)(pa + p * PLANEA + tm * 32 * LDPB + foff[j]);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) b[tn][p] = *(const bf16x8*)(pb + p * PLANEB + tn * 32 * LDPB + j * 16);
+                for (int tn = 0; tn < TN; ++tn) b[tn][p] = *(const bf16x8*)(pb + p * PLANEB + tn * 32 * LDPB + foff[j]);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
