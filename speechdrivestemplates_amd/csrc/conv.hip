@@ -268,6 +268,165 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 
 
 // ---------------------------------------------------------------------------------------------
+// conv_taps with asynchronous global->LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, two
+// LDS buffers and ONE barrier per K step.  An LDS-DMA writes wave-uniform base + lane*16 B, so a tile is stored as
+// unpadded 128-byte rows and the bank-conflict avoidance moves to the SOURCE side: lane (row, position c') fetches the
+// 16-byte chunk c' ^ ((row >> 1) & 7) of its row, and fragment reads address chunk q at position q ^ ((row >> 1) & 7)
+// (16 consecutive rows then hit 16 distinct 16-byte slots of the 256-byte bank window).  64x64 tile, Cin % 32 == 0.
+__global__ __launch_bounds__(256) void conv_taps_dma_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ Y,
+                                                            const sdt_conv_geom g, const int splitk,
+                                                            float* __restrict__ partial, const size_t ysize) {
+    constexpr int BM = 64, BN = 64, RA = 2, RB = 2;
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * BK];
+    __shared__ int sOut[BM];
+    __shared__ int sTap[3 * SDT_MAX_TAPS];
+    __shared__ int sLive[SDT_MAX_TAPS + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = g.B * g.Ho * g.Wo;
+    const int nmb = (M + BM - 1) / BM;
+    const int nnb = (g.Cout + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, nmb * nnb);
+    const int m0 = (lin / nnb) * BM;
+    const int n0 = (lin % nnb) * BN;
+
+    if (tid < g.ntaps) {
+        sTap[tid] = g.dy[tid];
+        sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
+        sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
+    }
+    if (tid <= SDT_MAX_TAPS) sLive[tid] = 0;
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            off = ((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout;
+        }
+        sOut[tid] = off;
+    }
+    const int kv = tid & 7, r0 = tid >> 3;
+    int rbH[RA], riy[RA], rix[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            int ox = m % g.Wo, t = m / g.Wo;
+            int oy = t % g.Ho, b = t / g.Ho;
+            rbH[i] = b * g.Hi;
+            riy[i] = oy * g.sy;
+            rix[i] = ox * g.sx;
+        } else {
+            rbH[i] = 0;
+            riy[i] = -(1 << 20);
+            rix[i] = 0;
+        }
+    }
+    __syncthreads();
+    if (kv == 0) {
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                any |= (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+            if (any) sLive[t] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < g.ntaps; ++t)
+            if (sLive[t]) sLive[n++] = t;
+        sLive[SDT_MAX_TAPS] = n;
+    }
+    __syncthreads();
+    const int ntl = sLive[SDT_MAX_TAPS];
+    const int nkc = g.Cin / BK;
+    const int nsteps_all = ntl * nkc;
+    const int step0 = (int)(((long)blockIdx.z * nsteps_all) / splitk);
+    const int nsteps = (int)(((long)(blockIdx.z + 1) * nsteps_all) / splitk);
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)g.Cout * g.Tw * g.Cin * 4u), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned swz = (unsigned)((kv ^ ((r0 >> 1) & 7)) * 16);  // byte offset of the chunk this lane fetches (r0 + 32 i keeps it)
+    unsigned aoff[RA], boff[RB];
+    int cur_tl = -1;
+    auto issue = [&](int step, int buf) {
+        const int tl = step / nkc;
+        const unsigned cb = (unsigned)((step - tl * nkc) * BK) * 4u + swz;
+        if (tl != cur_tl) {
+            cur_tl = tl;
+            const int t = sLive[tl];
+            const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int iy = riy[i] + dy, ix = rix[i] + dx;
+                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
+            }
+        }
+        // wave w fills rows [8w + 32i, 8w + 32i + 8) of each tile: 1 KiB, lane*16 B apart
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(&sA[buf][(wave * 8 + 32 * i) * BK]), 16, (int)(aoff[i] + cb), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(&sB[buf][(wave * 8 + 32 * i) * BK]), 16, (int)(boff[i] + cb), 0, 0, 0);
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // fragment chunk q = 2j + h of row (lane & 31) sits at position q ^ ((row >> 1) & 7)
+    const int fsw = (lane >> 1) & 7, fh = lane >> 5;
+    int foff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) foff[j] = ((2 * j + fh) ^ fsw) * 4;
+    const int rowA = (wm * 32 + (lane & 31)) * BK, rowB = (wn * 32 + (lane & 31)) * BK;
+
+    if (step0 < nsteps) issue(step0, 0);
+    for (int step = step0; step < nsteps; ++step) {
+        const int buf = (step - step0) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA for `step` has landed
+        __syncthreads();                      // ... everyone's has, and everyone is done reading the other buffer
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const float* pa = &sA[buf][rowA];
+        const float* pb = &sB[buf][rowB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = *(const f32x4*)(pa + foff[j]);
+            const f32x4 b = *(const f32x4*)(pb + foff[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+    }
+
+    if (splitk > 1) {
+        Y = partial + (size_t)blockIdx.z * ysize;
+        bias = nullptr;
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    const bool nok = n < g.Cout;
+    const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int off = sOut[row];
+        if (off >= 0 && nok) Y[(size_t)off + n] = acc[r] + bv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv_taps on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 in HBM, fp32 accumulate.
 //   NS = 1: operands rounded to bf16 (RNE)                      -> "bf16" math (BASELINE config 4)
 //   NS = 3: x = x1 + x2 (+ dropped x3), terms a1b1 + a1b2 + a2b1 -> ~16 significant bits ("bf16x3")
@@ -885,6 +1044,8 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 7>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 8)  // ablation: no global loads, no LDS traffic at all (MFMA + prologue/epilogue only)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 8>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 10 && BM == 64 && BN == 64)  // experiment: asynchronous global->LDS staging
+        hipLaunchKernelGGL(conv_taps_dma_kernel, grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
