@@ -394,9 +394,10 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
 
 # Weight gradients are off the backward critical path (only the optimiser consumes them): with OVERLAP_DW they are
 # launched on a side HIP stream, concurrently with the input-gradient / normalisation chain on the main stream, so the
-# two fill each other's launch tails and the latency-bound 1-D launches.  join_side_stream() is called before the
-# gradient exchange / optimiser step.
-OVERLAP_DW = False
+# two fill each other's launch tails (the 1060-workgroup layers leave 17 % of the CUs idle at the end of a launch) and
+# the latency-bound 1-D launches: +4 % on the train step.  join_side_stream() is called before the gradient exchange /
+# optimiser step.
+OVERLAP_DW = True
 _SIDE = {}
 
 
@@ -407,7 +408,7 @@ def _side_stream():
     return _SIDE[dev]
 
 
-OVERLAP_AUX = False
+OVERLAP_AUX = True  # the no-grad pose-encoder passes of a train step run on the side stream (voice2pose.py)
 
 
 class side_stream_scope:
@@ -459,7 +460,7 @@ class ConvFn(torch.autograd.Function):
         x_cl, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
         if w.requires_grad:
-            if OVERLAP_DW and PROFILER is None and not torch.cuda.is_current_stream_capturing():
+            if OVERLAP_DW and not torch.cuda.is_current_stream_capturing():
                 side = _side_stream()
                 side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
                 with torch.cuda.stream(side):

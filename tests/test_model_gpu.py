@@ -299,8 +299,9 @@ def test_aux_stream_overlap_is_bit_identical():
     two steps must equal the single-stream run exactly (same kernels, same order per stream, deterministic split-K)."""
     from speechdrivestemplates_amd import ops
     outs = []
+    prev = (ops.OVERLAP_AUX, ops.OVERLAP_DW)
     for flag in (False, True):
-        ops.OVERLAP_AUX = flag
+        ops.OVERLAP_AUX, ops.OVERLAP_DW = flag, False  # isolate the aux overlap from the weight-gradient side stream
         try:
             pipe, _ = _make_pipeline("voice2pose_sdt_vae", 16, 0.0)  # no atomically-accumulated code-table gradient
             for step in range(2):
@@ -310,7 +311,7 @@ def test_aux_stream_overlap_is_bit_identical():
             outs.append((results["mu_pred"].clone(), results["logvar_gt"].clone(), losses["G_reg_loss"].clone(),
                          pipe.model.pose_encoder.blocks[3].norm.running_var.clone(), results["poses_pred_normalized"].clone()))
         finally:
-            ops.OVERLAP_AUX = False
+            ops.OVERLAP_AUX, ops.OVERLAP_DW = prev
     for a, b in zip(*outs):
         # weight gradients use fp32 atomics (order-dependent in the last bit), so allow 1e-6 on anything downstream of them
         check("overlap vs single stream", b, a, 2e-5)
