@@ -398,6 +398,7 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
 # the latency-bound 1-D launches: +4 % on the train step.  join_side_stream() is called before the gradient exchange /
 # optimiser step.
 OVERLAP_DW = True
+OVERLAP_DW_MIN_FLOPS = 4e9
 _SIDE = {}
 
 
@@ -460,7 +461,10 @@ class ConvFn(torch.autograd.Function):
         x_cl, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
         if w.requires_grad:
-            if OVERLAP_DW and not torch.cuda.is_current_stream_capturing():
+            # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
+            # side stream costs more than it hides (pose2pose: -11 %)
+            big = 2.0 * gy.numel() * x_cl.shape[-1] * (w.numel() // (w.shape[0] * w.shape[1])) >= OVERLAP_DW_MIN_FLOPS
+            if OVERLAP_DW and big and not torch.cuda.is_current_stream_capturing():
                 side = _side_stream()
                 side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
                 with torch.cuda.stream(side):
