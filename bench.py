@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
+    ap.add_argument("--overlap-dx", action="store_true", help="parity classes of strided input gradients on alternating streams (measured: no gain)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     args = ap.parse_args()
 
@@ -123,6 +124,7 @@ def main():
     from speechdrivestemplates_amd import ops
     B = args.batch
     ops.OVERLAP_DW = not args.no_overlap_dw
+    ops.OVERLAP_DX = bool(args.overlap_dx)
     ops.OVERLAP_AUX = not args.no_overlap_aux
     ops.set_conv_math(args.conv_math)
     pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
