@@ -217,10 +217,16 @@ class Voice2Pose(Trainer):
         ops.begin_step(dev)
         losses, results = self.model(batch, self.train_dataset)
         stat = batch['speaker_stat']
-        fin_p, fin_g, metrics = ops.final_metrics(
-            results['poses_pred_batch'].detach(), results['poses_gt_batch'],
-            stat['mean'].to(dev, non_blocking=True), stat['std'].to(dev, non_blocking=True),
-            stat['scale_factor'].to(dev, non_blocking=True), bool(self.cfg.DATASET.HIERARCHICAL_POSE), want_final)
+        pred, gt = results['poses_pred_batch'].detach(), results['poses_gt_batch']
+        mean, std = stat['mean'].to(dev, non_blocking=True), stat['std'].to(dev, non_blocking=True)
+        scale = stat['scale_factor'].to(dev, non_blocking=True)
+        # the float64 per-step metrics feed only the log: side stream, concurrent with backward (joined before the
+        # optimiser step, like the pose-encoder passes)
+        side = ops.side_stream_scope(True)
+        with side:
+            side.uses(pred, gt, mean, std, scale)
+            fin_p, fin_g, metrics = ops.final_metrics(pred, gt, mean, std, scale, bool(self.cfg.DATASET.HIERARCHICAL_POSE),
+                                                      want_final)
         results['poses_pred_normalized'] = results['poses_pred_batch']  # extension: the raw network output
         if want_final:
             results['poses_pred_batch'], results['poses_gt_batch'] = fin_p, fin_g
