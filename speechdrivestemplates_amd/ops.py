@@ -108,7 +108,7 @@ _ARENA = _ZeroArena()
 def begin_step(dev=None):
     """Recycle the zero-workspace region; call once at the start of a train step, on the main stream, when no kernel of
     the previous step can still be using its workspaces (i.e. after the side stream has been joined)."""
-    if not torch.cuda.is_current_stream_capturing():
+    if _side_ok():
         join_side_stream()
     _ARENA.begin_step(torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev))
 
@@ -423,6 +423,13 @@ OVERLAP_DX = False  # parity classes of a big strided 2-D input gradient on alte
 _SIDE = {}
 
 
+CAPTURE_SIDE_STREAMS = False  # experiment: fork / join the side streams inside a hipGraph capture as well
+
+
+def _side_ok():
+    return CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing()
+
+
 def _side_stream(which=0):
     key = (torch.cuda.current_device(), which)
     if key not in _SIDE:
@@ -438,7 +445,7 @@ class side_stream_scope:
     stream so far) when OVERLAP_AUX is on and ``enabled``; otherwise it is a no-op."""
 
     def __init__(self, enabled=True):
-        self.on = bool(enabled and OVERLAP_AUX and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing())
+        self.on = bool(enabled and OVERLAP_AUX and torch.cuda.is_available() and _side_ok())
         self.ctx = None
 
     def __enter__(self):
@@ -485,7 +492,7 @@ class ConvFn(torch.autograd.Function):
             # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
             # side stream costs more than it hides (pose2pose: -11 %)
             big = 2.0 * gy.numel() * x_cl.shape[-1] * (w.numel() // (w.shape[0] * w.shape[1])) >= OVERLAP_DW_MIN_FLOPS
-            if OVERLAP_DW and big and not torch.cuda.is_current_stream_capturing():
+            if OVERLAP_DW and big and _side_ok():
                 side = _side_stream()
                 side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
                 with torch.cuda.stream(side):
