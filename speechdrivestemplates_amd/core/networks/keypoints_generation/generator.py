@@ -28,9 +28,15 @@ class AudioEncoder(nn.Module):
     def encode_cl(self, mel):
         """mel (B,n_mels,F) -> (B,H',W',256) channels-last feature map (H'=5 for 80 mels)."""
         x = mel.unsqueeze(-1)  # (B,H,W,1): the mel image is already channels-last with C=1
+        hooks = getattr(self, 'grad_bucket_hooks', None)  # {flat block index: hook on that block's INPUT gradient}
+        i = 0
         for stage in self.specgram_encoder_2d:
             for block in stage:
+                if hooks and i in hooks and x.requires_grad:
+                    # fires in backward once blocks i.. have produced their weight gradients (dp.GradReducer buckets)
+                    x.register_hook(hooks[i])
                 x = block.forward_cl(x)
+                i += 1
         return x
 
     def forward(self, x, num_frames):

@@ -196,7 +196,10 @@ class Voice2Pose(Trainer):
         if code.DIMENSION is not None and not code.EXTERNAL_CODE and code.TRAIN:
             add('optimizerClipCode', [self.model.clips_code], cfg.TRAIN.LR * code.LR_SCALING)
         self.reducer = dp.GradReducer(self.optimizers.values())
-        if self.reducer.active:  # early bucket: everything of netG behind the audio encoder (U-Net + decoder, ~14 MB)
+        if self.reducer.active:
+            # Gradient buckets in the order backward completes them (the flat buffer is laid out audio encoder L0..L7,
+            # U-Net, decoder): [U-Net + decoder, ~14 MB] when backward reaches the audio encoder, [L5..L7, ~11 MB] when it
+            # leaves L5; the remaining ~3 MB (L0..L4) and the code table go out right before the optimiser step.
             optg = self.optimizers['optimizerG']
             names = [n for n, p in self.model.netG.named_parameters() if p.requires_grad]
             first = next((i for i, n in enumerate(names) if not n.startswith('audio_encoder.')), None)
@@ -208,6 +211,15 @@ class Voice2Pose(Trainer):
                     return None
 
                 self.model.netG.post_encoder_grad_hook = _launch_late_layers
+                l5 = next((i for i, n in enumerate(names) if n.startswith('audio_encoder.specgram_encoder_2d.2.1.')), None)
+                if l5 is not None and all(n.startswith('audio_encoder.') for n in names[l5:first]):
+                    lo5 = optg.offsets[l5]
+
+                    def _launch_l5_to_l7(grad, _optg=optg, _lo=lo5, _hi=lo, _r=reducer):
+                        _r.launch(_optg, _lo, _hi)
+                        return None
+
+                    self.model.netG.audio_encoder.grad_bucket_hooks = {5: _launch_l5_to_l7}
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, batch, want_final=False):

@@ -80,7 +80,7 @@ def test_two_ranks_one_gpu_match_single_process_full_batch():
         assert p.exitcode == 0
     ref_sd, ref_losses, _ = _run(1, 0)
     (_, sd0, l0, launches0), (_, sd1, l1, _) = res
-    assert len(launches0) == 2 * STEPS  # per step: the U-Net/decoder range from the hook, then the audio-encoder range
+    assert len(launches0) == 3 * STEPS  # per step: U-Net/decoder and L5..L7 from the backward hooks, then the L0..L4 range
     for k, ref in ref_sd.items():
         a, b = torch.from_numpy(sd0[k]), torch.from_numpy(sd1[k])
         assert torch.equal(a, b), k  # both ranks applied the same averaged gradient with the same kernel

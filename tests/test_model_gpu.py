@@ -354,8 +354,9 @@ def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
             if forced:
                 n = pipe.optimizers["optimizerG"].flat_grad.numel()
                 per_step = calls[:len(calls) // 2]
-                assert len(per_step) == 2 and per_step[0][1] == n and per_step[1] == (0, per_step[0][0]), per_step  # late layers first
-                assert 0 < per_step[0][0] < n
+                # buckets in backward order: [U-Net + decoder], [audio encoder L5..L7], [L0..L4]; together the whole buffer once
+                assert len(per_step) == 3 and per_step[0][1] == n and per_step[1][1] == per_step[0][0], per_step
+                assert per_step[2] == (0, per_step[1][0]) and 0 < per_step[1][0] < per_step[0][0] < n, per_step
         finally:
             if forced:
                 os.environ.pop("SDT_DP_FORCE", None)
