@@ -27,7 +27,7 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 N_CLIPS = 4096
-EVENT_EVERY = 6  # HIP events around every conv launch on every 6th timed step (recording them perturbs the step)
+EVENT_STEPS = 4  # timed steps that carry HIP events around every conv launch (recording them perturbs the step): 2 + 2
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -145,14 +145,16 @@ def main():
 
     for i in range(args.warmup):
         runner(i)
-    # HIP events around every conv launch on 1 step in 6, recorded on the stream each kernel is launched on.  By default the
+    # HIP events around every conv launch on a few timed steps, recorded on the stream each kernel is launched on.  By default the
     # weight-gradient kernels run on a second stream, concurrently with the input-gradient chain, so a launch's duration
     # then includes the time it shared the GPU: sampled steps therefore ALTERNATE between "alone" (side stream off for
     # that step: the kernel-quality figure reported as roofline.achieved) and "as run" (roofline.overlapped).
     prof = prof_ovl = None
     if not args.no_kernel_events and not (args.graph and world == 1):
-        prof = ops.ConvProfiler(pool=2 * 200 * (args.steps // EVENT_EVERY + 1))
-        prof_ovl = ops.ConvProfiler(pool=2 * 200 * (args.steps // EVENT_EVERY + 1)) if ops.OVERLAP_DW else None
+        prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS)
+        prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS) if ops.OVERLAP_DW else None
+    n_ev = min(EVENT_STEPS, args.steps) if prof is not None else 0
+    sampled = sorted({(j + 1) * args.steps // (n_ev + 1) for j in range(n_ev)}) if n_ev else []  # spread over the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,7 +164,7 @@ def main():
     for i in range(args.steps):
         if prof is not None:  # sampled: the events serialise the host a little and cost a few % on the steps they cover
             ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
-            if i % EVENT_EVERY == EVENT_EVERY - 1:
+            if i in sampled:
                 if prof_ovl is not None and n_alone > n_ovl:
                     ops.PROFILER, n_ovl = prof_ovl, n_ovl + 1
                 else:
