@@ -391,6 +391,48 @@ def test_conv_math_modes_train_steps(golden_traj, mode, tol_pred, tol_loss):
         ops.set_conv_math("f32")
 
 
+def test_full_size_step_properties_b32():
+    """BASELINE config 2/3 size (32 clips per GPU), where the CPU oracle takes minutes: size-independent properties of the
+    per-sample-normalised sdt generator and its L1 loss instead --
+      * permuting the clips of a batch permutes the predictions (no cross-sample arithmetic in the generator);
+      * the gradient of a 32-clip batch is the mean of the gradients of its two 16-clip halves (what data parallelism
+        relies on), up to fp32 summation noise."""
+    def sub(batch, idx):
+        out = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                out[k] = v[idx]
+            elif isinstance(v, dict):
+                out[k] = {kk: vv[idx] for kk, vv in v.items()}
+            elif isinstance(v, list):
+                out[k] = [v[i] for i in idx.tolist()]
+            else:
+                out[k] = v
+        return out
+
+    pipe, _ = _make_pipeline("voice2pose_sdt_vae", 64, 0.0)
+    full = O.make_batch(32, 64, step=0, seed=5)
+    optg = pipe.optimizers["optimizerG"]
+
+    def grads_of(batch):
+        losses, results = pipe.forward_backward(batch)
+        torch.cuda.synchronize()
+        return optg.flat_grad.detach().clone(), results["poses_pred_normalized"].detach().clone(), float(losses["G_reg_loss"].detach())
+
+    g_full, pred_full, l_full = grads_of(full)
+    perm = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).permutation(32))
+    _, pred_perm, l_perm = grads_of(sub(full, perm))
+    check("B=32 permutation equivariance", pred_perm, pred_full[perm.to(pred_full.device)], 2e-6)
+    assert abs(l_perm - l_full) <= 1e-6 * abs(l_full)
+    g_a, _, l_a = grads_of(sub(full, torch.arange(0, 16)))
+    g_b, _, l_b = grads_of(sub(full, torch.arange(16, 32)))
+    assert abs(0.5 * (l_a + l_b) - l_full) <= 2e-6 * abs(l_full)
+    half = 0.5 * (g_a + g_b)
+    err = (half - g_full).abs().max().item() / g_full.abs().max().item()
+    print("  B=32 gradient additivity: max|mean(halves) - full| / max|full| = %.3e" % err)
+    assert err <= 2e-3, err  # early-layer weight gradients carry ~1e-3 relative fp32 summation noise (SURVEY.md 7)
+
+
 def test_hipgraph_replay_matches_eager():
     """graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
     from speechdrivestemplates_amd.graph import GraphedStep

@@ -452,3 +452,41 @@ def test_error_reporting(ops):
     x = torch.zeros(2, 4, 6, device=DEV)
     with pytest.raises(RuntimeError, match="libsdt_hip"):
         ops.RowNormActFn.apply(x, 0.2)  # C=6 is not a multiple of 4
+
+
+FULL_SIZE = [  # BASELINE config 2 sizes (B=32): name, Hi, Wi, Cin, Cout, kh, kw, s, p
+    ("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1, 1), ("L5", 20, 106, 256, 256, 4, 4, 2, 1),
+    ("L7", 10, 53, 256, 256, 6, 3, 1, 0), ("unet k4s2 T64", 1, 64, 256, 256, 1, 4, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_conv_full_size_properties(ops, case):
+    """At the benchmark's full sizes (B=32) the float64 reference is too slow, so the three conv kernels are tied together
+    by size-independent identities of a linear map and its adjoints:
+        <gy, conv(x, w)>  ==  <x, dX(gy, w)>  ==  <w, dW(x, gy)>           (forward, input-gradient, weight-gradient)
+        conv(a*x1 + x2, w) == a*conv(x1, w) + conv(x2, w)                    (linearity)
+    evaluated with float64 reductions of the fp32 kernel outputs."""
+    tag, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    B = 32
+    gen = torch.Generator(device=DEV).manual_seed(len(tag) * 7 + Cin)
+    one_d = Hi == 1
+    xs, ws = ((B, Wi, Cin), (Cout, Cin, kw)) if one_d else ((B, Hi, Wi, Cin), (Cout, Cin, kh, kw))
+    x = torch.randn(xs, device=DEV, generator=gen)
+    x2 = torch.randn(xs, device=DEV, generator=gen)
+    w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(ws, device=DEV, generator=gen) * (2.0 / (Cin * kh * kw)) ** 0.5))
+    y = ops.conv_forward(x, w, None, s, p)
+    gy = torch.randn(y.shape, device=DEV, generator=gen)
+    dx = ops.conv_input_grad(gy, w, x.shape, s, p)
+    w.grad = None
+    ops.conv_weight_grad(x, gy, w, s, p)
+    torch.cuda.synchronize()
+    a = (gy.double() * y.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.detach().double() * w.grad.double()).sum().item()
+    scale = (gy.double().norm() * y.double().norm()).item()
+    print("  %-16s <gy,y>=%.6e <x,dX>=%.6e <w,dW>=%.6e (|gy||y|=%.3e)" % (tag, a, b, c, scale))
+    assert scale > 0 and abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    y12 = ops.conv_forward(0.5 * x + x2, w, None, s, p)
+    y2 = ops.conv_forward(x2, w, None, s, p)
+    check(tag + " linearity", y12, 0.5 * y.double() + y2.double(), 5e-6)
