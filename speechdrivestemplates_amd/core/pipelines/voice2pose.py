@@ -9,7 +9,6 @@ Deliberate, documented differences from the reference (DESIGN.md "quirks"):
     DistributedDataParallel; discriminator gradients ARE synchronised (the reference's second backward is not);
   * per-loss scalars are reduced to rank 0 in one packed collective, only on logging steps.
 """
-import logging
 from collections import OrderedDict
 
 import torch
