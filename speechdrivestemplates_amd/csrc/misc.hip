@@ -87,13 +87,24 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void code_scatter_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
                                                                float* __restrict__ dtable, int B, int C, int T, int D) {
+    // thread = (time slice tq of 8, (b, d) pair): 32 pairs per workgroup, partial sums combined in slice order
+    __shared__ float sPart[8][32];
     const int total = B * D;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int d = i % D, b = i / D;
+    const int pl = threadIdx.x & 31, tq = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pl;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += dout[((size_t)b * T + t) * (C + D) + C + d];
-    atomicAdd(&dtable[(size_t)idx[b] * D + d], s);
+    if (i < total) {
+        const int d = i % D, b = i / D;
+        for (int t = tq; t < T; t += 8) s += dout[((size_t)b * T + t) * (C + D) + C + d];
+    }
+    sPart[tq][pl] = s;
+    __syncthreads();
+    if (tq == 0 && i < total) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot += sPart[j][pl];
+        atomicAdd(&dtable[(size_t)idx[i / D] * D + (i % D)], tot);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -172,35 +183,67 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
 
 // ---------------------------------------------------------------------------------------------
 // clip-code batch KL (voice2pose.py:147-157); one workgroup, one thread per code dimension
+// One workgroup; thread = (code dimension d, batch slice g): the B gathered rows are spread over 256/Dp slices so that
+// the dependent idx -> table loads of a column run in parallel; per-slice partial sums are combined in slice order
+// (deterministic).  Dp = D rounded up to a power of two.
+struct KlCol {
+    float mu, var;
+};
+template <typename LoadFn>
+__device__ __forceinline__ KlCol kl_column_stats(LoadFn load, int B, int d, int g, int G, int Dp, bool active, float* sRed) {
+    // sRed: G * Dp floats
+    float s = 0.f;
+    if (active)
+        for (int b = g; b < B; b += G) s += load(b);
+    sRed[g * Dp + d] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int j = 0; j < G; ++j) tot += sRed[j * Dp + d];
+    const float mu = tot / (float)B;
+    __syncthreads();
+    float q = 0.f;
+    if (active)
+        for (int b = g; b < B; b += G) {
+            const float dv = load(b) - mu;
+            q += dv * dv;
+        }
+    sRed[g * Dp + d] = q;
+    __syncthreads();
+    float qt = 0.f;
+    for (int j = 0; j < G; ++j) qt += sRed[j * Dp + d];
+    __syncthreads();
+    return {mu, qt / (float)(B - 1)};
+}
+__device__ __forceinline__ int kl_dp(int D) {
+    int Dp = 1;
+    while (Dp < D) Dp <<= 1;
+    return Dp;
+}
+
 __global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
                                                           int B, int D, float lambda, float* __restrict__ code,
                                                           float* __restrict__ loss, int* __restrict__ valid) {
+    __shared__ float sRed[256];
     __shared__ float sTerm[256];
     __shared__ int sBad;
-    const int d = threadIdx.x;
-    if (d == 0) sBad = 0;
+    const int Dp = kl_dp(D), G = 256 / Dp;
+    const int d = threadIdx.x % Dp, g = threadIdx.x / Dp;
+    const bool active = d < D;
+    if (threadIdx.x == 0) sBad = 0;
+    if (active)
+        for (int b = g; b < B; b += G) code[(size_t)b * D + d] = table[(size_t)idx[b] * D + d];
     __syncthreads();
-    float term = 0.f;
-    if (d < D) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float v = table[(size_t)idx[b] * D + d];
-            code[(size_t)b * D + d] = v;
-            s += v;
+    const KlCol c = kl_column_stats([&](int b) { return code[(size_t)b * D + d]; }, B, d, g, G, Dp, active, sRed);
+    if (g == 0) {
+        float term = 0.f;
+        if (active) {
+            if (!(c.var != 0.f)) atomicOr(&sBad, 1);
+            term = -logf(c.var) + c.mu * c.mu + c.var - 1.f;
         }
-        const float mu = s / (float)B;
-        float q = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float dv = table[(size_t)idx[b] * D + d] - mu;
-            q += dv * dv;
-        }
-        const float var = q / (float)(B - 1);
-        if (!(var != 0.f)) atomicOr(&sBad, 1);
-        term = -logf(var) + mu * mu + var - 1.f;
+        sTerm[d] = term;
     }
-    sTerm[d] = term;
     __syncthreads();
-    if (d == 0) {
+    if (threadIdx.x == 0) {
         float s = 0.f;
         for (int j = 0; j < D; ++j) s += sTerm[j];
         const int ok = sBad ? 0 : 1;
@@ -211,21 +254,17 @@ __global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void code_kl_bwd_kernel(const float* __restrict__ code, const int* __restrict__ valid,
                                                           const float* __restrict__ gout, const int64_t* __restrict__ idx,
                                                           int B, int D, float lambda, float* __restrict__ dtable) {
-    const int d = threadIdx.x;
-    if (d >= D || valid[0] == 0) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += code[(size_t)b * D + d];
-    const float mu = s / (float)B;
-    float q = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float dv = code[(size_t)b * D + d] - mu;
-        q += dv * dv;
-    }
-    const float var = q / (float)(B - 1);
+    __shared__ float sRed[256];
+    if (valid[0] == 0) return;  // uniform
+    const int Dp = kl_dp(D), G = 256 / Dp;
+    const int d = threadIdx.x % Dp, g = threadIdx.x / Dp;
+    const bool active = d < D;
+    const KlCol c = kl_column_stats([&](int b) { return code[(size_t)b * D + d]; }, B, d, g, G, Dp, active, sRed);
+    if (!active) return;
     const float k = gout[0] * lambda * 0.5f / (float)D;
-    const float dmu = k * 2.f * mu / (float)B;
-    const float dvar = k * (1.f - 1.f / var) * 2.f / (float)(B - 1);
-    for (int b = 0; b < B; ++b) atomicAdd(&dtable[(size_t)idx[b] * D + d], dmu + dvar * (code[(size_t)b * D + d] - mu));
+    const float dmu = k * 2.f * c.mu / (float)B;
+    const float dvar = k * (1.f - 1.f / c.var) * 2.f / (float)(B - 1);
+    for (int b = g; b < B; b += G) atomicAdd(&dtable[(size_t)idx[b] * D + d], dmu + dvar * (code[(size_t)b * D + d] - c.mu));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,7 +524,7 @@ extern "C" int sdt_resize_concat_bwd_f32(const float* dout, const int64_t* idx, 
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C / 4)), dim3(256), 0, s, dout, dx, B, H, W, C, T, C + D);
     if (D > 0 && dtable != nullptr) {
         SDT_CHECK_ARG(idx != nullptr, "indices missing");
-        hipLaunchKernelGGL(code_scatter_bwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, dout, idx, dtable, B, C, T, D);
+        hipLaunchKernelGGL(code_scatter_bwd_kernel, dim3(cdiv(B * D, 32)), dim3(256), 0, s, dout, idx, dtable, B, C, T, D);
     }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
