@@ -4,7 +4,7 @@ Runs ONLY in the build container (needs /root/reference, imported under tests/go
 here travels to the GPU box or is used by bench.py.  The point is to show that the restatement bench.py times as
 ``cpu_baseline`` (kind "port") is neither slower nor faster than the original, so the reported GPU/CPU ratio is fair.
 
-    python tools/time_reference_cpu.py [--batch 8] [--steps 3] [--threads 8]
+    python tests/tools/time_reference_cpu.py [--batch 8] [--steps 3] [--threads 8]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
 
