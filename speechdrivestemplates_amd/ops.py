@@ -11,6 +11,7 @@ Conventions
     parameters / gradients in two flat buffers (one fused Adam launch, one all-reduce).
 There is no CPU or eager-PyTorch fallback: a non-CUDA tensor raises.
 """
+import functools
 import math
 
 import torch
@@ -41,6 +42,7 @@ def _geom(**kw):
     return g
 
 
+@functools.lru_cache(maxsize=None)
 def fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p):
     """Forward conv: X (B,Hi,Wi,Cin) * W (Cout,kh*kw,Cin) -> Y (B,Ho,Wo,Cout)."""
     Ho, Wo = out_size(Hi, kh, s, p), out_size(Wi, kw, s, p)
@@ -49,6 +51,7 @@ def fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p):
                  Tw=kh * kw, taps=taps)
 
 
+@functools.lru_cache(maxsize=None)
 def dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, s, p):
     """Input gradient as tap-convs of dY (B,Ho,Wo,Cout) with W^T (Cin,kh*kw,Cout) -> dX (B,Hi,Wi,Cin):
     one geometry per output parity class (iy%s, ix%s); only taps with (iy+p-kh)%s==0 contribute, so a k4-s2
@@ -114,7 +117,9 @@ def begin_step(dev=None):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw hipStream_t of torch's current stream on the current device (thread-local, follows torch.cuda.stream());
+    # the C-level getters cost ~0.3 us, torch.cuda.current_stream().cuda_stream ~5 us -- at ~340 launches per step
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _req_cuda(*ts):
@@ -139,6 +144,14 @@ def cf_view(x_cl):
 
 def weight_storage(w):
     """(Cout,Cin,*k) logical weight -> (Cout,taps,Cin) contiguous storage tensor sharing memory when possible."""
+    if w.dim() == 4:  # fast path: already in the kernel layout (every parameter of an engine module is)
+        co, ci, kh, kw = w.shape
+        if w.stride() == (kh * kw * ci, 1, kw * ci, ci):
+            return w.as_strided((co, kh * kw, ci), (kh * kw * ci, ci, 1))
+    elif w.dim() == 3:
+        co, ci, k = w.shape
+        if w.stride() == (k * ci, 1, ci):
+            return w.as_strided((co, k, ci), (k * ci, ci, 1))
     perm = [0] + list(range(2, w.dim())) + [1]
     s = w.permute(perm)
     if not s.is_contiguous():
@@ -177,12 +190,17 @@ def conv_geom_for(x4_shape, w, stride, pad):
     B, Hi, Wi, Cin = x4_shape
     if w.dim() == 4:
         return fwd_geom(B, Hi, Wi, Cin, w.shape[0], w.shape[2], w.shape[3], stride, pad)
-    k = w.shape[2]
+    return _fwd_geom_1d(B, Wi, Cin, w.shape[0], w.shape[2], stride, pad)
+
+
+@functools.lru_cache(maxsize=None)
+def _fwd_geom_1d(B, Wi, Cin, Cout, k, stride, pad):
     Wo = out_size(Wi, k, stride, pad)
-    return _geom(B=B, Hi=1, Wi=Wi, Cin=Cin, Ho=1, Wo=Wo, Hy=1, Wy=Wo, Cout=w.shape[0], sy=1, sx=stride, osy=1, osx=1,
+    return _geom(B=B, Hi=1, Wi=Wi, Cin=Cin, Ho=1, Wo=Wo, Hy=1, Wy=Wo, Cout=Cout, sy=1, sx=stride, osy=1, osx=1,
                  ooy=0, oox=0, Tw=k, taps=[(0, j - pad, j) for j in range(k)])
 
 
+@functools.lru_cache(maxsize=None)
 def dx_geoms_1d(B, Wi, Cin, Cout, k, s, p):
     """1-D analogue of ``dx_geoms`` on (B,1,T,C) views."""
     Wo = out_size(Wi, k, s, p)
@@ -255,6 +273,13 @@ def _conv_launch(kind, is2d, g, call):
     PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
+def _splitk_hint(lib, g):
+    k = getattr(g, "_splitk", None)  # geometries are cached objects: ask the library once per geometry
+    if k is None:
+        k = g._splitk = lib.sdt_conv_taps_splitk_hint(g)
+    return k
+
+
 def conv_forward(x_cl, w, bias, stride, pad):
     """x_cl (B,H,W,Cin)|(B,T,Cin); w logical (Cout,Cin,kh,kw)|(Cout,Cin,k) -> y channels-last."""
     _req_cuda(x_cl, w, bias)
@@ -264,7 +289,7 @@ def conv_forward(x_cl, w, bias, stride, pad):
     ws = weight_storage(w)
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
     st = _stream()
-    k = lib.sdt_conv_taps_splitk_hint(g)
+    k = _splitk_hint(lib, g)
     if k > 1:  # too few output tiles for 256 CUs (1-D stage): slice the K loop, then a fixed-order reduce (+bias)
         part = torch.empty((k,) + tuple(y.shape), device=x_cl.device, dtype=torch.float32)
         _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_splitk_f32(_p(x4), _p(ws), None, _p(y), g, k, _p(part), st))
@@ -366,7 +391,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
     geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, stride, pad) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad)
     k = 1
     if all(g is not None for g, _ in geoms):
-        k = max(lib.sdt_conv_taps_splitk_hint(g) for g, _ in geoms)
+        k = max(_splitk_hint(lib, g) for g, _ in geoms)
     part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
     # The parity classes of a strided input gradient write disjoint elements of dx: big 2-D ones alternate between the
     # main stream and a second side stream so that each launch's tail (4.14 workgroups per CU on the deep layers) is
@@ -469,7 +494,9 @@ class side_stream_scope:
 
 
 def join_side_stream():
-    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    if not _SIDE:
+        return
+    dev = torch._C._cuda_getDevice()
     if (dev, 0) in _SIDE:
         torch.cuda.current_stream().wait_stream(_SIDE[(dev, 0)])
 
