@@ -142,6 +142,10 @@ int sdt_rownorm_fwd_f32(const float* y, float* z, float* mean, float* rstd, int6
                         float eps, float slope, void* stream);
 int sdt_rownorm_bwd_f32(const float* dz, const float* y, const float* mean, const float* rstd, float* dy,
                         int64_t rows, int C, float slope, void* stream);
+/* rownorm_fwd fused with the split-K reduction of the producing conv: partial = nslab slabs of (rows, C) written by
+ * sdt_conv_taps_splitk_f32; y <- their sum in slab order (what sdt_splitk_reduce_f32 computes), z/mean/rstd as above. */
+int sdt_rownorm_slabs_fwd_f32(const float* partial, int nslab, float* y, float* z, float* mean, float* rstd,
+                              int64_t rows, int C, float eps, float slope, void* stream);
 
 /*
  * F.interpolate(x,(1,T),'bilinear') on the (B,H,W,C) encoder output, squeezed, with the gathered

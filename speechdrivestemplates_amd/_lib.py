@@ -48,6 +48,7 @@ SIGNATURES = {
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_rownorm_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i, _f, _p],
+    "sdt_rownorm_slabs_fwd_f32": [_p, _i, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_resize_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_resize_concat_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_upsample_add_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p],

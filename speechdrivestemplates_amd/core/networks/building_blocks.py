@@ -52,6 +52,8 @@ class ConvNormRelu(nn.Module):
                 return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, None, None, None, None, None, x_cl.shape[0], self.slope)
             return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, n.weight, n.bias, n.running_mean, n.running_var,
                                        n.num_batches_tracked, 1, self.slope)
+        if self.norm_type == 'IN' and self.conv_type == '1d':  # conv (+ split-K reduction) + norm over C + activation
+            return ops.ConvRowNormFn.apply(x_cl, self.conv.weight, self.stride, self.padding, self.slope)
         y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W

@@ -183,11 +183,15 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
 
 // ---------------------------------------------------------------------------------------------
 // One wave per row; NV float4 per lane (C <= 256*NV).
-template <int NV, bool BWD>
+// SLABS (forward only): ``a`` holds nslab split-K partial outputs of the producing conv, slab_stride floats apart; they are
+// summed here in slab order (exactly what splitk_reduce_kernel would have done) and the sum is also stored to ``ysum``
+// (the raw conv output backward needs), so conv -> reduce -> norm is two launches instead of three.
+template <int NV, bool BWD, bool SLABS = false>
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ a,  // fwd: y   bwd: dz
                                                       const float* __restrict__ y, float* __restrict__ out,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                      int C, float eps, float slope) {
+                                                      int C, float eps, float slope, int nslab = 1, size_t slab_stride = 0,
+                                                      float* __restrict__ ysum = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -199,6 +203,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         const int c = 4 * (lane + 64 * i);
         ok[i] = c < C;
         v[i] = ok[i] ? *(const f32x4*)(a + base + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SLABS) {
+            if (ok[i]) {
+                for (int z = 1; z < nslab; ++z) v[i] += *(const f32x4*)(a + (size_t)z * slab_stride + base + c);
+                *(f32x4*)(ysum + base + c) = v[i];
+            }
+        }
     }
     const float invC = 1.f / (float)C;
     if constexpr (!BWD) {
@@ -345,6 +355,24 @@ extern "C" int sdt_rownorm_fwd_f32(const float* y, float* z, float* mean, float*
     SDT_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= MAXC, "C must be a multiple of 4 in [4,1024]");
     int rc = launch_rownorm<false>(y, nullptr, z, mean, rstd, rows, C, eps, slope, (hipStream_t)stream);
     if (rc) return rc;
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+extern "C" int sdt_rownorm_slabs_fwd_f32(const float* partial, int nslab, float* y, float* z, float* mean, float* rstd,
+                                         int64_t rows, int C, float eps, float slope, void* stream) {
+    SDT_CHECK_ARG(partial && y && z && mean && rstd && rows > 0 && nslab >= 1 && nslab <= 64, "bad argument");
+    SDT_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= MAXC, "C must be a multiple of 4 in [4,1024]");
+    const unsigned grid = (unsigned)cdiv64(rows, 4);
+    const size_t stride = (size_t)rows * C;
+    hipStream_t s = (hipStream_t)stream;
+    switch (cdiv(C, 256)) {
+        case 1: hipLaunchKernelGGL((rownorm_kernel<1, false, true>), dim3(grid), dim3(256), 0, s, partial, (const float*)nullptr, z, mean, rstd, rows, C, eps, slope, nslab, stride, y); break;
+        case 2: hipLaunchKernelGGL((rownorm_kernel<2, false, true>), dim3(grid), dim3(256), 0, s, partial, (const float*)nullptr, z, mean, rstd, rows, C, eps, slope, nslab, stride, y); break;
+        case 3:
+        case 4: hipLaunchKernelGGL((rownorm_kernel<4, false, true>), dim3(grid), dim3(256), 0, s, partial, (const float*)nullptr, z, mean, rstd, rows, C, eps, slope, nslab, stride, y); break;
+        default: sdt_set_error("%s: unsupported channel count", __func__); return SDT_ERR_UNSUPPORTED;
+    }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -514,25 +514,73 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x_cl, w, bias = ctx.saved_tensors
-        gy = gy.contiguous()
-        if w.requires_grad:
-            # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
-            # side stream costs more than it hides (pose2pose: -11 %)
-            big = 2.0 * gy.numel() * x_cl.shape[-1] * (w.numel() // (w.shape[0] * w.shape[1])) >= OVERLAP_DW_MIN_FLOPS
-            if OVERLAP_DW and big and _side_ok():
-                side = _side_stream()
-                side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
-                with torch.cuda.stream(side):
-                    conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
-                gy.record_stream(side)  # keep the caching allocator from recycling gy under the side stream
-                x_cl.record_stream(side)
-            else:
-                conv_weight_grad(x_cl, gy, w, ctx.stride, ctx.pad)
-        if bias is not None and bias.requires_grad:
-            gb = grad_buffer(bias)
-            check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
-        dx = conv_input_grad(gy, w, x_cl.shape, ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None, None
+        return _conv_backward(x_cl, w, bias, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0]), None, None, None, None
+
+
+def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx):
+    """Weight / bias gradients accumulated into ``.grad``; returns dX (or None)."""
+    if w.requires_grad:
+        # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
+        # side stream costs more than it hides (pose2pose: -11 %)
+        big = 2.0 * gy.numel() * x_cl.shape[-1] * (w.numel() // (w.shape[0] * w.shape[1])) >= OVERLAP_DW_MIN_FLOPS
+        if OVERLAP_DW and big and _side_ok():
+            side = _side_stream()
+            side.wait_stream(torch.cuda.current_stream())  # gy (and x) are produced on the main stream
+            with torch.cuda.stream(side):
+                conv_weight_grad(x_cl, gy, w, stride, pad)
+            gy.record_stream(side)  # keep the caching allocator from recycling gy under the side stream
+            x_cl.record_stream(side)
+        else:
+            conv_weight_grad(x_cl, gy, w, stride, pad)
+    if bias is not None and bias.requires_grad:
+        gb = grad_buffer(bias)
+        check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
+    return conv_input_grad(gy, w, x_cl.shape, stride, pad) if need_dx else None
+
+
+class ConvRowNormFn(torch.autograd.Function):
+    """ConvNormRelu('1d', norm='IN') in one autograd node (building_blocks.py:31-51): Conv1d (no bias) -> per-(b,t) norm
+    over channels -> LeakyReLU.  When the conv is K-split (the 1-D stage: too few output tiles for 256 CUs) the slab
+    reduction is done by the normalisation kernel (sdt_rownorm_slabs_fwd_f32): two launches instead of three, same
+    summation order as conv -> splitk_reduce -> rownorm."""
+
+    @staticmethod
+    def forward(ctx, x_cl, w, stride, pad, slope):
+        _req_cuda(x_cl, w)
+        lib = _lib.load()
+        x_cl = x_cl.contiguous()
+        x4 = _as4(x_cl)
+        g = conv_geom_for(x4.shape, w, stride, pad)
+        k = _splitk_hint(lib, g)
+        ws = weight_storage(w)
+        st = _stream()
+        dev = x_cl.device
+        y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=dev, dtype=torch.float32)
+        z = torch.empty_like(y)
+        rows, C = g.B * g.Ho * g.Wo, g.Cout
+        mean = torch.empty(rows, device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        if k > 1:
+            part = torch.empty((k,) + tuple(y.shape), device=dev, dtype=torch.float32)
+            _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_splitk_f32(_p(x4), _p(ws), None, _p(y), g, k, _p(part), st))
+            check(lib.sdt_rownorm_slabs_fwd_f32(_p(part), k, _p(y), _p(z), _p(mean), _p(rstd), rows, C, BN_EPS, slope, st))
+        else:
+            _conv_launch("fwd", w.dim() == 4, g, lambda: lib.sdt_conv_taps_f32(_p(x4), _p(ws), None, _p(y), g, st))
+            check(lib.sdt_rownorm_fwd_f32(_p(y), _p(z), _p(mean), _p(rstd), rows, C, BN_EPS, slope, st))
+        if x_cl.dim() == 3:
+            y, z = y.squeeze(1), z.squeeze(1)
+        ctx.save_for_backward(x_cl, w, y, mean, rstd)
+        ctx.stride, ctx.pad, ctx.slope = stride, pad, slope
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x_cl, w, y, mean, rstd = ctx.saved_tensors
+        gz = gz.contiguous()
+        C = y.shape[-1]
+        gy = torch.empty_like(y)
+        check(_lib.load().sdt_rownorm_bwd_f32(_p(gz), _p(y), _p(mean), _p(rstd), _p(gy), y.numel() // C, C, ctx.slope, _stream()))
+        return _conv_backward(x_cl, w, None, gy, ctx.stride, ctx.pad, ctx.needs_input_grad[0]), None, None, None, None
 
 
 class ColNormActFn(torch.autograd.Function):
