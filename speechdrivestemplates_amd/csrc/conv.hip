@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     }
     __syncthreads();
     int ntl = g.ntaps;
-    if constexpr (VEC4) {
+    if (VEC4 && g.Hi == 1 && PRIO != 11) {
+        // 1-D stage: a tap can only be dead for a whole tile when T is tiny, and these launches are latency-bound --
+        // skip the culling passes (two barriers and two serial loops of the prologue)
+        if (tid < g.ntaps) sLive[tid] = tid;
+        if (tid == 0) sLive[SDT_MAX_TAPS] = g.ntaps;
+        __syncthreads();
+    } else if constexpr (VEC4) {
         // tap culling: a tap whose input coordinates are out of range for EVERY row of this tile contributes only
         // zeros -- skip its K steps (halves the work of the p=0 (6,3) layer's input gradient; trims padded borders)
         if (kv == 0) {
@@ -1046,6 +1052,8 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 8>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 10 && BM == 64 && BN == 64)  // experiment: asynchronous global->LDS staging
         hipLaunchKernelGGL(conv_taps_dma_kernel, grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 11)  // A/B: tap culling also on 1-D launches (the previous behaviour)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 11>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
