@@ -489,4 +489,4 @@ def test_conv_full_size_properties(ops, case):
     assert scale > 0 and abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
     y12 = ops.conv_forward(0.5 * x + x2, w, None, s, p)
     y2 = ops.conv_forward(x2, w, None, s, p)
-    check(tag + " linearity", y12, 0.5 * y.double() + y2.double(), 5e-6)
+    check(tag + " linearity", y12, 0.5 * y.double() + y2.double(), 1e-5)  # three fp32 roundings of K ~ 4096 products
