@@ -327,16 +327,29 @@ class Voice2Pose(Trainer):
 
 
 class _MultiStepLR:
-    """torch.optim.lr_scheduler.MultiStepLR on FlatAdam.param_groups (stepped once per epoch, trainer.py:396-398)."""
+    """torch.optim.lr_scheduler.MultiStepLR on FlatAdam.param_groups, stepped once per epoch (voice2pose.py:253-279,
+    trainer.py:396-398), with torch's exact (recursive) semantics, which the reference's resume path depends on:
+      * construction does one ``step()``; a step multiplies the CURRENT lr by gamma^(multiplicity) only when the new
+        ``last_epoch`` EQUALS a milestone -- a milestone <= 0 other than 0 never fires, and a resumed optimiser keeps the
+        (already decayed) lr it was saved with;
+      * resuming (``last_epoch != -1``) requires 'initial_lr' in the loaded param group (torch raises KeyError otherwise);
+      * resumed from a checkpoint of epoch k the counter sits at k+1 while epoch k runs, so milestones fire one epoch
+        earlier than in an uninterrupted run (reference behaviour, reproduced)."""
 
     def __init__(self, opt, milestones, gamma, last_epoch=-1):
-        self.opt, self.milestones, self.gamma = opt, sorted(milestones), gamma
-        self.base_lr = opt.param_groups[0]['lr']
+        self.opt, self.gamma = opt, gamma
+        self.milestones = {m: list(milestones).count(m) for m in milestones}
+        g = opt.param_groups[0]
+        if last_epoch == -1:
+            g.setdefault('initial_lr', g['lr'])
+        elif 'initial_lr' not in g:
+            raise KeyError("param 'initial_lr' is not specified in param_groups[0] when resuming an optimizer")
+        self.base_lr = g['initial_lr']
         self.last_epoch = last_epoch
         self.step()
 
     def step(self):
         self.last_epoch += 1
-        n = sum(1 for m in self.milestones if m <= self.last_epoch)
-        self.opt.param_groups[0]['lr'] = self.base_lr * (self.gamma ** n)
+        if self.last_epoch in self.milestones:
+            self.opt.param_groups[0]['lr'] *= self.gamma ** self.milestones[self.last_epoch]
         self.opt.sync_lr()

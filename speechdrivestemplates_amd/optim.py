@@ -89,7 +89,7 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         g = sd['param_groups'][0]
-        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+        for k in ('lr', 'betas', 'eps', 'weight_decay', 'initial_lr'):  # 'initial_lr' is what an lr scheduler left there
             if k in g:
                 self.param_groups[0][k] = g[k]
         step = 0

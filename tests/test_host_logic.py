@@ -1,0 +1,61 @@
+"""Host-side logic that does not need a GPU: the per-epoch learning-rate schedule must follow
+torch.optim.lr_scheduler.MultiStepLR exactly as the reference drives it (voice2pose.py:253-279, trainer.py:172-200,396-398),
+including its behaviour when training is resumed from a checkpoint."""
+import pytest
+import torch
+
+
+class _Opt:
+    """What _MultiStepLR needs of FlatAdam: param_groups[0] and sync_lr()."""
+
+    def __init__(self, lr, group=None):
+        self.param_groups = [dict(lr=lr) if group is None else dict(group)]
+        self.synced = []
+
+    def sync_lr(self):
+        self.synced.append(self.param_groups[0]['lr'])
+
+
+def _torch_run(E, epochs, resume_at=None):
+    """lr seen during each epoch by the reference's loop; optionally save after `resume_at` epochs and resume."""
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([w], lr=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [E - 10, E - 2], gamma=0.1, last_epoch=-1)
+    seen = []
+    for epoch in range(epochs):
+        if resume_at is not None and epoch == resume_at:
+            sd = opt.state_dict()  # what trainer.save_checkpoint stores after `epoch` epochs
+            opt = torch.optim.Adam([w], lr=1e-4)
+            opt.load_state_dict(sd)
+            sch = torch.optim.lr_scheduler.MultiStepLR(opt, [E - 10, E - 2], gamma=0.1, last_epoch=epoch)
+        seen.append(opt.param_groups[0]['lr'])
+        opt.step()
+        sch.step()
+    return seen
+
+
+def _own_run(E, epochs, resume_at=None):
+    from speechdrivestemplates_amd.core.pipelines.voice2pose import _MultiStepLR
+    opt = _Opt(1e-4)
+    sch = _MultiStepLR(opt, [E - 10, E - 2], 0.1, -1)
+    seen = []
+    for epoch in range(epochs):
+        if resume_at is not None and epoch == resume_at:
+            opt = _Opt(1e-4, group=opt.param_groups[0])  # FlatAdam.load_state_dict copies lr and initial_lr
+            sch = _MultiStepLR(opt, [E - 10, E - 2], 0.1, epoch)
+        seen.append(opt.param_groups[0]['lr'])
+        sch.step()
+    return seen
+
+
+@pytest.mark.parametrize("E,resume_at", [(100, None), (100, 50), (100, 89), (100, 90), (100, 97), (100, 98), (12, None), (12, 1),
+                                         (2, None), (2, 1)])
+def test_lr_schedule_matches_torch_multisteplr(E, resume_at):
+    got, want = _own_run(E, E, resume_at), _torch_run(E, E, resume_at)
+    assert got == pytest.approx(want, rel=1e-12), (E, resume_at, got[-12:], want[-12:])
+
+
+def test_lr_schedule_resume_needs_initial_lr():
+    from speechdrivestemplates_amd.core.pipelines.voice2pose import _MultiStepLR
+    with pytest.raises(KeyError):
+        _MultiStepLR(_Opt(1e-4), [90, 98], 0.1, last_epoch=5)
