@@ -170,14 +170,15 @@ class Trainer(object):
             self.model.train()
             tic = time.time()
             if getattr(self, 'train_sampler', None) is not None:
-                self.train_sampler.set_epoch(epoch)
+                self.train_sampler.set_epoch(epoch + 1)  # the reference counts epochs from 1 (trainer.py:379,384)
             for t_step, batch in enumerate(self.train_dataloader):
                 global_step += 1
                 self.train_step(batch, t_step + 1, global_step, epoch + 1)
-            if self.is_master_process() and (epoch + 1) % self.cfg.TRAIN.CHECKPOINT_INTERVAL == 0:
-                self.save_checkpoint(epoch + 1, global_step)
-            if self.cfg.TRAIN.VALIDATE:
-                self.validate(epoch + 1)
+            if (epoch + 1) % self.cfg.TRAIN.CHECKPOINT_INTERVAL == 0:  # validation rides on the checkpoint interval (:389-394)
+                if self.is_master_process():
+                    self.save_checkpoint(epoch + 1, global_step)
+                if self.cfg.TRAIN.VALIDATE:
+                    self.validate(epoch + 1)
             for s in self.schedulers.values():
                 s.step()
             if self.is_master_process():
