@@ -88,3 +88,32 @@ class Pose2Pose(Trainer):
                 dp.reduce_scalars(losses)
             if self.is_master_process():
                 self.logger_writer_step('TRAIN', losses, t_step, epoch, global_step)
+
+    @torch.no_grad()
+    def test_step(self, batch, t_step, epoch=0):
+        """Validation / test step of the pose VAE (pose2pose.py:172-217) without the video writer."""
+        tag = 'TEST' if epoch == 0 else 'VAL'
+        dev = self.model.clip_code_mu.device
+        m = self.cfg.TEST.MULTIPLE
+        assert isinstance(m, int) and m >= 1, 'TEST.MULTIPLE should be an integer that larger than 1, but get %r (%s).' % (m, type(m))
+        if m > 1:
+            batch = self.mutiply_batch(batch, m)
+        losses, results = self.model(batch, is_testing=True)
+        stat = batch['speaker_stat']
+        fin_p, fin_g, metrics = ops.final_metrics(results['poses_pred_batch'], results['poses_gt_batch'], stat['mean'].to(dev),
+                                                  stat['std'].to(dev), stat['scale_factor'].to(dev),
+                                                  bool(self.cfg.DATASET.HIERARCHICAL_POSE), True)
+        results['poses_pred_batch'], results['poses_gt_batch'] = fin_p, fin_g
+        losses['L2_dist'], losses['lip_sync_error_n'] = metrics[0], metrics[1]
+        if m > 1:  # spread of the per-copy mean distance over the TEST.MULTIPLE stochastic decodings (pose2pose.py:271-281)
+            per_copy = torch.norm(fin_p - fin_g, p=2, dim=2).reshape(m, -1).mean(1)
+            losses['L2_dist_min'], losses['L2_dist_max'] = per_copy.min(), per_copy.max()
+        if self.cfg.SYS.DISTRIBUTED:
+            dp.reduce_scalars(losses)
+        if self.is_master_process():
+            if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
+                self.logger_writer_step(tag, losses, t_step, epoch)
+            if t_step % self.result_saving_interval_test == 0 and self.cfg.TEST.SAVE_NPZ and self.base_path is not None:
+                self.save_results(tag, t_step, epoch, self.base_path,
+                                  {k: v.detach().cpu().numpy() for k, v in results.items() if torch.is_tensor(v)})
+        return {k: v.detach() * self.cfg.TEST.BATCH_SIZE for k, v in losses.items()}, {}

@@ -31,6 +31,7 @@ class Trainer(object):
         self.test_dataset = None
         self.num_train_samples = None
         self.result_saving_interval_train = 1 << 60
+        self.result_saving_interval_test = 1 << 60
         self.base_path = None
         self.step_tic = time.time()
         if not torch.cuda.is_available():
@@ -77,6 +78,19 @@ class Trainer(object):
                                           num_workers=cfg.SYS.NUM_WORKERS // ws, sampler=sampler)
         self.num_test_samples = len(self.test_dataset)
         self.num_test_batches = len(self.test_dataloader)
+        self.result_saving_interval_test = max(1, self.num_test_batches // cfg.TEST.NUM_RESULT_SAMPLE)  # trainer.py:96-97
+
+    def mutiply_batch(self, batch, multiple):
+        """TEST.MULTIPLE copies of every sample, batch-major (trainer.py:343-353; name as in the reference)."""
+        if isinstance(batch, dict):
+            for k, v in batch.items():
+                batch[k] = self.mutiply_batch(v, multiple)
+            return batch
+        if isinstance(batch, list):
+            return batch * multiple
+        if isinstance(batch, torch.Tensor):
+            return batch.unsqueeze(0).repeat_interleave(multiple, dim=0).reshape(multiple * batch.shape[0], *batch.shape[1:])
+        raise NotImplementedError
 
     def setup_model(self, cfg, state_dict=None):
         raise NotImplementedError

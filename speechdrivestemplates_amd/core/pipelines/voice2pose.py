@@ -282,7 +282,12 @@ class Voice2Pose(Trainer):
     @torch.no_grad()
     def test_step(self, batch, t_step, epoch=0):
         """Validation / test step (voice2pose.py:333-384) without the video writer."""
+        tag = 'TEST' if epoch == 0 else 'VAL'
         dev = self.model._device()
+        m = self.cfg.TEST.MULTIPLE
+        assert isinstance(m, int) and m >= 1, 'TEST.MULTIPLE should be an integer that larger than 1, but get %r (%s).' % (m, type(m))
+        if m > 1:
+            batch = self.mutiply_batch(batch, m)
         losses, results = self.model(batch, self.test_dataset)
         stat = batch['speaker_stat']
         fin_p, fin_g, metrics = ops.final_metrics(results['poses_pred_batch'], results['poses_gt_batch'], stat['mean'].to(dev),
@@ -292,6 +297,12 @@ class Voice2Pose(Trainer):
         losses['L2_dist'], losses['lip_sync_error_n'] = metrics[0], metrics[1]
         if self.cfg.SYS.DISTRIBUTED:
             dp.reduce_scalars(losses)
+        if self.is_master_process():
+            if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
+                self.logger_writer_step(tag, losses, t_step, epoch)
+            if t_step % self.result_saving_interval_test == 0 and self.cfg.TEST.SAVE_NPZ and self.base_path is not None:
+                self.save_results(tag, t_step, epoch, self.base_path,
+                                  {k: v.detach().cpu().numpy() for k, v in results.items() if torch.is_tensor(v)})
         batch_losses = {k: v.detach() * self.cfg.TEST.BATCH_SIZE for k, v in losses.items()}
         keep = ('mu_pred', 'mu_gt', 'logvar_pred', 'logvar_gt', 'condition_code')
         return batch_losses, {k: v.detach().cpu().numpy() for k, v in results.items() if k in keep and v is not None}
