@@ -119,8 +119,18 @@ class GestureDataset(PoseTransforms, Dataset):
             return
         assert speaker is not None, 'The speaker is "None"!'
         self.root_dir = os.path.join(root_dir, speaker)
-        if split == 'demo':
-            raise NotImplementedError('demo input (wav via librosa) is outside the training hot path')
+        if split == 'demo':  # wav file(s) / a directory of wav files (gesture_dataset.py:28-36)
+            assert demo_input is not None, 'demo split needs demo_input'
+            if len(demo_input.split()) == 1 and os.path.isdir(demo_input):
+                files = os.listdir(demo_input)
+                np.random.shuffle(files)
+                files = [f for f in files[:1000] if f.split('.')[-1] == 'wav'][:cfg.DEMO.NUM_SAMPLES]
+                self.clips = [os.path.join(demo_input, f) for f in files]
+            else:
+                self.clips = demo_input.split()
+            if self.cfg.SUBSET is not None:
+                self.clips = self.clips[:self.cfg.SUBSET]
+            return
         if split not in ('train', 'val'):
             raise NotImplementedError(split)
         csv_path = os.path.join(self.root_dir, 'processed_137.csv')
@@ -143,7 +153,40 @@ class GestureDataset(PoseTransforms, Dataset):
         poses[..., :2, :] = poses[..., :2, :] - poses[..., :2, self.root_node, None]
         return poses[..., :, _DROP_ROOT]
 
+    def _demo_item(self, idx):
+        """gesture_dataset.py:54-79.  The reference decodes with librosa.load(path, sr=16000) (mono, float32 in [-1,1]);
+        here PCM wav files are read with scipy and, only if their rate differs from DATASET.AUDIO_SR, resampled with a
+        polyphase filter (librosa's resampler is not available offline -- identical samples for 16 kHz input)."""
+        feed = self.clips[idx]
+        if feed.split('.')[-1] != 'wav':
+            raise NotImplementedError('Audio format %s is not supported.' % feed.split('.')[-1])
+        from scipy.io import wavfile
+        sr, a = wavfile.read(feed)
+        if a.dtype.kind == 'i':
+            a = a.astype(np.float32) / float(2 ** (8 * a.dtype.itemsize - 1))
+        elif a.dtype.kind == 'u':  # 8-bit PCM is unsigned
+            a = (a.astype(np.float32) - 128.0) / 128.0
+        else:
+            a = a.astype(np.float32)
+        if a.ndim == 2:
+            a = a.mean(axis=1)
+        if sr != self.cfg.AUDIO_SR:
+            from math import gcd
+            from scipy.signal import resample_poly
+            k = gcd(int(sr), int(self.cfg.AUDIO_SR))
+            a = resample_poly(a, self.cfg.AUDIO_SR // k, sr // k).astype(np.float32)
+        if self.cfg.MAX_DEMO_LENGTH is not None:
+            max_length = self.cfg.MAX_DEMO_LENGTH * self.cfg.AUDIO_SR
+            if len(a) > max_length:
+                start = np.random.randint(0, len(a) - max_length)
+                a = a[start:start + max_length]
+        audio_length, num_frames = parse_audio_length(len(a), self.cfg.AUDIO_SR, self.cfg.FPS)
+        return {'speaker': self.speaker, 'audio': crop_pad_audio(a, audio_length), 'clip_index': idx,
+                'speaker_stat': self.get_speaker_stat(self.speaker, 121, self.cfg.HIERARCHICAL_POSE), 'num_frames': num_frames}
+
     def __getitem__(self, idx):
+        if self.split == 'demo':
+            return self._demo_item(idx)
         clip = self.clips.iloc[idx]
         speaker = clip['speaker']
         arr = np.load(os.path.join(self.root_dir, clip['pose_fn']))

@@ -67,6 +67,12 @@ class Trainer(object):
         elif split == 'test':
             self.num_train_samples = None
             self._setup_eval(cfg, ds_cls, 'val', ws)
+        elif split == 'demo':  # one clip per step, variable length (trainer.py:124-132)
+            self.num_train_samples = None
+            self.test_dataset = get_dataset('GestureDataset')(cfg.DATASET.ROOT_DIR, cfg.DATASET.SPEAKER, 'demo', cfg, demo_input=demo_input)
+            self.test_dataloader = DataLoader(self.test_dataset, batch_size=1, shuffle=False, num_workers=0)
+            self.num_test_samples = len(self.test_dataset)
+            self.num_test_batches = len(self.test_dataloader)
         else:
             raise Exception('Unknown data split.')
 
@@ -103,7 +109,7 @@ class Trainer(object):
         dt = str(datetime.now()).replace('.', '-').replace(':', '-').replace(' ', '_')
         exp_tag = '_'.join([dt, exp_tag])
         if not is_training:
-            self.setup_dataset(self.cfg, 'test')
+            self.setup_dataset(self.cfg, 'test' if demo_input is None else 'demo', demo_input=demo_input)
             base_path = os.path.join(self.cfg.SYS.OUTPUT_DIR, exp_tag)
             if self.is_master_process():
                 os.makedirs(base_path, exist_ok=True)
@@ -220,3 +226,20 @@ class Trainer(object):
     def test(self, exp_tag, checkpoint):
         self.base_path = self.setup_experiment(False, exp_tag, checkpoint=checkpoint)
         return self.validate(0)
+
+    @torch.no_grad()
+    def demo(self, exp_tag, checkpoint, demo_input):
+        """Variable-length inference on wav input (trainer.py:459-484): one demo_step per clip, or DEMO.MULTIPLE steps with the
+        code interpolation coefficient swept over [0, 1].  Returns the list of results dicts (the reference only writes
+        videos / npz files)."""
+        self.base_path = self.setup_experiment(False, exp_tag, checkpoint=checkpoint, demo_input=demo_input)
+        self.model.eval()
+        out = []
+        for t_step, batch in enumerate(self.test_dataloader):
+            m = self.cfg.DEMO.MULTIPLE
+            if m > 1:
+                for i in range(m):
+                    out.append(self.demo_step(batch, t_step + 1, epoch=0, extra_id=i, interpolation_coeff=i / (m - 1)))
+            else:
+                out.append(self.demo_step(batch, t_step + 1, epoch=0))
+        return out

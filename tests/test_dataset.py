@@ -114,3 +114,36 @@ def test_train_step_from_device_clip_store(tmp_path):
     (reg_a, l2_a, pred_a), (reg_b, l2_b, pred_b) = out
     assert torch.equal(reg_a, reg_b) and torch.equal(pred_a, pred_b)
     assert abs(float(l2_a) - float(l2_b)) <= 1e-12 * abs(float(l2_a))  # float64 atomics: summation order only
+
+
+def test_demo_split_reads_wav(tmp_path):
+    """Row f-4, host side: the demo split turns wav files into the sample dict of gesture_dataset.py:54-79 (mono float32 at
+    16 kHz, cropped to a whole number of 1/15 s frames, MAX_DEMO_LENGTH honoured)."""
+    from scipy.io import wavfile
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import get_dataset
+    from speechdrivestemplates_amd.core.datasets.gesture_dataset import load_speaker_stats
+    load_speaker_stats(os.path.join(GOLDEN, "speaker_stat_oliver.npz"), "oliver")
+    rng = np.random.default_rng(5)
+    a16 = (rng.standard_normal(16000 * 3 + 123) * 3000).astype(np.int16)           # 3.0077 s mono 16 kHz
+    a22 = (rng.standard_normal((22050 * 2, 2)) * 3000).astype(np.int16)             # 2 s stereo 22.05 kHz
+    long = (rng.standard_normal(16000 * 30) * 3000).astype(np.int16)                # 30 s > MAX_DEMO_LENGTH = 24 s
+    for name, sr, a in (("a.wav", 16000, a16), ("b.wav", 22050, a22), ("c.wav", 16000, long)):
+        wavfile.write(str(tmp_path / name), sr, a)
+    cfg = get_cfg_defaults()
+    ds = get_dataset("GestureDataset")("unused_root", "oliver", "demo", cfg,
+                                       demo_input=" ".join(str(tmp_path / n) for n in ("a.wav", "b.wav", "c.wav")))
+    assert len(ds) == 3
+    s = ds[0]
+    assert s["num_frames"] == int(len(a16) / (16000 / 15)) == 45 and len(s["audio"]) == int(45 * 16000 / 15) == 48000
+    np.testing.assert_array_equal(s["audio"], a16[:48000].astype(np.float32) / 32768.0)  # what librosa.load returns at 16 kHz
+    assert s["audio"].dtype == np.float32 and s["speaker"] == "oliver" and set(s["speaker_stat"]) == {"mean", "std", "scale_factor"}
+    s = ds[1]
+    # 2 s resampled to 32000 samples; parse_audio_length's float arithmetic gives int(32000 / (16000 / 15)) = 29 frames
+    assert s["num_frames"] == int(32000 / (16000 / 15)) == 29 and len(s["audio"]) == int(29 * (16000 / 15)) and np.abs(s["audio"]).max() < 1.0
+    s = ds[2]
+    assert s["num_frames"] == 360 and len(s["audio"]) == 384000  # cropped to 24 s
+    d = get_dataset("GestureDataset")("unused_root", "oliver", "demo", cfg, demo_input=str(tmp_path))
+    assert len(d) == 1  # a directory: DEMO.NUM_SAMPLES (=1) wav files of it
+    with pytest.raises(NotImplementedError):
+        get_dataset("GestureDataset")("unused_root", "oliver", "demo", cfg, demo_input="x.m4a")[0]

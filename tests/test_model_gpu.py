@@ -605,3 +605,37 @@ def test_pose2pose_epoch_loop_with_validation(tmp_path):
     saved = np.load(npz[0])
     assert saved["poses_pred_batch"].shape == (8, 64, 2, 121) and saved["poses_pred_batch"].dtype == np.float64
     assert len(glob.glob(os.path.join(str(tmp_path), "*p2p", "checkpoints", "*.pth"))) == 1
+
+
+def test_trainer_demo_loop_on_wav_files(tmp_path):
+    """Row f-4: Trainer.demo (trainer.py:459-484) on wav input -- variable-length inference through the trained generator with
+    the code interpolated between two training clips over DEMO.MULTIPLE passes (voice2pose.py:107-117,386-410)."""
+    from scipy.io import wavfile
+
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets.gesture_dataset import load_speaker_stats
+    from speechdrivestemplates_amd.core.pipelines import get_pipeline
+    load_speaker_stats(os.path.join(GOLDEN, "speaker_stat_oliver.npz"), "oliver")
+    pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+    pipe.base_path = str(tmp_path)
+    ckpt = pipe.save_checkpoint(1, 1)
+    rng = np.random.default_rng(2)
+    for name, secs in (("x.wav", 2.4), ("y.wav", 5.0)):
+        wavfile.write(str(tmp_path / name), 16000, (rng.standard_normal(int(16000 * secs)) * 2000).astype(np.int16))
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "voice2pose_sdt_bp.yaml"))
+    cfg.merge_from_list(["DATASET.SPEAKER", "oliver", "DEMO.MULTIPLE", 3, "DEMO.CODE_INDEX", 0, "DEMO.CODE_INDEX_B", 5,
+                         "SYS.OUTPUT_DIR", str(tmp_path), "TEST.SAVE_NPZ", True, "TEST.SAVE_VIDEO", False])
+    cfg.freeze()
+    demo = get_pipeline(cfg.PIPELINE_TYPE)(cfg)
+    outs = demo.demo("demo", ckpt, "%s %s" % (tmp_path / "x.wav", tmp_path / "y.wav"))
+    assert len(outs) == 2 * 3
+    T = [36, 36, 36, 75, 75, 75]
+    for o, t in zip(outs, T):
+        p = o["poses_pred_batch"]
+        assert p.shape == (1, t, 2, 121) and p.dtype == torch.float64 and torch.isfinite(p).all()
+    table = demo.model.clips_code.detach()
+    for i, coeff in enumerate((0.0, 0.5, 1.0)):  # the code is interpolated between rows 0 and 5 of the trained table
+        want = table[0] * (1 - coeff) + table[5] * coeff
+        assert torch.allclose(outs[i]["condition_code"][0], want, atol=1e-7)
+    assert not torch.equal(outs[0]["poses_pred_batch"], outs[2]["poses_pred_batch"])
