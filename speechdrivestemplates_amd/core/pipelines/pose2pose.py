@@ -1,5 +1,6 @@
 """Pose2Pose (pose-sequence VAE) pipeline on the gfx950 engine -- reference core/pipelines/pose2pose.py:20-169:
 L1 reconstruction + analytic KL on (mu, logvar), one Adam, per-clip code buffers written every step."""
+import numpy as np
 import torch
 from torch import nn
 
@@ -28,8 +29,13 @@ class Pose2PoseModel(nn.Module):
         dev = self.clip_code_mu.device
         poses_gt = batch['poses'].to(dev, non_blocking=True) if return_loss else None
         num_frames = int(batch['num_frames'][0])
-        if not return_loss:
-            raise NotImplementedError('Pose2Pose demo decoding from DEMO.CODE_PATH is not part of the training hot path')
+        if not return_loss:  # decode one stored code, picked by the interpolation coefficient (pose2pose.py:50-63)
+            assert self.cfg.DEMO.CODE_PATH is not None
+            idx = int((self.cfg.DEMO.MULTIPLE - 1) * interpolation_coeff)
+            code = np.load(self.cfg.DEMO.CODE_PATH)['v'][idx] * 10  # "10 is empirically selected" (the reference's words)
+            code = torch.tensor(np.asarray(code), dtype=torch.float32, device=dev).unsqueeze(0)
+            pred, mu, logvar = self.ae(None, self.cfg.DATASET.NUM_FRAMES, external_code=code)
+            return {'poses_pred_batch': pred, 'clip_code_mu': mu, 'clip_code_logvar': logvar}
         # the reference computes the mel spectrogram here and discards it (pose2pose.py:48, autoencoder.py:79); skipped
         pred, mu, logvar = self.ae(poses_gt, num_frames)
         reg = ops.L1LossFn.apply(pred, poses_gt, float(self.cfg.POSE2POSE.LAMBDA_REG))
@@ -117,3 +123,15 @@ class Pose2Pose(Trainer):
                 self.save_results(tag, t_step, epoch, self.base_path,
                                   {k: v.detach().cpu().numpy() for k, v in results.items() if torch.is_tensor(v)})
         return {k: v.detach() * self.cfg.TEST.BATCH_SIZE for k, v in losses.items()}, {}
+
+
+    @torch.no_grad()
+    def demo_step(self, batch, t_step=0, epoch=0, extra_id=None, interpolation_coeff=None):
+        """Decode a stored clip code into a pose sequence (pose2pose.py:219-244) without the video writer."""
+        self.model.eval()
+        results = self.model(batch, return_loss=False, interpolation_coeff=interpolation_coeff)
+        results['poses_pred_batch'] = self.test_dataset.get_final_results(results['poses_pred_batch'].detach(), batch['speaker_stat'])
+        if self.is_master_process() and self.cfg.TEST.SAVE_NPZ and self.base_path is not None:
+            self.save_results('DEMO', t_step, epoch, self.base_path,
+                              {k: v.detach().cpu().numpy() for k, v in results.items() if torch.is_tensor(v)}, extra_id=extra_id)
+        return results

@@ -639,3 +639,34 @@ def test_trainer_demo_loop_on_wav_files(tmp_path):
         want = table[0] * (1 - coeff) + table[5] * coeff
         assert torch.allclose(outs[i]["condition_code"][0], want, atol=1e-7)
     assert not torch.equal(outs[0]["poses_pred_batch"], outs[2]["poses_pred_batch"])
+
+
+def test_pose2pose_demo_decodes_stored_codes(tmp_path):
+    """Config 5's demo path (pose2pose.py:50-63,219-244): decode codes stored in DEMO.CODE_PATH; checked against the oracle's
+    decoder on the same weights."""
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
+    from speechdrivestemplates_amd.core.pipelines import get_pipeline
+    codes = np.random.default_rng(4).standard_normal((3, 32)).astype(np.float32) * 0.1
+    np.savez(str(tmp_path / "codes.npz"), v=codes)
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "pose2pose.yaml"))
+    cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DATASET.SYNTHETIC_CLIPS", 8, "DEMO.MULTIPLE", 3,
+                         "DEMO.CODE_PATH", str(tmp_path / "codes.npz"), "TEST.SAVE_NPZ", False])
+    cfg.freeze()
+    pipe = get_pipeline(cfg.PIPELINE_TYPE)(cfg)
+    ocfg = O.cfg_named("pose2pose")
+    st = O.make_pose2pose_state(ocfg, 8, seed=0)
+    st["mel_transfm.spectrogram.window"], st["mel_transfm.mel_scale.fb"] = O.mel_window(), O.mel_filterbank()
+    pipe.setup_model(cfg, state_dict={"module." + k: v for k, v in st.items()})
+    pipe.test_dataset = gd.SyntheticGestureDataset(cfg=cfg, num_clips=8, split="val")
+    batch = torch.utils.data.default_collate([pipe.test_dataset[0]])
+    pipe.model.eval()
+    for i, coeff in enumerate((0.0, 0.5, 1.0)):
+        out = pipe.demo_step(batch, 1, extra_id=i, interpolation_coeff=coeff)
+        assert out["poses_pred_batch"].shape == (1, 64, 2, 121) and out["poses_pred_batch"].dtype == torch.float64
+        code = torch.from_numpy(codes[int(2 * coeff)] * 10).unsqueeze(0)
+        assert torch.allclose(out["clip_code_mu"].cpu(), code)
+        ref = O.pose_seq_decoder(st, "ae.decoder", code, ocfg, False).permute(0, 2, 1).reshape(1, 64, 2, 121)
+        fin = pipe.test_dataset.get_final_results(ref, batch["speaker_stat"])
+        check("pose2pose demo decode vs oracle", out["poses_pred_batch"], fin, 5e-4)
