@@ -103,7 +103,6 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: capture the side streams too (experiment)")
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
-    ap.add_argument("--overlap-dx", action="store_true", help="parity classes of strided input gradients on alternating streams (measured: no gain)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     args = ap.parse_args()
 
@@ -125,7 +124,6 @@ def main():
     from speechdrivestemplates_amd import ops
     B = args.batch
     ops.OVERLAP_DW = not args.no_overlap_dw
-    ops.OVERLAP_DX = bool(args.overlap_dx)
     ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
     ops.OVERLAP_AUX = not args.no_overlap_aux
     ops.set_conv_math(args.conv_math)

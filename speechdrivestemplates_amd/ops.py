@@ -393,31 +393,14 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
     if all(g is not None for g, _ in geoms):
         k = max(_splitk_hint(lib, g) for g, _ in geoms)
     part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
-    # The parity classes of a strided input gradient write disjoint elements of dx: big 2-D ones alternate between the
-    # main stream and a second side stream so that each launch's tail (4.14 workgroups per CU on the deep layers) is
-    # filled by its neighbour.
-    spread = (OVERLAP_DX and not one_d and k == 1 and len(geoms) > 1 and not torch.cuda.is_current_stream_capturing()
-              and 2.0 * gy4.numel() * Cin * kh * kw / len(geoms) >= OVERLAP_DW_MIN_FLOPS / 2)
-    main = torch.cuda.current_stream()
-    if spread:
-        side = _side_stream(1)
-        side.wait_stream(main)
-    for i, (g, (py, px)) in enumerate(geoms):
+    # (launching the parity classes of a big strided 2-D gradient on alternating streams was measured: 3784 vs 3816 clips/s,
+    #  no gain on top of the weight-gradient side stream)
+    for g, (py, px) in geoms:
         if g is None:  # parity class that no tap reaches: the gradient is zero there
             dx[:, py::(1 if one_d else stride), px::stride].zero_()
             continue
-        if spread and i % 2 == 1:
-            with torch.cuda.stream(side):
-                _conv_launch("dX", not one_d, g,
-                             lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), _stream()))
-        else:
-            _conv_launch("dX", not one_d, g,
-                         lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), st))
-    if spread:
-        main.wait_stream(side)
-        gy4.record_stream(side)
-        wt.record_stream(side)
-        dx.record_stream(side)
+        _conv_launch("dX", not one_d, g,
+                     lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), st))
     if k > 1:  # every dX element belongs to exactly one parity class, so each slab is fully written
         check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
     return dx.squeeze(1) if one_d else dx
@@ -443,8 +426,6 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
 # optimiser step.
 OVERLAP_DW = True
 OVERLAP_DW_MIN_FLOPS = 4e9
-OVERLAP_DX = False  # parity classes of a big strided 2-D input gradient on alternating streams: measured 3784 vs 3816
-                    # clips/s (no gain on top of the weight-gradient side stream) -> off
 _SIDE = {}
 
 
