@@ -1,0 +1,25 @@
+/* Plain-C consumer of include/sdt_hip.h: proves the boundary is a C ABI (no C++ / torch types in the signatures).
+ * Runs without a GPU: only the argument-validation paths are exercised (they return before any launch). */
+#include <stdio.h>
+#include <string.h>
+
+#include "sdt_hip.h"
+
+int main(void) {
+    sdt_conv_geom g;
+    int rc;
+    memset(&g, 0, sizeof g);
+    if (sdt_abi_version() != 1) return 10;
+    if (sizeof(sdt_conv_geom) != (17 + 3 * SDT_MAX_TAPS) * sizeof(int32_t)) return 11;
+    if (sizeof(sdt_wt_desc) != 2 * sizeof(void*) + 4 * sizeof(int32_t)) return 12;
+    rc = sdt_conv_taps_f32(NULL, NULL, NULL, NULL, &g, NULL); /* zero geometry -> argument error, message set */
+    if (rc != SDT_ERR_ARG || strlen(sdt_last_error()) == 0) return 13;
+    printf("last error: %s\n", sdt_last_error());
+    rc = sdt_adam_step_f32(NULL, NULL, NULL, NULL, 0, NULL, 0.9f, 0.999f, 1e-8f, 0.f, 1.f, NULL, NULL);
+    if (rc != SDT_ERR_ARG) return 14;
+    if (sdt_set_conv_math(42) != SDT_ERR_ARG || sdt_get_conv_math() != SDT_MATH_F32) return 15;
+    if (sdt_set_conv_math(SDT_MATH_BF16) != SDT_OK || sdt_get_conv_math() != SDT_MATH_BF16) return 16;
+    if (sdt_set_conv_math(SDT_MATH_F32) != SDT_OK) return 17;
+    puts("C ABI OK");
+    return 0;
+}
