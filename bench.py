@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: capture the side streams too (experiment)")
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
+    ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     args = ap.parse_args()
 
@@ -124,6 +125,7 @@ def main():
     from speechdrivestemplates_amd import ops
     B = args.batch
     ops.OVERLAP_DW = not args.no_overlap_dw
+    ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
     ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
     ops.OVERLAP_AUX = not args.no_overlap_aux
     ops.set_conv_math(args.conv_math)

@@ -50,6 +50,13 @@ typedef struct sdt_conv_geom {
 /* nn.Conv2d / nn.Conv1d forward and input-gradient (building_blocks.py:15-22,31-38; ATen conv). */
 int sdt_conv_taps_f32(const float* x, const float* w, const float* bias, float* y,
                       const sdt_conv_geom* g, void* stream);
+/* The same forward conv with the statistics pass of the normalisation that follows fused into its epilogue:
+ * stats[(g * Cout + n) * 2 + {0,1}] += sum / sum of squares of Y[., n] over the output rows m (= (b*Ho+oy)*Wo+ox) with
+ * m / rows_per_group == g (InstanceNorm2d: rows_per_group = Ho*Wo; BatchNorm: B*Ho*Wo).  stats must be zero on entry.
+ * sdt_conv_taps_stats_supported: 1 if the geometry qualifies (dense output, Cin % 32 == 0, no split-K, fp32 math). */
+int sdt_conv_taps_stats_supported(const sdt_conv_geom* g, int rows_per_group);
+int sdt_conv_taps_stats_f32(const float* x, const float* w, const float* bias, float* y, const sdt_conv_geom* g,
+                            double* stats, int rows_per_group, void* stream);
 /* Split-K form for launches with too few output tiles to fill the chip (the 1-D stage): slice z of `splitk`
  * writes its partial sums to partial + z*numel(Y) (no bias); after ALL launches that share the Y tensor (the parity
  * classes of an input-gradient) sdt_splitk_reduce_f32 sums the slabs in a fixed order (deterministic) and adds bias.
@@ -99,6 +106,7 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
  * dirty -- callers carve it from a region zeroed once per step instead of paying a memset per layer).
  * num_batches_tracked (nullable) is the
  * BatchNorm int64 counter, incremented on the device.  gamma/beta/running_* may be NULL (IN).
+ * stats_ready != 0: sums already holds sum(y), sum(y^2) per (g, c) (sdt_conv_taps_stats_f32) -- the statistics pass is skipped.
  * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
  * momentum (unbiased variance), as nn.BatchNorm does in training mode.
  * eval: z = act(gamma*(y-running_mean)/sqrt(running_var+eps)+beta).
@@ -106,7 +114,7 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
 int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                        float slope, void* stream);
+                        float slope, int stats_ready, void* stream);
 int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
                          int64_t rows, int C, float eps, float slope, void* stream);

@@ -41,7 +41,9 @@ SIGNATURES = {
     "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],
     "sdt_set_conv_math": [_i],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
-    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _p],
+    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p],
+    "sdt_conv_taps_stats_supported": [_G, _i],
+    "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p],
     "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],

@@ -54,6 +54,16 @@ class ConvNormRelu(nn.Module):
                                        n.num_batches_tracked, 1, self.slope)
         if self.norm_type == 'IN' and self.conv_type == '1d':  # conv (+ split-K reduction) + norm over C + activation
             return ops.ConvRowNormFn.apply(x_cl, self.conv.weight, self.stride, self.padding, self.slope)
+        if self.conv_type == '2d' and (self.norm_type == 'IN' or self.training):
+            groups = x_cl.shape[0] if self.norm_type == 'IN' else 1
+            if ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups):
+                # the conv's epilogue accumulates the normalisation statistics: y is not re-read for them
+                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups)
+                n = self.norm
+                if self.norm_type == 'IN':
+                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums)
+                return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
+                                              self.slope, sums)
         y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W

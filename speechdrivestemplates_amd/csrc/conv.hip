@@ -21,11 +21,16 @@
 #define SDT_OOB 0x80000000u
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, bool VEC4, int PRIO = 0>
+// STATS: the epilogue also accumulates sum(y) and sum(y^2) per (group, output channel) into ``stats`` (fp64 atomics; the
+// buffer must be zero on entry), group = output row index / rows_per_group -- the statistics pass of the InstanceNorm2d /
+// BatchNorm that follows (sdt_colnorm_fwd_f32 with stats_ready = 1) then never reads y.  rows_per_group >= BM, so a tile
+// touches at most two groups.
+template <int BM, int BN, bool VEC4, int PRIO = 0, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         const sdt_conv_geom g, const int splitk,
-                                                        float* __restrict__ partial, const size_t ysize) {
+                                                        float* __restrict__ partial, const size_t ysize,
+                                                        double* __restrict__ stats = nullptr, const int rows_per_group = 0) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;
     __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
@@ -268,6 +273,38 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int off = sOut[row];
                 if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
+            }
+            if constexpr (STATS) {
+                const int g0 = m0 / rows_per_group;
+                const int mb = (g0 + 1) * rows_per_group;  // first row of the next group
+                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (sOut[row] >= 0 && nok) {
+                        const float v = acc[tm][tn][r] + bv;
+                        if (m0 + row < mb) {
+                            s0 += v;
+                            q0 = fmaf(v, v, q0);
+                        } else {
+                            s1 += v;
+                            q1 = fmaf(v, v, q1);
+                        }
+                    }
+                }
+                s0 += __shfl_xor(s0, 32, 64);  // the two lane halves hold different rows of the same column
+                q0 += __shfl_xor(q0, 32, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                q1 += __shfl_xor(q1, 32, 64);
+                if (lane < 32 && nok) {
+                    double* d = stats + ((size_t)g0 * g.Cout + n) * 2;
+                    atomicAdd(d, (double)s0);
+                    atomicAdd(d + 1, (double)q0);
+                    if (mb < m0 + BM && mb < M) {
+                        atomicAdd(d + 2 * (size_t)g.Cout, (double)s1);
+                        atomicAdd(d + 2 * (size_t)g.Cout + 1, (double)q1);
+                    }
+                }
             }
         }
 }
@@ -1114,6 +1151,30 @@ extern "C" int sdt_conv_taps_splitk_f32(const float* x, const float* w, const fl
         case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
         default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
     }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+// Forward conv + per-(group, channel) sum / sum-of-squares of its output in the epilogue (64x64 tile, vector path, fp32 math).
+extern "C" int sdt_conv_taps_stats_supported(const sdt_conv_geom* g, int rows_per_group) {
+    if (!g || check_geom(g) || rows_per_group < 64) return 0;
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    return (g->Cin % BK == 0) && g_conv_math == SDT_MATH_F32 && M % rows_per_group == 0 &&
+           sdt_conv_taps_splitk_hint(g) == 1 && g->osy == 1 && g->osx == 1 && g->ooy == 0 && g->oox == 0 && g->Hy == g->Ho &&
+           g->Wy == g->Wo;
+}
+extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const float* bias, float* y, const sdt_conv_geom* g,
+                                       double* stats, int rows_per_group, void* stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    SDT_CHECK_ARG(x && w && y && stats, "null pointer");
+    SDT_CHECK_ARG(sdt_conv_taps_stats_supported(g, rows_per_group), "geometry not supported by the fused-statistics epilogue");
+    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w) % 16) == 0, "x and w must be 16-byte aligned");
+    const int M = g->B * g->Ho * g->Wo;
+    const size_t ysize = (size_t)g->B * g->Hy * g->Wy * g->Cout;
+    dim3 grid(cdiv(M, 64) * cdiv(g->Cout, 64), 1, 1);
+    hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
+                       (float*)nullptr, ysize, stats, rows_per_group);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -288,15 +288,16 @@ static int check_colnorm(int G, int64_t R, int C) {
 extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                                   float slope, void* stream) {
+                                   float slope, int stats_ready, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int rpb = colnorm_rows_per_block(C, G, R);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rpb);
+    if (!stats_ready)  // otherwise the producing conv's epilogue already accumulated them (sdt_conv_taps_stats_f32)
+        hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rpb);
     hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
                        running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope);
     SDT_LAUNCH_CHECK();

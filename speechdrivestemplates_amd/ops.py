@@ -300,6 +300,7 @@ def conv_forward(x_cl, w, bias, stride, pad):
 
 
 CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+_CONV_MATH_NOW = [0]  # mirror of the library's process-wide setting (only set_conv_math changes it)
 
 
 def set_conv_math(mode):
@@ -308,6 +309,7 @@ def set_conv_math(mode):
     lib = _lib.load()
     prev = lib.sdt_get_conv_math()
     check(lib.sdt_set_conv_math(CONV_MATH[mode]))
+    _CONV_MATH_NOW[0] = CONV_MATH[mode]
     return {v: k for k, v in CONV_MATH.items()}[prev]
 
 
@@ -519,6 +521,50 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx):
     return conv_input_grad(gy, w, x_cl.shape, stride, pad) if need_dx else None
 
 
+class ConvStatsFn(torch.autograd.Function):
+    """Bias-free forward conv whose epilogue also accumulates the per-(group, channel) sum / sum of squares of its output
+    (sdt_conv_taps_stats_f32) -- the statistics pass of the InstanceNorm2d / BatchNorm that follows.  Returns (y, sums);
+    ``sums`` goes to ColNormActFn(..., sums).  Use only when ``conv_stats_fusable`` says so."""
+
+    @staticmethod
+    def forward(ctx, x_cl, w, stride, pad, groups):
+        _req_cuda(x_cl, w)
+        lib = _lib.load()
+        x_cl = x_cl.contiguous()
+        g = conv_geom_for(x_cl.shape, w, stride, pad)
+        y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
+        sums = _ARENA.take(2 * groups * g.Cout, x_cl.device)
+        rpg = g.B * g.Ho * g.Wo // groups
+        ws, st = weight_storage(w), _stream()
+        _conv_launch("fwd", True, g, lambda: lib.sdt_conv_taps_stats_f32(_p(x_cl), _p(ws), None, _p(y), g, _p(sums), rpg, st))
+        ctx.save_for_backward(x_cl, w)
+        ctx.stride, ctx.pad = stride, pad
+        ctx.mark_non_differentiable(sums)
+        return y, sums
+
+    @staticmethod
+    def backward(ctx, gy, _gsums):
+        x_cl, w = ctx.saved_tensors
+        return _conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0]), None, None, None, None
+
+
+def conv_stats_fusable(x_cl, w, stride, pad, groups):
+    """True when the conv + column-norm pair can use the fused-statistics epilogue (2-D, dense geometry, Cin % 32 == 0, exact
+    fp32 math, no split-K, groups dividing the batch)."""
+    if x_cl.dim() != 4 or w.dim() != 4 or PROFILER_NO_FUSION:
+        return False
+    g = conv_geom_for(x_cl.shape, w, stride, pad)
+    key = (groups, _CONV_MATH_NOW[0])  # the library's answer depends on the product arithmetic in force
+    ok = getattr(g, "_stats_ok", None)
+    if ok is None or ok[0] != key:
+        m = g.B * g.Ho * g.Wo
+        ok = g._stats_ok = (key, bool(m % groups == 0 and _lib.load().sdt_conv_taps_stats_supported(g, m // groups)))
+    return ok[1]
+
+
+PROFILER_NO_FUSION = False  # experiments: force the unfused conv -> colstats -> apply sequence
+
+
 class ConvRowNormFn(torch.autograd.Function):
     """ConvNormRelu('1d', norm='IN') in one autograd node (building_blocks.py:31-51): Conv1d (no bias) -> per-(b,t) norm
     over channels -> LeakyReLU.  When the conv is K-split (the 1-D stage: too few output tiles for 256 CUs) the slab
@@ -568,18 +614,20 @@ class ColNormActFn(torch.autograd.Function):
     """InstanceNorm2d (groups = batch) or training-mode BatchNorm (groups = 1) + LeakyReLU/ReLU."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope):
+    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None):
         _req_cuda(y)
         lib = _lib.load()
         y = y.contiguous()
         C = y.shape[-1]
         R = y.numel() // C // groups
         z = torch.empty_like(y)
-        sums = _ARENA.take(2 * groups * C, y.device)
+        ready = sums is not None  # accumulated by the producing conv's epilogue (ConvStatsFn)
+        if not ready:
+            sums = _ARENA.take(2 * groups * C, y.device)
         mean = torch.empty(groups * C, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
-                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, _stream()))
+                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _stream()))
         ctx.save_for_backward(y, mean, rstd, gamma, beta)
         ctx.groups, ctx.slope = groups, slope
         return z
@@ -597,7 +645,7 @@ class ColNormActFn(torch.autograd.Function):
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
         check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
                                       ctx.groups, R, C, ctx.slope, _stream()))
-        return dy, None, None, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None, None
 
 
 class L0BlockFn(torch.autograd.Function):

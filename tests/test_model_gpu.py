@@ -397,7 +397,8 @@ def test_conv_math_modes_train_steps(golden_traj, mode, tol_pred, tol_loss):
 def test_full_size_step_properties_b32():
     """BASELINE config 2/3 size (32 clips per GPU), where the CPU oracle takes minutes: size-independent properties of the
     per-sample-normalised sdt generator and its L1 loss instead --
-      * permuting the clips of a batch permutes the predictions (no cross-sample arithmetic in the generator);
+      * permuting the clips of a batch permutes the predictions (no cross-sample arithmetic in the generator), up to fp32
+        summation order;
       * the gradient of a 32-clip batch is the mean of the gradients of its two 16-clip halves (what data parallelism
         relies on), up to fp32 summation noise."""
     def sub(batch, idx):
@@ -425,7 +426,9 @@ def test_full_size_step_properties_b32():
     g_full, pred_full, l_full = grads_of(full)
     perm = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).permutation(32))
     _, pred_perm, l_perm = grads_of(sub(full, perm))
-    check("B=32 permutation equivariance", pred_perm, pred_full[perm.to(pred_full.device)], 2e-6)
+    # not bit-for-bit: the InstanceNorm statistics come from the conv epilogue, whose fp32 partial sums depend on how a clip's
+    # rows fall onto the 64-row tiles (its position in the batch); measured 2e-6
+    check("B=32 permutation equivariance", pred_perm, pred_full[perm.to(pred_full.device)], 1e-5)
     assert abs(l_perm - l_full) <= 1e-6 * abs(l_full)
     g_a, _, l_a = grads_of(sub(full, torch.arange(0, 16)))
     g_b, _, l_b = grads_of(sub(full, torch.arange(16, 32)))
@@ -459,8 +462,11 @@ def test_hipgraph_replay_matches_eager():
         runs.append((hist, pipe.model.netG.decoder[4].weight.detach().clone(), int(pipe.optimizers["optimizerG"].state_dev[0])))
     (h0, w0, s0), (h1, w1, s1) = runs
     assert s0 == s1 == 4
-    for (a, b), (c, d) in zip(h0, h1):
-        assert abs(a - c) <= 2e-5 * abs(a) and abs(b - d) <= 2e-5 * abs(b), (h0, h1)
+    for i, ((a, b), (c, d)) in enumerate(zip(h0, h1)):
+        # step 0 sees identical weights (atomics order only); later steps sit behind Adam updates that turn last-bit
+        # gradient differences into lr-sized weight differences
+        tol = 2e-5 if i == 0 else 2e-4
+        assert abs(a - c) <= tol * abs(a) and abs(b - d) <= tol * abs(b), (h0, h1)
     # weight-gradient atomics make the two runs differ in the last bits; Adam's sign-like early steps amplify that to at
     # most 2*lr per step and element
     assert (w1 - w0).abs().max().item() <= 2 * 1e-4 * 4
