@@ -21,11 +21,12 @@
 #define SDT_OOB 0x80000000u
 
 // ---------------------------------------------------------------------------------------------
-// STATS: the epilogue also accumulates sum(y) and sum(y^2) per (group, output channel) into ``stats`` (fp64 atomics; the
-// buffer must be zero on entry), group = output row index / rows_per_group -- the statistics pass of the InstanceNorm2d /
-// BatchNorm that follows (sdt_colnorm_fwd_f32 with stats_ready = 1) then never reads y.  rows_per_group >= BM, so a tile
-// touches at most two groups.
-template <int BM, int BN, bool VEC4, int PRIO = 0, bool STATS = false>
+// stats != nullptr: the epilogue also accumulates sum(y) and sum(y^2) per (group, output channel) into ``stats`` (fp64
+// atomics; the buffer must be zero on entry), group = output row index / rows_per_group -- the statistics pass of the
+// InstanceNorm2d / BatchNorm that follows (sdt_colnorm_fwd_f32 with stats_ready = 1) then never reads y.
+// rows_per_group >= BM, so a tile touches at most two groups.  (A run-time switch, not a template argument: one kernel
+// symbol for every forward / input-gradient launch; the branch is uniform and outside the K loop.)
+template <int BM, int BN, bool VEC4, int PRIO = 0>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         const sdt_conv_geom g, const int splitk,
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 const int off = sOut[row];
                 if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
             }
-            if constexpr (STATS) {
+            if (stats != nullptr) {
                 const int g0 = m0 / rows_per_group;
                 const int mb = (g0 + 1) * rows_per_group;  // first row of the next group
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
@@ -1173,7 +1174,7 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
     const int M = g->B * g->Ho * g->Wo;
     const size_t ysize = (size_t)g->B * g->Hy * g->Wy * g->Cout;
     dim3 grid(cdiv(M, 64) * cdiv(g->Cout, 64), 1, 1);
-    hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
+    hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
                        (float*)nullptr, ysize, stats, rows_per_group);
     SDT_LAUNCH_CHECK();
     return SDT_OK;

@@ -231,9 +231,10 @@ class ConvProfiler:
     @staticmethod
     def kernel_name(kind, variant):
         bm, bn, vec = variant // 10 // 1000, variant // 10 % 1000, variant % 10
-        if kind == "dW":
-            return "conv_dw_kernel<%d, %d, %s>" % (bm, bn, "true" if vec else "false")
-        # as rocprofv3 prints it: the 4th template argument is the (experiment-only) priority/ablation mode, 0 in production
+        # names as rocprofv3 prints them (template arguments included)
+        if kind == "dW":  # last argument: product arithmetic (0 = exact fp32)
+            return "conv_dw_kernel<%d, %d, %s, 0>" % (bm, bn, "true" if vec else "false")
+        # 4th argument: experiment-only priority/ablation mode (0 in production)
         return "conv_taps_kernel<%d, %d, %s, 0>" % (bm, bn, "true" if vec else "false")
 
     def summary(self):
