@@ -156,10 +156,14 @@ class Trainer(object):
         return path
 
     def save_results(self, tag, step, epoch, base_path, results_dict, extra_id=None):
+        """<base>/results/epoch<E>-<TAG>-step<S>[-<extra>].npz, the reference's naming (voice2pose.py:461-477)."""
         d = os.path.join(base_path, 'results')
         os.makedirs(d, exist_ok=True)
-        np.savez(os.path.join(d, '%s_epoch-%d_step-%d%s.npz' % (tag, epoch, step, '' if extra_id is None else '_%s' % extra_id)),
-                 **results_dict)
+        path = '%s/epoch%d-%s-step%s.npz' % (d, epoch, tag, step) if extra_id is None \
+            else '%s/epoch%d-%s-step%s-%d.npz' % (d, epoch, tag, step, extra_id)
+        if os.path.exists(path):
+            os.remove(path)
+        np.savez(path, **results_dict)
 
     # -- logging (trainer.py:242-263) --------------------------------------------------------------------
     def logger_writer_step(self, tag, losses, step, epoch=None, global_step=None):

@@ -606,7 +606,7 @@ def test_pose2pose_epoch_loop_with_validation(tmp_path):
     for k in ("reg_loss", "kl_loss", "loss", "L2_dist", "lip_sync_error_n", "L2_dist_min", "L2_dist_max"):
         assert k in out and np.isfinite(float(out[k])), (k, out)
     assert float(out["L2_dist_min"]) <= float(out["L2_dist_max"])
-    npz = glob.glob(os.path.join(str(tmp_path), "*p2p", "results", "VAL_*.npz"))
+    npz = glob.glob(os.path.join(str(tmp_path), "*p2p", "results", "epoch1-VAL-step*.npz"))  # the reference's file naming
     assert npz, "validation results were not saved"
     saved = np.load(npz[0])
     assert saved["poses_pred_batch"].shape == (8, 64, 2, 121) and saved["poses_pred_batch"].dtype == np.float64
