@@ -141,10 +141,21 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     unsigned aoff[RA], boff[RB];
     int cur_tl = -1;
     f32x4 ra[RA], rb[RB];
+    // (tap, channel-chunk) of the next step to load: steps are requested consecutively, so the pair is advanced
+    // incrementally instead of dividing step by nkc in every K step
+    int nxt_tl = step0 / nkc, nxt_kc = step0 - nxt_tl * nkc;
     auto load = [&](int step) {
         if constexpr (VEC4) {
-            const int tl = step / nkc;
-            const unsigned cb = (unsigned)((step - tl * nkc) * BK + kv * 4) * 4u;
+            int tl, kc;
+            if constexpr (PRIO == 11) {  // A/B: the division form
+                tl = step / nkc;
+                kc = step - tl * nkc;
+            } else {
+                tl = nxt_tl;
+                kc = nxt_kc;
+                if (++nxt_kc == nkc) nxt_kc = 0, ++nxt_tl;
+            }
+            const unsigned cb = (unsigned)(kc * BK + kv * 4) * 4u;
             if (tl != cur_tl) {
                 cur_tl = tl;
                 const int t = sLive[tl];
