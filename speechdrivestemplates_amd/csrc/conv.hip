@@ -138,7 +138,14 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     // only when the tap changes (every Cin/32 steps).
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)g.Cout * g.Tw * g.Cin * 4u), 0x00020000);
-    unsigned aoff[RA], boff[RB];
+    unsigned aoff[RA], boff[RB], abase[RA], bbase[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) abase[i] = (unsigned)(((rbH[i] + riy[i]) * g.Wi + rix[i]) * g.Cin) * 4u;  // tap (0,0); masked rows never use it
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        bbase[i] = n < g.Cout ? (unsigned)(n * g.Tw * g.Cin) * 4u : SDT_OOB;
+    }
     int cur_tl = -1;
     f32x4 ra[RA], rb[RB];
     // (tap, channel-chunk) of the next step to load: steps are requested consecutively, so the pair is advanced
@@ -160,16 +167,27 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 cur_tl = tl;
                 const int t = sLive[tl];
                 const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+                if constexpr (PRIO == 11) {  // A/B: offsets rebuilt from scratch
 #pragma unroll
-                for (int i = 0; i < RA; ++i) {
-                    const int iy = riy[i] + dy, ix = rix[i] + dx;
-                    const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                    aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
-                }
+                    for (int i = 0; i < RA; ++i) {
+                        const int iy = riy[i] + dy, ix = rix[i] + dx;
+                        const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                        aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
+                    }
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int n = n0 + r0 + 32 * i;
-                    boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
+                    for (int i = 0; i < RB; ++i) {
+                        const int n = n0 + r0 + 32 * i;
+                        boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
+                    }
+                } else {  // row bases are fixed for the tile: a tap only adds a uniform shift (and decides the mask)
+                    const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 4u, bshift = (unsigned)(wt * g.Cin) * 4u;
+#pragma unroll
+                    for (int i = 0; i < RA; ++i) {
+                        const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                        aoff[i] = ok ? abase[i] + ashift : SDT_OOB;
+                    }
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) boff[i] = bbase[i] == SDT_OOB ? SDT_OOB : bbase[i] + bshift;
                 }
             }
 #pragma unroll
