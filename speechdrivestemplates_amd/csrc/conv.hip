@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 if (++nxt_kc == nkc) nxt_kc = 0, ++nxt_tl;
             }
             const unsigned cb = (unsigned)(kc * BK + kv * 4) * 4u;
+            const int cs = kc * BK * 4;  // uniform part of cb: goes into the load's scalar offset operand
             if (tl != cur_tl) {
                 cur_tl = tl;
                 const int t = sLive[tl];
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                         boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
                     }
                 } else {  // row bases are fixed for the tile: a tap only adds a uniform shift (and decides the mask)
-                    const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 4u, bshift = (unsigned)(wt * g.Cin) * 4u;
+                    const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 4u + (unsigned)kv * 16u;
+                    const unsigned bshift = (unsigned)(wt * g.Cin) * 4u + (unsigned)kv * 16u;
 #pragma unroll
                     for (int i = 0; i < RA; ++i) {
                         const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
@@ -190,12 +192,21 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     for (int i = 0; i < RB; ++i) boff[i] = bbase[i] == SDT_OOB ? SDT_OOB : bbase[i] + bshift;
                 }
             }
+            if constexpr (PRIO == 11) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(aoff[i] + cb), 0, 0));
+                for (int i = 0; i < RA; ++i)
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(aoff[i] + cb), 0, 0));
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
-                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(boff[i] + cb), 0, 0));
+                for (int i = 0; i < RB; ++i)
+                    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(boff[i] + cb), 0, 0));
+            } else {  // per-lane part of the column offset lives in aoff/boff, the K-chunk part in the scalar operand
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)aoff[i], cs, 0));
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)boff[i], cs, 0));
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
