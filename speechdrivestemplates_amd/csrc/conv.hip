@@ -865,8 +865,8 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int n = n0 + 4 * nva;
             if constexpr (VEC4) {
-                // offY is a byte offset or SDT_OOB; SDT_OOB + SDT_OOB wraps to 0, so mask the sum explicitly
-                const unsigned o = ((unsigned)offY | colA) & SDT_OOB ? SDT_OOB : (unsigned)offY + colA;
+                // offY is a byte offset or SDT_OOB; SDT_OOB + SDT_OOB would wrap to 0, hence the saturating add
+                const unsigned o = __builtin_elementwise_add_sat((unsigned)offY, colA);  // saturating: OOB + OOB stays out of range
                 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)o, 0, 0));
                 (void)n;
             } else {
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (VEC4) {
                 const unsigned xo = (unsigned)bH;  // byte offset of the gathered X row for this block's tap, or SDT_OOB
-                const unsigned o = (xo | colB) & SDT_OOB ? SDT_OOB : xo + colB;
+                const unsigned o = __builtin_elementwise_add_sat(xo, colB);
                 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, 0, 0));
                 (void)iy0;
                 (void)ix0;
