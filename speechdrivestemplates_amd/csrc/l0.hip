@@ -244,41 +244,58 @@ __global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const float* __restric
     for (int i = tid; i < L0_C * L0_NSUM; i += 256) atomicAdd(&sums[(size_t)g * L0_C * L0_NSUM + i], sS[i]);
 }
 
-// thread = (channel, tap): dW[c][t] += sum_groups gamma*rstd*(T - S1/n*S_t - S2/n*Q_t); dgamma += S2, dbeta += S1 (BN)
-__global__ __launch_bounds__(64) void l0_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
-                                                             const float* __restrict__ w, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                             float* __restrict__ dW, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int B, int groups, double n_per_group) {
-    const int c = blockIdx.x, t = threadIdx.x;
-    if (t >= L0_T) return;
+// workgroup = channel, thread = (slice j of 32, tap t): dW[c][t] += sum_groups gamma*rstd*(T - S1/n*S_t - S2/n*Q_t);
+// dgamma += S2, dbeta += S1 (BN).  Groups (InstanceNorm) or batch items (BatchNorm moments) are spread over the 32 slices and
+// combined in slice order.
+__global__ __launch_bounds__(288) void l0_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
+                                                              const float* __restrict__ w, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              float* __restrict__ dW, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int B, int groups, double n_per_group) {
+    __shared__ double sA[32][L0_T], sB[32][L0_T];
+    const int c = blockIdx.x, j = threadIdx.x / L0_T, t = threadIdx.x % L0_T;
     double wv[L0_T];
     for (int u = 0; u < L0_T; ++u) wv[u] = (double)w[c * L0_T + u];
     const double ga = gamma ? (double)gamma[c] : 1.0;
-    double dw = 0.0;
-    for (int g = 0; g < groups; ++g) {
-        // moments of this group: first S_u and second R[u][t] (upper-triangular storage, index as in l0_moments_kernel)
-        double S_t = 0.0, wR = 0.0;
-        const int b0 = groups == 1 ? 0 : g, b1 = groups == 1 ? B : g + 1;
-        for (int b = b0; b < b1; ++b) {
-            const double* M = mom + (size_t)b * L0_NMOM;
-            S_t += M[t];
-            for (int u = 0; u < L0_T; ++u) {
-                const int lo = u < t ? u : t, hi = u < t ? t : u;
-                const int idx = L0_T + lo * L0_T - lo * (lo - 1) / 2 + (hi - lo);  // row lo starts after rows 0..lo-1 (9, 8, ... entries)
-                wR += wv[u] * M[idx];
-            }
+    // first / second moments of batch item b seen from tap t: S_t and sum_u w[c][u] R[u][t] (upper-triangular storage)
+    auto item = [&](int b, double& S_t, double& wR) {
+        const double* M = mom + (size_t)b * L0_NMOM;
+        S_t += M[t];
+        for (int u = 0; u < L0_T; ++u) {
+            const int lo = u < t ? u : t, hi = u < t ? t : u;
+            wR += wv[u] * M[L0_T + lo * L0_T - lo * (lo - 1) / 2 + (hi - lo)];
         }
+    };
+    auto term = [&](int g, double S_t, double wR) {
         const double mu = (double)mean[(size_t)g * L0_C + c], rs = (double)rstd[(size_t)g * L0_C + c];
         const double Q_t = rs * (wR - mu * S_t);
         const double* sg = sums + ((size_t)g * L0_C + c) * L0_NSUM;
-        dw += ga * rs * (sg[2 + t] - sg[0] / n_per_group * S_t - sg[1] / n_per_group * Q_t);
-        if (t == 0) {
+        return ga * rs * (sg[2 + t] - sg[0] / n_per_group * S_t - sg[1] / n_per_group * Q_t);
+    };
+    double a = 0.0, b2 = 0.0;
+    if (groups == 1) {  // BatchNorm: one group, its moments are the sum over the batch
+        for (int b = j; b < B; b += 32) item(b, a, b2);
+    } else {            // InstanceNorm: group g == batch item g
+        for (int g = j; g < groups; g += 32) {
+            double S_t = 0.0, wR = 0.0;
+            item(g, S_t, wR);
+            a += term(g, S_t, wR);
+        }
+    }
+    sA[j][t] = a;
+    sB[j][t] = b2;
+    __syncthreads();
+    if (j == 0) {
+        double x = 0.0, y = 0.0;
+        for (int i = 0; i < 32; ++i) x += sA[i][t], y += sB[i][t];
+        const double dw = groups == 1 ? term(0, x, y) : x;
+        dW[c * L0_T + t] += (float)dw;
+        if (t == 0 && groups == 1) {
+            const double* sg = sums + (size_t)c * L0_NSUM;
             if (dgamma) dgamma[c] += (float)sg[1];
             if (dbeta) dbeta[c] += (float)sg[0];
         }
     }
-    dW[c * L0_T + t] += (float)dw;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,7 +333,7 @@ extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const flo
     dim3 grid(cdiv(H, rpb), B);
     hipLaunchKernelGGL(l0_bwd_sums_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
-    hipLaunchKernelGGL(l0_bwd_finalize_kernel, dim3(L0_C), dim3(64), 0, s, sums, mom, w, mean, rstd, gamma, dw, dgamma, dbeta, B,
+    hipLaunchKernelGGL(l0_bwd_finalize_kernel, dim3(L0_C), dim3(288), 0, s, sums, mom, w, mean, rstd, gamma, dw, dgamma, dbeta, B,
                        groups, n);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
