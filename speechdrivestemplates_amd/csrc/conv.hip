@@ -1300,7 +1300,7 @@ extern "C" int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_
 
 extern "C" int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream) {
     SDT_CHECK_ARG(x && out && rows > 0 && c > 0, "bad argument");
-    const int rpb = 64;
+    const int rpb = rows >= 2048 ? 8 : 64;  // short dependent-load chains: ~256 workgroups on the head conv's (2048, 242) gradient
     hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)cdiv64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, rows, c, rpb);
     SDT_LAUNCH_CHECK();
     return SDT_OK;

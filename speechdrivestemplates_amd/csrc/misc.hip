@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
         const float wy = (yh == y0 ? 1.f - ly : 0.f) + (yh == y1 ? ly : 0.f);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (wy != 0.f) {
-            for (int t = 0; t < T; ++t) {
+            // only output frames whose source coordinate (t + 0.5) * sw - 0.5 lies within (xw - 1, xw + 1) can touch column
+            // xw; a generous window around them (the exact weights are re-derived inside) instead of all T frames
+            const int t_lo = max(0, (int)floorf(((float)xw - 0.5f) / sw - 0.5f) - 2);
+            const int t_hi = min(T - 1, (int)ceilf(((float)xw + 1.5f) / sw - 0.5f) + 2);
+            for (int t = t_lo; t <= t_hi; ++t) {
                 int x0, x1;
                 float lx;
                 src_index(sw, t, W, x0, x1, lx);
