@@ -642,34 +642,44 @@ __global__ __launch_bounds__(256) void conv_taps_bf_kernel(const float* __restri
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)g.Cout * g.Tw * g.Cin * 4u), 0x00020000);
-    unsigned aoff[RA], boff[RB];
+    // same lean loader as conv_taps_kernel: per-tile row bases + a uniform shift per tap, (tap, chunk) advanced
+    // incrementally, the K-chunk offset in the load's scalar operand
+    unsigned aoff[RA], boff[RB], abase[RA], bbase[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) abase[i] = (unsigned)(((rbH[i] + riy[i]) * g.Wi + rix[i]) * g.Cin) * 4u;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        bbase[i] = n < g.Cout ? (unsigned)(n * g.Tw * g.Cin) * 4u : SDT_OOB;
+    }
     int cur_tl = -1;
+    int nxt_tl = step0 / nkc, nxt_kc = step0 - nxt_tl * nkc;
     f32x4 ra[RA], rb[RB];
     auto load = [&](int step) {
-        const int tl = step / nkc;
-        const unsigned cb = (unsigned)((step - tl * nkc) * BK + kv * 4) * 4u;
+        (void)step;  // consecutive steps: the pair is carried
+        const int tl = nxt_tl, kc = nxt_kc;
+        if (++nxt_kc == nkc) nxt_kc = 0, ++nxt_tl;
+        const int cs = kc * BK * 4;
         if (tl != cur_tl) {
             cur_tl = tl;
             const int t = sLive[tl];
             const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
+            const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 4u + (unsigned)kv * 16u;
+            const unsigned bshift = (unsigned)(wt * g.Cin) * 4u + (unsigned)kv * 16u;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                const int iy = riy[i] + dy, ix = rix[i] + dx;
-                const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                aoff[i] = ok ? (unsigned)(((rbH[i] + iy) * g.Wi + ix) * g.Cin) * 4u : SDT_OOB;
+                const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                aoff[i] = ok ? abase[i] + ashift : SDT_OOB;
             }
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                boff[i] = n < g.Cout ? (unsigned)((n * g.Tw + wt) * g.Cin) * 4u : SDT_OOB;
-            }
+            for (int i = 0; i < RB; ++i) boff[i] = bbase[i] == SDT_OOB ? SDT_OOB : bbase[i] + bshift;
         }
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(aoff[i] + cb), 0, 0));
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)aoff[i], cs, 0));
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(boff[i] + cb), 0, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)boff[i], cs, 0));
     };
 
     f32x16 acc[TM][TN], accl[TM][TN];
