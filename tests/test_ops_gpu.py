@@ -490,3 +490,35 @@ def test_conv_full_size_properties(ops, case):
     y12 = ops.conv_forward(0.5 * x + x2, w, None, s, p)
     y2 = ops.conv_forward(x2, w, None, s, p)
     check(tag + " linearity", y12, 0.5 * y.double() + y2.double(), 1e-5)  # three fp32 roundings of K ~ 4096 products
+
+
+def test_flat_adam_resumes_from_a_torch_adam_state_dict(ops):
+    """Checkpoint wire format (trainer.py:313-319): '<optimizer>_state_dict' written by the reference's torch.optim.Adam loads into
+    FlatAdam (and back), and the next step agrees -- conv weights included, whose physical layout differs from the logical one."""
+    from speechdrivestemplates_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(31)
+    shapes = [(8, 6, 3, 3), (10, 8, 4), (10,), (5, 7)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g, dtype=torch.float64)) for s in shapes]
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-2)
+    grads = [[torch.randn(s, generator=g, dtype=torch.float64) for s in shapes] for _ in range(3)]
+    for p, gr in zip(ref_p, grads[0]):
+        p.grad = gr.clone()
+    ref_opt.step()  # the "checkpoint" is taken after one reference step
+    sd = ref_opt.state_dict()
+    mine_p = [torch.nn.Parameter(ops.to_weight_layout(p.detach().float().to(DEV)) if p.dim() >= 3 else p.detach().float().to(DEV)) for p in ref_p]
+    opt = FlatAdam(mine_p, lr=1e-2)
+    opt.load_state_dict(sd)
+    assert int(opt.state_dev[0]) == 1
+    for step in (1, 2):
+        for p, q, gr in zip(ref_p, mine_p, grads[step]):
+            p.grad = gr.clone()
+            q.grad.copy_(gr.float().to(DEV))
+        ref_opt.step()
+        opt.step()
+    for i, (p, q) in enumerate(zip(ref_p, mine_p)):
+        check("param %d after resume + 2 steps" % i, q, p, 2e-6)
+    back = opt.state_dict()  # and the other way: torch accepts what FlatAdam writes
+    chk = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in shapes], lr=1e-2)
+    chk.load_state_dict(back)
+    assert float(chk.state_dict()["state"][0]["step"]) == 3.0
+    check("exp_avg of the conv weight round-trips in logical layout", chk.state_dict()["state"][0]["exp_avg"], ref_opt.state_dict()["state"][0]["exp_avg"], 2e-6)
