@@ -522,3 +522,47 @@ def test_flat_adam_resumes_from_a_torch_adam_state_dict(ops):
     chk.load_state_dict(back)
     assert float(chk.state_dict()["state"][0]["step"]) == 3.0
     check("exp_avg of the conv weight round-trips in logical layout", chk.state_dict()["state"][0]["exp_avg"], ref_opt.state_dict()["state"][0]["exp_avg"], 2e-6)
+
+
+@pytest.mark.parametrize("norm,groups", [("IN", None), ("BN", 1)])
+def test_conv_epilogue_statistics_match_the_separate_pass(ops, norm, groups):
+    """sdt_conv_taps_stats_f32: the normalisation statistics accumulated by the conv epilogue give the same block output and
+    gradients as conv -> colstats -> apply (tiles straddling two clips, ragged last tile included), and the float64 reference."""
+    B, Hi, Wi, Cin, Cout = 3, 40, 61, 64, 128  # 3*2440 = 7320 rows: 114 full tiles + a ragged one, clip boundaries inside tiles
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) * (2.0 / (Cin * 9)) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, 1, 1)
+    z = F.leaky_relu(F.instance_norm(y, eps=1e-5) if norm == "IN" else F.batch_norm(y, None, None, training=True, eps=1e-5), 0.2)
+    gz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(gz)
+    outs = []
+    for fused in (True, False):
+        ops.PROFILER_NO_FUSION = not fused
+        try:
+            xd = ops.cl(x.float()).to(DEV).requires_grad_(True)
+            wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+            grp = B if norm == "IN" else 1
+            assert ops.conv_stats_fusable(xd, wd, 1, 1, grp) == fused
+            if fused:
+                yd, sums = ops.ConvStatsFn.apply(xd, wd, 1, 1, grp)
+                zd = ops.ColNormActFn.apply(yd, None, None, None, None, None, grp, 0.2, sums)
+            else:
+                zd = ops.ColNormActFn.apply(ops.ConvFn.apply(xd, wd, None, 1, 1), None, None, None, None, None, grp, 0.2)
+            zd.backward(ops.cl(gz.float()).to(DEV))
+            torch.cuda.synchronize()
+            outs.append((ops.cf_view(zd).detach().clone(), ops.cf_view(xd.grad).clone(), wd.grad.clone()))
+        finally:
+            ops.PROFILER_NO_FUSION = False
+    check(norm + " fused block fwd vs float64", outs[0][0], z, 2e-5)
+    check(norm + " fused vs separate statistics", outs[0][0], outs[1][0], 2e-6)
+
+    def l2(got, ref):  # an fp32 pre-activation within rounding of the LeakyReLU kink flips one derivative: compare in L2
+        got, ref = got.double().cpu(), ref.double().cpu()
+        return ((got - ref).norm() / ref.norm()).item()
+
+    for name, i, ref in (("dX", 1, xr.grad), ("dW", 2, wr.grad)):
+        e64, esep = l2(outs[0][i], ref), l2(outs[0][i], outs[1][i])
+        print("  %s fused block %s: L2 error vs float64 %.2e, vs separate pass %.2e" % (norm, name, e64, esep))
+        assert e64 < 3e-3 and esep < 1e-5, (name, e64, esep)  # the kink flips are shared by both fp32 paths
