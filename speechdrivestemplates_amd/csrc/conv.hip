@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
     __shared__ int sOut[BM];
     __shared__ int sTap[3 * SDT_MAX_TAPS];
-    __shared__ int sLive[SDT_MAX_TAPS + 1];  // taps that reach at least one in-range input for this tile; [MAX] = count
+    __shared__ int sLive[SDT_MAX_TAPS + 1];  // flags, then the ordered list of the taps that reach at least one in-range input for this tile; [MAX] = count
+    __shared__ int sFlag[SDT_MAX_TAPS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
         sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
     }
-    if (tid <= SDT_MAX_TAPS) sLive[tid] = 0;
+    if (tid < SDT_MAX_TAPS) sFlag[tid] = 0;
     if (tid < BM) {
         int m = m0 + tid, off = -1;
         if (m < M) {
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     }
     __syncthreads();
     int ntl = g.ntaps;
+    // tap order (uniform per launch; PRIO 12 / 14 force table / row-residue order for A/B runs), see the note below
+    const bool rotate = PRIO == 14 || (PRIO != 12 && (unsigned)(g.Cout * g.Tw) * (unsigned)g.Cin <= (3u << 17));  // weights <= 1.5 MiB
     if (VEC4 && g.Hi == 1 && PRIO != 11) {
         // 1-D stage: a tap can only be dead for a whole tile when T is tiny, and these launches are latency-bound --
         // skip the culling passes (two barriers and two serial loops of the prologue)
@@ -112,15 +115,50 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < RA; ++i)
                     any |= (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
-                if (any) sLive[t] = 1;  // benign race: every writer stores 1
+                if (any) sFlag[t] = 1;  // benign race: every writer stores 1
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            int n = 0;
-            for (int t = 0; t < g.ntaps; ++t)
-                if (sLive[t]) sLive[n++] = t;  // in-place compaction (n <= t)
-            sLive[SDT_MAX_TAPS] = n;
+        // Order of the live taps, chosen per launch so that re-reads hit the XCD's 4 MiB L2 (fabric-side traffic measured
+        // with tools/fetch_calibration.py --encoder; the kernel is MFMA-bound either way, its speed does not change):
+        //  * small weight tensor, big activations (L1..L4): by the residue of the input row a tap reads,
+        //    (oy0*sy + dy) mod (number of tap rows), oy0 = output row of the tile's first pixel -- NOT by dy.  An input row
+        //    is needed by every output row within the kernel's vertical reach; their tiles are co-resident on one XCD, and
+        //    in dy-major order they would touch that row a third (k3) or a quarter (k4) of a workgroup's lifetime apart, by
+        //    which time the L2 has streamed several times its size and the row is fetched again (1.9x / 2.6x the input
+        //    bytes on the 3x3 / 4x4-stride-2 layers; 1.05x / 1.2x with this order: all co-resident tiles read input rows of
+        //    one residue class in the same phase of their K loops);
+        //  * weights that alone fill an L2 (L5..L7, 2.4-4.7 MB): table order, so that all tiles read the SAME weight tap
+        //    at the same time (rotating them re-streams the weights: 2.7x more traffic on L7).  A channel-chunk-major
+        //    K loop would fix these layers' re-reads too (measured: L5 forward 368 -> 145 MB, L7 input gradient 230 -> 85 MB)
+        //    but rebuilds the tap offsets every K step and costs 7-17 % of the launch time -- rejected.
+        if (tid < 64) {
+            int dymin = sTap[0], dymax = sTap[0];
+            for (int u = 1; u < g.ntaps; ++u) {
+                dymin = min(dymin, sTap[u]);
+                dymax = max(dymax, sTap[u]);
+            }
+            const int nd = dymax - dymin + 1;
+            const int b0 = rotate ? (((m0 / g.Wo) % g.Ho) * g.sy) % nd : 0;  // uniform
+            const bool mine = tid < g.ntaps && sFlag[tid] != 0;
+            int kt = 0;
+            if (mine && rotate) {
+                kt = b0 + sTap[tid] - dymin;
+                kt -= kt >= nd ? nd : 0;
+            }
+            int rank = 0, total = 0;
+            for (int u = 0; u < g.ntaps; ++u) {
+                if (sFlag[u] == 0) continue;
+                int ku = 0;
+                if (rotate) {
+                    ku = b0 + sTap[u] - dymin;
+                    ku -= ku >= nd ? nd : 0;
+                }
+                rank += (ku < kt || (ku == kt && u < tid)) ? 1 : 0;
+                ++total;
+            }
+            if (mine) sLive[rank] = tid;
+            if (tid == 0) sLive[SDT_MAX_TAPS] = total;
         }
         __syncthreads();
         ntl = sLive[SDT_MAX_TAPS];
@@ -1142,6 +1180,10 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL(conv_taps_dma_kernel, grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 11)  // A/B: tap culling also on 1-D launches (the previous behaviour)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 11>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 12)  // A/B: live taps in table (dy-major) order, the previous behaviour
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 12>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 14)  // A/B: row-residue tap order on every launch
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 14>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4)
@@ -1224,8 +1266,16 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
     const int M = g->B * g->Ho * g->Wo;
     const size_t ysize = (size_t)g->B * g->Hy * g->Wy * g->Cout;
     dim3 grid(cdiv(M, 64) * cdiv(g->Cout, 64), 1, 1);
-    hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
-                       (float*)nullptr, ysize, stats, rows_per_group);
+    static const int order = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // A/B only
+    if (order == 12)
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group);
+    else if (order == 14)
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group);
+    else
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--match", default="")
     ap.add_argument("--min-us", type=float, default=0.0)
+    ap.add_argument("--per-dispatch", action="store_true", help="one line per dispatch, in dispatch order")
     a = ap.parse_args()
     disp = {}
     for row in csv.DictReader(open(a.csv)):
@@ -24,6 +25,13 @@ def main():
         d = disp.setdefault(row["Dispatch_Id"], {"name": name.split("(")[0].replace("void ", ""), "grid": int(row["Grid_Size"]),
                                                   "us": (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3, "c": {}})
         d["c"][row["Counter_Name"]] = d["c"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    if a.per_dispatch:
+        for k in sorted(disp, key=int):
+            d = disp[k]
+            if d["us"] >= a.min_us:
+                print("%-40s WGs %6d  %8.1f us  %s" % (d["name"][:40], d["grid"] // 256, d["us"],
+                                                      "  ".join("%s=%.4g" % kv for kv in sorted(d["c"].items()))))
+        return
     groups = collections.OrderedDict()
     for d in disp.values():
         if d["us"] < a.min_us:
