@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
+    ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +126,7 @@ def main():
     from speechdrivestemplates_amd import ops
     B = args.batch
     ops.OVERLAP_DW = not args.no_overlap_dw
+    ops.DEFER_SMALL_DW = not args.no_defer_dw
     ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
     ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
     ops.OVERLAP_AUX = not args.no_overlap_aux

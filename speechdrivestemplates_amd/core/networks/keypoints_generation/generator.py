@@ -86,11 +86,16 @@ class SequenceGeneratorCNN(nn.Module):
         num_frames = int(num_frames)
         feat = self.audio_encoder.encode_cl(x)
         hook = getattr(self, 'post_encoder_grad_hook', None)
-        if hook is not None and feat.requires_grad:
-            # fires in backward once the gradient w.r.t. the encoder output exists, i.e. when every U-Net / decoder
-            # weight-gradient kernel has been enqueued: the data-parallel exchange of those gradients starts here and
-            # overlaps the (much longer) Conv2d backward (dp.GradReducer)
-            feat.register_hook(hook)
+        if feat.requires_grad:
+            # fires in backward once the gradient w.r.t. the encoder output exists, i.e. when the U-Net / decoder backward
+            # is done: their deferred weight-gradient launches go to the side stream here (ops.flush_deferred_dw), and the
+            # data-parallel exchange of those gradients starts (dp.GradReducer); both overlap the much longer Conv2d
+            # backward
+            def _at_encoder_output(grad, _hook=hook):
+                ops.flush_deferred_dw()
+                return _hook(grad) if _hook is not None else None
+
+            feat.register_hook(_at_encoder_output)
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
         h = self.unet.forward_cl(h)

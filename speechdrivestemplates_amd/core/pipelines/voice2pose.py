@@ -246,7 +246,12 @@ class Voice2Pose(Trainer):
         if 'optimizerClipCode' in self.optimizers:
             self.optimizers['optimizerClipCode'].zero_grad()
         self.optimizers['optimizerG'].zero_grad()
-        losses['G_loss'].backward(retain_graph=has_d)
+        ops.defer_small_dw(True)  # the 1-D stage's weight gradients go to the side stream in one batch (ops.flush_deferred_dw)
+        try:
+            losses['G_loss'].backward(retain_graph=has_d)
+        finally:
+            ops.defer_small_dw(False)
+            ops.flush_deferred_dw()
         return losses, results
 
     def optimizer_updates(self, losses):

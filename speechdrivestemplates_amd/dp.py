@@ -39,17 +39,23 @@ class GradReducer:
         if not self.active:
             return
         from . import ops
-        ops.join_side_stream()  # side-stream weight-gradient kernels write into this buffer
         hi = opt.flat_grad.numel() if hi is None else hi
         if hi <= lo:
             return
         self._launched.setdefault(id(opt), []).append((lo, hi))
         buf = opt.flat_grad[lo:hi]
+        # side-stream weight-gradient kernels write into this buffer: the exchange waits for them -- on the communication
+        # stream when there is one (the main stream keeps running backward), else by joining the main stream
         if self.comm_stream is not None:
+            ops.flush_deferred_dw()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            side = ops.side_stream_if_any()
+            if side is not None:
+                self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         else:
+            ops.join_side_stream()
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         self._pending.append(work)
 

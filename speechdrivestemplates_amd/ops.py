@@ -477,7 +477,41 @@ class side_stream_scope:
         return False
 
 
+# The 1-D stage's weight-gradient launches (15 of 10-20 us, latency-bound) are too short to be worth a pair of cross-stream
+# events each, but nothing on the backward chain needs them either: while deferral is on (a train step that promises to
+# flush) they are only recorded, and ``flush_deferred_dw`` enqueues all of them behind ONE event on the side stream --
+# from the hook that fires when backward reaches the audio encoder, so they run under the long Conv2d backward instead
+# of between the 1-D stage's input-gradient launches.
+DEFER_SMALL_DW = True
+_DEFERRED = []  # (x_cl, gy, w, stride, pad)
+_DEFER_ON = [False]
+
+
+def defer_small_dw(on):
+    _DEFER_ON[0] = bool(on) and DEFER_SMALL_DW and OVERLAP_DW and torch.cuda.is_available() and _side_ok()
+
+
+def flush_deferred_dw():
+    if not _DEFERRED:
+        return
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for x_cl, gy, w, stride, pad in _DEFERRED:
+            conv_weight_grad(x_cl, gy, w, stride, pad)
+    for x_cl, gy, _w, _s, _p2 in _DEFERRED:
+        gy.record_stream(side)
+        x_cl.record_stream(side)
+    _DEFERRED.clear()
+
+
+def side_stream_if_any():
+    return _SIDE.get((torch._C._cuda_getDevice(), 0))
+
+
 def join_side_stream():
+    if _DEFERRED:
+        flush_deferred_dw()
     if not _SIDE:
         return
     dev = torch._C._cuda_getDevice()
@@ -514,6 +548,8 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx):
                 conv_weight_grad(x_cl, gy, w, stride, pad)
             gy.record_stream(side)  # keep the caching allocator from recycling gy under the side stream
             x_cl.record_stream(side)
+        elif _DEFER_ON[0] and not big:
+            _DEFERRED.append((x_cl, gy, w, stride, pad))
         else:
             conv_weight_grad(x_cl, gy, w, stride, pad)
     if bias is not None and bias.requires_grad:

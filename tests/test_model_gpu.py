@@ -320,6 +320,40 @@ def test_aux_stream_overlap_is_bit_identical():
         check("overlap vs single stream", b, a, 5e-5)
 
 
+def test_deferred_weight_gradients_cover_every_layer():
+    """ops.DEFER_SMALL_DW: the 1-D stage's weight-gradient launches are recorded during backward and enqueued as one batch
+    on the side stream from the hook at the audio encoder's output.  Nothing may be left behind when forward_backward
+    returns, the hook must be what flushes them, and the gradients must equal the inline launches (fp32 atomics: order
+    noise only)."""
+    from speechdrivestemplates_amd import ops
+    grads, seen = [], []
+    prev, orig_flush = ops.DEFER_SMALL_DW, ops.flush_deferred_dw
+
+    def spy():
+        seen.append(len(ops._DEFERRED))
+        orig_flush()
+
+    for flag in (False, True):
+        ops.DEFER_SMALL_DW = flag
+        ops.flush_deferred_dw = spy
+        try:
+            pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
+            del seen[:]
+            losses, _ = pipe.forward_backward(O.make_batch(4, 16, step=0, seed=1))
+            assert not ops._DEFERRED and not ops._DEFER_ON[0]
+            if flag:
+                # first flush = the hook at the encoder output: U-Net (12) + decoder (5) convolutions, none from the 2-D stage
+                # (at this batch size some Conv2d layers fall under the side stream's size threshold too: later flushes)
+                assert seen and seen[0] == 17, seen
+            else:
+                assert all(n == 0 for n in seen), seen
+            torch.cuda.synchronize()
+            grads.append(pipe.optimizers["optimizerG"].flat_grad.clone())
+        finally:
+            ops.DEFER_SMALL_DW, ops.flush_deferred_dw = prev, orig_flush
+    check("deferred vs inline weight gradients", grads[1], grads[0], 2e-5)
+
+
 @pytest.mark.parametrize("name,code_std,tol", [("voice2pose_sdt_vae", 0.0, 2e-5), ("voice2pose_sdt_bp", 0.5, 1e-3)])
 def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
     """The bucketed, backward-overlapped all-reduce path (dp.GradReducer + the post-encoder hook) exercised over RCCL with
