@@ -577,6 +577,7 @@ class ConvStatsFn(torch.autograd.Function):
         ctx.save_for_backward(x_cl, w)
         ctx.stride, ctx.pad = stride, pad
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)  # no zero-filled float64 "gradient" of sums in backward (one fill launch per layer)
         return y, sums
 
     @staticmethod
@@ -697,7 +698,9 @@ class L0BlockFn(torch.autograd.Function):
         B, H, W = mel.shape
         ws = weight_storage(w)
         z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.float32)
-        mom = torch.zeros(54 * B, device=mel.device, dtype=torch.float64)  # kept for backward: not from the per-step arena
+        # zero on entry; read again by this step's backward (an arena slice is not handed out twice within a step, and
+        # the arena is only recycled by the next step's begin_step)
+        mom = _ARENA.take(54 * B, mel.device)
         mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
@@ -761,6 +764,17 @@ class RowNormActFn(torch.autograd.Function):
         return dy, None
 
 
+_ROW_INDEX = {}
+
+
+def _row_index(n, dev):
+    """arange(n) on ``dev`` (int64), created once per (n, device): read-only."""
+    key = (n, dev.type, dev.index)
+    if key not in _ROW_INDEX:
+        _ROW_INDEX[key] = torch.arange(n, device=dev, dtype=torch.int64)
+    return _ROW_INDEX[key]
+
+
 class ResizeConcatFn(torch.autograd.Function):
     """F.interpolate(x,(1,T),'bilinear').squeeze(2) ++ code (generator.py:41-42,110-111), channels-last."""
 
@@ -774,7 +788,7 @@ class ResizeConcatFn(torch.autograd.Function):
         idx = None
         if code is not None:
             code = code.contiguous()
-            idx = torch.arange(B, device=x_cl.device, dtype=torch.int64)
+            idx = _row_index(B, x_cl.device)
         out = torch.empty((B, T, C + D), device=x_cl.device, dtype=torch.float32)
         check(lib.sdt_resize_concat_fwd_f32(_p(x_cl), _p(code), _p(idx), _p(out), B, H, W, C, T, D, _stream()))
         ctx.dims = (B, H, W, C, T, D)
@@ -861,6 +875,7 @@ class CodeGatherKLFn(torch.autograd.Function):
         ctx.save_for_backward(code, valid, idx, table)
         ctx.lam = lam
         ctx.mark_non_differentiable(valid)
+        ctx.set_materialize_grads(False)  # backward takes None for an unused output's gradient
         return code, loss, valid
 
     @staticmethod
