@@ -108,12 +108,28 @@ class _ZeroArena:
 _ARENA = _ZeroArena()
 
 
+# The host enqueues a step in about half the time the GPU needs for it and would run ahead until the launch queue is full
+# (10+ steps).  Tensors handed to the side streams (record_stream) return to the caching allocator only when the GPU has
+# passed their last use, so the reserved pool grows with the host's lead (measured: 21 GB reserved for 1.2 GB live, still
+# creeping after thousands of steps).  begin_step therefore lets the host lead by at most MAX_STEPS_IN_FLIGHT steps.
+MAX_STEPS_IN_FLIGHT = 2
+_STEP_FENCE = {}
+
+
 def begin_step(dev=None):
     """Recycle the zero-workspace region; call once at the start of a train step, on the main stream, when no kernel of
     the previous step can still be using its workspaces (i.e. after the side stream has been joined)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
     if _side_ok():
         join_side_stream()
-    _ARENA.begin_step(torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev))
+        if MAX_STEPS_IN_FLIGHT and not torch.cuda.is_current_stream_capturing():
+            q = _STEP_FENCE.setdefault((dev.type, dev.index), [])
+            if len(q) >= MAX_STEPS_IN_FLIGHT:
+                q.pop(0).synchronize()  # the GPU has started the step that began MAX_STEPS_IN_FLIGHT calls ago
+            e = torch.cuda.Event()
+            e.record()
+            q.append(e)
+    _ARENA.begin_step(dev)
 
 
 def _stream():

@@ -33,9 +33,11 @@ def main():
     # (the very first steps have no KL term: zero-initialised clip codes have zero batch variance and the reference skips
     #  the term then, voice2pose.py:154 -- compare from the first sample after that)
     assert hist[-1] < hist[1], "loss did not decrease"
-    # blocks handed to the side streams (record_stream) are recycled late, so the caching allocator's reserve settles at
-    # ~12x the 1.2 GiB working set within ~150 steps and must then stay flat
-    assert len(mem) < 5 or mem[-1] <= mem[3] * 1.02 + 64, "allocator footprint keeps growing: %s" % mem
+    # blocks handed to the side streams (record_stream) are recycled only when the GPU has passed their last use; with the
+    # host's lead bounded (ops.MAX_STEPS_IN_FLIGHT) the caching allocator's reserve settles at ~3.5x the 1.2 GiB working
+    # set (it was ~17x, and creeping, with an unbounded lead) and must be flat over the second half of the run
+    assert len(mem) < 5 or mem[-1] <= mem[len(mem) // 2] * 1.02 + 64, "allocator footprint keeps growing: %s" % mem
+    assert mem[-1] < 8 * 1024, "allocator reserve %.0f MiB: is the host running unboundedly ahead?" % mem[-1]
     for p in pipe.model.parameters():
         assert torch.isfinite(p).all()
     print("soak OK")
