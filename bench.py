@@ -27,7 +27,14 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 N_CLIPS = 4096
-EVENT_STEPS = 4  # timed steps that carry HIP events around every conv launch (recording them perturbs the step): 2 + 2
+# timed steps that carry HIP events around every conv launch, half of them "alone", half "as run" (see below).  A sampled
+# step costs ~1.6 ms extra (the events serialise neighbouring launches, and an "alone" step gives up the side stream), so they
+# are kept to ~1 in 15: 2 of the default 30 steps, 4 from 60 steps on
+EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "4"))
+
+
+def event_steps(steps):
+    return min(EVENT_STEPS_MAX, max(2, (steps // 30) * 2), steps)
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -153,9 +160,9 @@ def main():
     # that step: the kernel-quality figure reported as roofline.achieved) and "as run" (roofline.overlapped).
     prof = prof_ovl = None
     if not args.no_kernel_events and not (args.graph and world == 1):
-        prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS)
-        prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS) if ops.OVERLAP_DW else None
-    n_ev = min(EVENT_STEPS, args.steps) if prof is not None else 0
+        prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX)
+        prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX) if ops.OVERLAP_DW else None
+    n_ev = event_steps(args.steps) if prof is not None else 0
     sampled = sorted({(j + 1) * args.steps // (n_ev + 1) for j in range(n_ev)}) if n_ev else []  # spread over the timed region
     torch.cuda.synchronize()
     if world > 1:
