@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     int ntl = g.ntaps;
     // tap order (uniform per launch; PRIO 12 / 14 force table / row-residue order for A/B runs), see the note below
     const bool rotate = PRIO == 14 || (PRIO != 12 && (unsigned)(g.Cout * g.Tw) * (unsigned)g.Cin <= (3u << 17));  // weights <= 1.5 MiB
-    if (VEC4 && g.Hi == 1 && PRIO != 11) {
+    if (VEC4 && (g.Hi == 1 || (g.ntaps <= 4 && PRIO != 16)) && PRIO != 11) {
         // 1-D stage: a tap can only be dead for a whole tile when T is tiny, and these launches are latency-bound --
-        // skip the culling passes (two barriers and two serial loops of the prologue)
+        // skip the culling passes (two barriers and two serial loops of the prologue).  Likewise the parity classes of a
+        // strided layer's input gradient (2x2 taps, K loop of only 8-32 steps: the prologue is a visible share of a
+        // workgroup's life, culling could only trim border tiles, and their re-reads already hit the L2)
         if (tid < g.ntaps) sLive[tid] = tid;
         if (tid == 0) sLive[SDT_MAX_TAPS] = g.ntaps;
         __syncthreads();
@@ -1182,6 +1184,8 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 11>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 12)  // A/B: live taps in table (dy-major) order, the previous behaviour
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 12>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 16)  // A/B: tap culling also on launches with <= 4 taps (the previous behaviour)
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 16>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 14)  // A/B: row-residue tap order on every launch
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 14>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
