@@ -432,22 +432,26 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
     }
 }
 
-// spec (B,F,2*nfreq) interleaved re/im -> mel (B,nmel,F); block = 32 frames, 320 threads
-#define MEL_FT 32
+// spec (B,F,2*nfreq) interleaved re/im -> mel (B,nmel,F); block = 16 frames, 320 threads
+#define MEL_FT 16
 __global__ __launch_bounds__(320) void mel_fb_kernel(const float* __restrict__ spec, const float* __restrict__ fb,
                                                      const int* __restrict__ bin_lo, const int* __restrict__ bin_hi,
                                                      float* __restrict__ mel, int F, int nfreq, int nmel) {
     extern __shared__ float sP[];  // [MEL_FT][nfreq+1]
     const int b = blockIdx.y, f0 = blockIdx.x * MEL_FT;
     const int ldp = nfreq + 1;
-    for (int i = threadIdx.x; i < MEL_FT * nfreq; i += 320) {
-        const int fr = i / nfreq, k = i - fr * nfreq;
-        float pw = 0.f;
-        if (f0 + fr < F) {
-            const float* s = spec + ((size_t)b * F + f0 + fr) * 2 * nfreq + 2 * k;
-            pw = s[0] * s[0] + s[1] * s[1];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int k = threadIdx.x; k < nfreq; k += 320) {  // thread = frequency bin: one 8-byte (re, im) load per frame, no division
+        const float* s = spec + ((size_t)b * F + f0) * 2 * nfreq + 2 * k;
+#pragma unroll 8
+        for (int fr = 0; fr < MEL_FT; ++fr) {
+            float pw = 0.f;
+            if (f0 + fr < F) {
+                const f32x2 v = *(const f32x2*)(s + (size_t)fr * 2 * nfreq);
+                pw = v[0] * v[0] + v[1] * v[1];
+            }
+            sP[fr * ldp + k] = pw;
         }
-        sP[fr * ldp + k] = pw;
     }
     __syncthreads();
     const int npg = 320 / nmel;  // frame groups handled in parallel (4 for 80 mels)
