@@ -8,14 +8,26 @@ Workload (BASELINE.json configs[1]): voice2pose_sdt_bp, 32 clips per GPU (weak s
 logging: mel -> generator -> L1 + clip-code KL -> no-grad pose encoder x2 -> float64 metrics -> backward ->
 gradient all-reduce (N>1) -> Adam on the clip-code table and the generator.  Prints ONE JSON line on rank 0.
 
-The JSON carries `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv instantiation with the most
-time): algorithmic FLOPs per launch / mean launch duration from HIP events recorded over the timed region, against
-the 157.3 TFLOP/s fp32 matrix peak; and `cpu_baseline`: the CPU oracle (PyTorch-CPU restatement of the reference
-step, oracle/) timed on this box's host cores for a few steps of the same workload (rank 0, N=1 only).
+Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs; `value` = clips of all ranks / the
+slowest rank's wall time (the driver's contract).  Every step is also bracketed by one HIP event on the main stream, so the
+line carries the MEDIAN step time (SURVEY.md 8d's definition) and the mean over the steps that carried no per-kernel events.
+
+`roofline`        : the dominant kernel (the fp32-MFMA implicit-GEMM conv): algorithmic FLOPs per launch / mean launch
+                    duration from HIP events on the launching stream over sampled steps of the timed region, against the
+                    157.3 TFLOP/s fp32 matrix peak.  `traffic` is NOT measured in this process (PMC counters need rocprofv3):
+                    the line cites the committed measurement and says which source revision it was taken at, or null when the
+                    kernel source has changed since.
+`roofline_conv1d` : the Conv1d stacks (U-Net + decoder forward/backward, the two pose-encoder passes, their weight
+                    gradients): algorithmic bytes and FLOPs of the stage / the stage's event-timed windows,
+                    against 8 TB/s and 157.3 TFLOP/s -- the north-star's ">= 40 % HBM roofline on the Conv1d stacks" tracker.
+`cpu_baseline`    : the CPU oracle (PyTorch-CPU restatement of the reference step, oracle/) timed on this box's host cores for
+                    a few steps of the same workload (rank 0, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,10 +38,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 N_CLIPS = 4096
+# Algorithmic work of the Conv1d stacks per 32-clip step (weights counted once per step): generator U-Net + decoder
+# forward+backward 153.3 MB / 3 x 0.243 GFLOP per clip; two no-grad pose-encoder passes 40.6 MB / 2 x 0.0806 GFLOP per clip
+CONV1D_MB_PER_32 = {"generator_fwd_bwd": 153.3, "pose_encoder_x2": 40.6}
+CONV1D_GFLOP_PER_CLIP = {"generator_fwd_bwd": 3 * 0.243, "pose_encoder_x2": 2 * 0.0806}
 # timed steps that carry HIP events around every conv launch, half of them "alone", half "as run" (see below).  A sampled
 # step costs ~1.6 ms extra (the events serialise neighbouring launches, and an "alone" step gives up the side stream), so they
-# are kept to ~1 in 15: 2 of the default 30 steps, 4 from 60 steps on
+# are kept to ~1 in 15
 EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "4"))
 
 
@@ -96,11 +113,64 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
+def kernel_source_digest():
+    """sha256 over the kernel sources: what a committed PMC measurement has to match to be cited."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "speechdrivestemplates_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cited_traffic(kernel_name):
+    """HBM-side traffic cannot be read from inside the process (PMC counters need rocprofv3, separate passes for FETCH_SIZE and
+    WRITE_SIZE).  Cite the newest committed measurement of this command (tools/hbm_traffic.py) -- but only when it was taken on
+    the kernel sources that are running now; otherwise report null and say why."""
+    prof = os.path.join(REPO, "profiles")
+    cands = sorted((f for f in os.listdir(prof) if f.endswith("_hbm_traffic_bench.json")), reverse=True) if os.path.isdir(prof) else []
+    info = {"traffic": None, "traffic_measured_in_run": False}
+    for f in cands:
+        tj = json.load(open(os.path.join(prof, f)))
+        if tj.get("dominant_kernel", "") != kernel_name:
+            continue
+        info["traffic_source"] = "profiles/" + f
+        info["traffic_source_kernel_digest"] = tj.get("kernel_source_digest")
+        info["traffic_source_git_head"] = tj.get("git_head")
+        if tj.get("kernel_source_digest") == kernel_source_digest():
+            info["traffic"] = tj["traffic_mb_per_launch"] * 1e6
+            info["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, fabric side, upper bound on HBM)"
+        else:
+            info["traffic_note"] = "kernel sources changed since that measurement (digest now %s): not cited" % kernel_source_digest()
+        break
+    return info
+
+
+class _StubPipeline:
+    """SDT_BENCH_STUB=1: the control flow of this script (process group, barriers, timed loop, max over ranks, JSON) with the
+    train step replaced by a tiny CPU all-reduce -- tests/test_bench_flow.py runs it under gloo with two ranks so that the
+    driver's multi-GPU launch cannot die on plumbing that a 1-GPU box never executes."""
+
+    def __init__(self, world):
+        self.world = world
+        self.buf = torch.ones(1024)
+
+    def forward_backward(self, batch):
+        time.sleep(0.002)
+        return {"G_loss": torch.tensor(0.5)}, {}
+
+    def optimizer_updates(self, losses):
+        if self.world > 1:
+            dist.all_reduce(self.buf)
+            self.buf.div_(self.world)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--config", default="voice2pose_sdt_bp")
     ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
@@ -113,33 +183,48 @@ def main():
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    stub = os.environ.get("SDT_BENCH_STUB") == "1"
+    backend = os.environ.get("SDT_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for the CPU control-flow test
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = not stub
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        try:  # "nccl" is RCCL on ROCm; device_id binds the communicator to this rank's GPU up front
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        except TypeError:
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            try:  # device_id binds the communicator to this rank's GPU up front
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except TypeError:
+                dist.init_process_group("nccl", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
 
-    from __graft_entry__ import make_pipeline
-    from speechdrivestemplates_amd import ops
     B = args.batch
-    ops.OVERLAP_DW = not args.no_overlap_dw
-    ops.DEFER_SMALL_DW = not args.no_defer_dw
-    ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
-    ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
-    ops.OVERLAP_AUX = not args.no_overlap_aux
-    ops.set_conv_math(args.conv_math)
-    pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
-    batches = stage_batches(4, B, rank, dev)
+    if stub:
+        ops = None
+        pipe = _StubPipeline(world)
+        batches = [None]
+    else:
+        from __graft_entry__ import make_pipeline
+        from speechdrivestemplates_amd import ops
+        ops.OVERLAP_DW = not args.no_overlap_dw
+        ops.DEFER_SMALL_DW = not args.no_defer_dw
+        ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
+        ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
+        ops.OVERLAP_AUX = not args.no_overlap_aux
+        ops.set_conv_math(args.conv_math)
+        # every rank draws its own initial weights (nothing here seeds torch): setup_optimizer's dp.sync_replicas makes the
+        # replicas identical, as DDP's constructor does in the reference
+        pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
+        batches = stage_batches(4, B, rank, dev)
 
     def step(i):
         losses, _ = pipe.forward_backward(batches[i % len(batches)])
@@ -147,7 +232,7 @@ def main():
         return losses
 
     runner = step
-    if args.graph and world == 1:
+    if args.graph and world == 1 and not stub:
         from speechdrivestemplates_amd.graph import GraphedStep
         gs = GraphedStep(pipe, warmup=min(3, max(1, args.warmup - 1)))
         runner = lambda i: gs.run(batches[i % len(batches)])  # noqa: E731
@@ -158,37 +243,57 @@ def main():
     # weight-gradient kernels run on a second stream, concurrently with the input-gradient chain, so a launch's duration
     # then includes the time it shared the GPU: sampled steps therefore ALTERNATE between "alone" (side stream off for
     # that step: the kernel-quality figure reported as roofline.achieved) and "as run" (roofline.overlapped).
-    prof = prof_ovl = None
-    if not args.no_kernel_events and not (args.graph and world == 1):
+    prof = prof_ovl = stages = None
+    if not stub and not args.no_kernel_events and not (args.graph and world == 1):
         prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX)
         prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX) if ops.OVERLAP_DW else None
+        stages = ops.StageTimer()
     n_ev = event_steps(args.steps) if prof is not None else 0
     sampled = sorted({(j + 1) * args.steps // (n_ev + 1) for j in range(n_ev)}) if n_ev else []  # spread over the timed region
-    torch.cuda.synchronize()
+    # one event per step boundary on the main stream: per-step GPU time without a host synchronisation
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if on_gpu else None
+    host_marks = []
+    sync()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    overlap_dw = ops.OVERLAP_DW
+    overlap_dw = ops.OVERLAP_DW if ops is not None else False
     n_alone = n_ovl = 0
     for i in range(args.steps):
+        if marks is not None:
+            marks[i].record()
+        else:
+            host_marks.append(time.perf_counter())
         if prof is not None:  # sampled: the events serialise the host a little and cost a few % on the steps they cover
-            ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
+            ops.PROFILER, ops.STAGES, ops.OVERLAP_DW = None, None, overlap_dw
             if i in sampled:
                 if prof_ovl is not None and n_alone > n_ovl:
-                    ops.PROFILER, n_ovl = prof_ovl, n_ovl + 1
+                    ops.PROFILER, ops.STAGES, n_ovl = prof_ovl, stages, n_ovl + 1  # stage windows are taken on "as run" steps
                 else:
                     ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
         losses = runner(args.warmup + i)
-    torch.cuda.synchronize()
+    if marks is not None:
+        marks[args.steps].record()
+    else:
+        host_marks.append(time.perf_counter())
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
+    if ops is not None:
+        ops.PROFILER, ops.STAGES, ops.OVERLAP_DW = None, None, overlap_dw
     prof_steps = n_alone
+    if marks is not None:
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    else:
+        step_ms = [1e3 * (host_marks[i + 1] - host_marks[i]) for i in range(args.steps)]
+    clean_ms = [t for i, t in enumerate(step_ms) if i not in sampled] or step_ms
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, statistics.median(step_ms), sum(clean_ms) / len(clean_ms)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, median_ms, clean_mean_ms = (float(x) for x in t.tolist())
+    else:
+        median_ms, clean_mean_ms = statistics.median(step_ms), sum(clean_ms) / len(clean_ms)
     final_loss = float(losses["G_loss" if "G_loss" in losses else "loss"].detach())
     assert final_loss == final_loss and final_loss < 10.0, "training diverged: G_loss=%r" % final_loss
 
@@ -204,7 +309,14 @@ def main():
                                    % (args.config, B, world, N_CLIPS),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1)},
             "final_G_loss": final_loss,
+            # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
+            # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included
+            "median_ms_per_step": median_ms, "value_at_median": world * B / (median_ms * 1e-3),
+            "event_instrumented_steps": sampled,
+            "ms_per_step_uninstrumented": clean_mean_ms, "value_uninstrumented": world * B / (clean_mean_ms * 1e-3),
         }
+        if stub:
+            out["stub"] = True
         if prof is not None and prof_steps > 0:
             summ = prof.summary()
             name, d = max(summ.items(), key=lambda kv: kv[1]["us"])
@@ -219,15 +331,7 @@ def main():
                                            "weight-gradient side stream switched off (the kernel alone on the GPU)",
                                "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
                                "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6}
-            # HBM-side traffic cannot be read from inside the process: cite the committed rocprofv3 PMC measurement of this
-            # same command (two separate --pmc passes, gfx950 x2 correction on FETCH_SIZE; profiles/README.md)
-            tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_bench.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("dominant_kernel", "") == name:
-                    out["roofline"]["traffic"] = tj["traffic_mb_per_launch"] * 1e6
-                    out["roofline"]["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, fabric side, upper bound on HBM)"
-                    out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic_bench.json"
+            out["roofline"].update(cited_traffic(name))
             if prof_ovl is not None and n_ovl > 0:
                 do = prof_ovl.summary()[name]
                 out["roofline"]["overlapped"] = {
@@ -241,7 +345,32 @@ def main():
                                        "tflops": v["flops"] / (v["us"] * 1e-6) / 1e12} for k, v in sorted(summ.items())}
             out["conv_total"] = {"ms_per_step": tot_us / prof_steps / 1e3, "tflops": tot_fl / (tot_us * 1e-6) / 1e12,
                                  "gflop_per_step": tot_fl / prof_steps / 1e9}
-        if world == 1 and not args.no_cpu_baseline:
+            if stages is not None and n_ovl > 0 and args.config.startswith("voice2pose"):
+                win = {k: v[1] / v[0] for k, v in stages.windows_us().items()}  # us per step, per window
+                if all(k in win for k in ("g1d_fwd", "g1d_bwd")):
+                    scale = B / 32.0
+                    mb = sum(CONV1D_MB_PER_32.values()) * scale  # weights are counted once per step; activations scale with B
+                    gflop = sum(CONV1D_GFLOP_PER_CLIP.values()) * B
+                    stage_us = sum(win.values())
+                    exposed_us = win["g1d_fwd"] + win["g1d_bwd"]
+                    tbs = mb * 1e6 / (stage_us * 1e-6) / 1e12
+                    out["roofline_conv1d"] = {
+                        "bound": "hbm", "achieved": tbs * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": tbs / HBM_PEAK_TBS,
+                        "mfma_achieved_tflops": gflop * 1e9 / (stage_us * 1e-6) / 1e12,
+                        "mfma_frac": gflop * 1e9 / (stage_us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                        "algorithmic_mb_per_step": mb, "algorithmic_gflop_per_step": gflop,
+                        "stage_us_per_step": stage_us, "windows_us": win, "exposed_us_per_step": exposed_us,
+                        "note": "Conv1d stacks of one train step: U-Net + decoder forward and backward chains (main stream, exposed), "
+                                "their weight gradients and the two no-grad pose-encoder passes (side stream, overlapped with the "
+                                "Conv2d backward); HIP-event windows on the stream each piece runs on, as-run sampled steps; "
+                                "algorithmic bytes / FLOPs from SURVEY.md 8d.  In fp32 the stage is bound by the fp32 MFMA rate and "
+                                "by launch latency, not by HBM: at the MFMA roofline (%.0f us) it would still reach only %.0f %% of 8 TB/s"
+                                % (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) * 1e6,
+                                   100 * mb * 1e6 / (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12)) / 1e12 / HBM_PEAK_TBS)}
+            hb = os.path.join(REPO, "profiles", "r02_hbm_kernels.txt")
+            if os.path.exists(hb):
+                out["hbm_kernels_table"] = "profiles/r02_hbm_kernels.txt (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)"
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(B)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

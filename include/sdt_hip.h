@@ -178,11 +178,13 @@ int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, i
  * Clip-code batch KL (voice2pose.py:147-157): code = table[idx] (B,D); mu/unbiased var over the batch;
  * loss = 0.5*mean(-log v + mu^2 + v - 1)*lambda if every v != 0 else 0; valid[0] = that predicate
  * (kept on the device: no host sync).  code_out (B,D) receives the gathered rows.
+ * N = rows of the table: an index outside [0, N) reads nothing (the reference raises IndexError there) -- its code row
+ * becomes NaN, which poisons the losses, and its gradient row is dropped.
  */
-int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int B, int D, float lambda,
+int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int N, int B, int D, float lambda,
                         float* code_out, float* loss, int32_t* valid, void* stream);
 int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* gout, const int64_t* idx,
-                        int B, int D, float lambda, float* dtable, void* stream);
+                        int N, int B, int D, float lambda, float* dtable, void* stream);
 
 /*
  * GestureDataset.get_final_results x2 + Voice2Pose.evaluate_step (gesture_dataset.py:193-220,
@@ -215,8 +217,9 @@ int sdt_stft_frames_f32(const float* audio, float* hops, int B, int L, int nhops
 int sdt_mel_fb_f32(const float* spec, const float* fb, const int32_t* bin_lo, const int32_t* bin_hi, float* mel, int B, int F,
                    int nfreq, int nmel, void* stream);
 
-/* dst[idx[b], :] += src[b, :]  -- dense gradient of the clip-code table for `clips_code[clip_indices]` (voice2pose.py:94). */
-int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int B, int D, void* stream);
+/* dst[idx[b], :] += src[b, :]  -- dense gradient of the clip-code table for `clips_code[clip_indices]` (voice2pose.py:94).
+ * dst has N rows; rows with idx outside [0, N) are skipped. */
+int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int N, int B, int D, void* stream);
 
 /* y[i] = a[i+stride]-a[i] helper for the motion discriminator input (voice2pose.py:187-188): (B,T,C)->(B,T-1,C) */
 int sdt_time_diff_fwd_f32(const float* x, float* y, int B, int T, int C, void* stream);

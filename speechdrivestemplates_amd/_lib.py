@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdt_hip.so")
+# SDT_HIP_LIB: developer tools only (tools/conv_bench.py points it at the -DSDT_TUNING build); the package itself never sets it
+LIB_PATH = os.environ.get("SDT_HIP_LIB") or os.path.join(_HERE, "lib", "libsdt_hip.so")
 MAX_TAPS = 20
 
 
@@ -57,13 +58,13 @@ SIGNATURES = {
     "sdt_upsample_add_bwd_f32": [_p, _p, _i, _i, _i, _i, _p],
     "sdt_l1_loss_fwd_f32": [_p, _p, _i64, _f, _p, _p, _p],
     "sdt_l1_loss_bwd_f32": [_p, _p, _p, _i64, _f, _p, _p],
-    "sdt_code_kl_fwd_f32": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
-    "sdt_code_kl_bwd_f32": [_p, _p, _p, _p, _i, _i, _f, _p, _p],
+    "sdt_code_kl_fwd_f32": [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p],
+    "sdt_code_kl_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
     "sdt_final_metrics_f64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "sdt_adam_step_f32": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p, _p],
     "sdt_stft_frames_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_mel_fb_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _p],
+    "sdt_rows_scatter_add_f32": [_p, _p, _p, _i, _i, _i, _p],
     "sdt_time_diff_fwd_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_time_diff_bwd_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_clip_poses_prepare_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

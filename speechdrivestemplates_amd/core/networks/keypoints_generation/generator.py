@@ -92,14 +92,19 @@ class SequenceGeneratorCNN(nn.Module):
             # data-parallel exchange of those gradients starts (dp.GradReducer); both overlap the much longer Conv2d
             # backward
             def _at_encoder_output(grad, _hook=hook):
+                ops.stage_mark("g1d_bwd:end")
                 ops.flush_deferred_dw()
                 return _hook(grad) if _hook is not None else None
 
             feat.register_hook(_at_encoder_output)
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
+        ops.stage_mark("g1d_fwd:begin")
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
         h = self.unet.forward_cl(h)
         for block in list(self.decoder)[:4]:
             h = block.forward_cl(h)
         h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
+        ops.stage_mark("g1d_fwd:end")
+        if ops.STAGES is not None and h.requires_grad:
+            h.register_hook(lambda g: ops.stage_mark("g1d_bwd:begin"))
         return h.reshape(-1, num_frames, 2, self.cfg.DATASET.NUM_LANDMARKS)

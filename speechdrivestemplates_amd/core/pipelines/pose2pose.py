@@ -62,6 +62,7 @@ class Pose2Pose(Trainer):
             E = self.cfg.TRAIN.NUM_EPOCHS
             self.schedulers['scheduler'] = _MultiStepLR(opt, [E - 10, E - 2], 0.1, last_epoch)
         self.reducer = dp.GradReducer(self.optimizers.values())
+        dp.sync_replicas(self.model, list(self.optimizers.values()))  # DDP-constructor semantics (pose2pose.py:102)
 
     def forward_backward(self, batch, want_final=False):
         dev = self.model.clip_code_mu.device

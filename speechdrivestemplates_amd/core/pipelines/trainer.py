@@ -186,7 +186,9 @@ class Trainer(object):
         return {}
 
     # -- loops (trainer.py:367-427) ----------------------------------------------------------------------
-    def train(self, exp_tag, resume_from=None):
+    def train(self, cfg, exp_tag, resume_from=None):
+        """``pipeline.train(cfg, exp_tag, args.resume_from)`` as main.py:51 calls it (trainer.py:367).  ``cfg`` is the object
+        the pipeline was constructed with; like the reference, the loop reads ``self.cfg``."""
         self.base_path, epoch_start, global_step = self.setup_experiment(True, exp_tag, resume_from=resume_from)
         if self.cfg.SYS.DISTRIBUTED:
             torch.distributed.barrier()
@@ -202,18 +204,25 @@ class Trainer(object):
                 if self.is_master_process():
                     self.save_checkpoint(epoch + 1, global_step)
                 if self.cfg.TRAIN.VALIDATE:
-                    self.validate(epoch + 1)
+                    self.validate(self.test_dataloader, epoch + 1)
             for s in self.schedulers.values():
                 s.step()
             if self.is_master_process():
                 logging.info('[TRAIN] epoch_time: %.2f hours' % ((time.time() - tic) / 3600))
 
     @torch.no_grad()
-    def validate(self, epoch=0):
+    def validate(self, test_dataloader=None, epoch=0):
+        """trainer.py:407-427 (same positional signature).  Data-parallel runs first take rank 0's buffers (dp.sync_buffers):
+        eval-mode BatchNorm then reads the same running statistics on every rank, as under DDP's per-forward buffer
+        broadcast."""
+        from ... import dp
+        test_dataloader = self.test_dataloader if test_dataloader is None else test_dataloader
+        if self.cfg.SYS.DISTRIBUTED:
+            dp.sync_buffers(self.model)
         self.model.eval()
         tic = time.time()
         sums, coll = {}, {}
-        for t_step, batch in enumerate(self.test_dataloader):
+        for t_step, batch in enumerate(test_dataloader):
             losses, res = self.test_step(batch, t_step + 1, epoch)
             for k, v in losses.items():
                 sums[k] = sums.get(k, 0) + v
@@ -227,13 +236,14 @@ class Trainer(object):
                          ''.join('%s: %.5f  ' % (k, float(v)) for k, v in out.items()))
         return out
 
-    def test(self, exp_tag, checkpoint):
+    def test(self, cfg, exp_tag, checkpoint):
+        """``pipeline.test(cfg, exp_tag, args.checkpoint)`` (main.py:48, trainer.py:429)."""
         self.base_path = self.setup_experiment(False, exp_tag, checkpoint=checkpoint)
-        return self.validate(0)
+        return self.validate(self.test_dataloader, 0)
 
     @torch.no_grad()
-    def demo(self, exp_tag, checkpoint, demo_input):
-        """Variable-length inference on wav input (trainer.py:459-484): one demo_step per clip, or DEMO.MULTIPLE steps with the
+    def demo(self, cfg, exp_tag, checkpoint, demo_input):
+        """``pipeline.demo(cfg, exp_tag, args.checkpoint, args.demo_input)`` (main.py:45, trainer.py:459).  Variable-length inference on wav input (trainer.py:459-484): one demo_step per clip, or DEMO.MULTIPLE steps with the
         code interpolation coefficient swept over [0, 1].  Returns the list of results dicts (the reference only writes
         videos / npz files)."""
         self.base_path = self.setup_experiment(False, exp_tag, checkpoint=checkpoint, demo_input=demo_input)

@@ -41,6 +41,11 @@ class Voice2PoseModel(nn.Module):
                     ckpt = torch.load(path, map_location='cpu')
                     self.clips_code = {k.replace('module.', ''): v for k, v in ckpt['model_state_dict'].items()
                                        if 'clip_code' in k}['clip_code_mu']
+                if num_train_samples is not None and self.clips_code.shape[0] < num_train_samples:
+                    # the reference leaves this shape check commented out and fails later with an IndexError on the first
+                    # clip beyond the table; fail here, before any kernel sees such an index
+                    raise RuntimeError('external clip codes have %d rows but the training set has %d clips'
+                                       % (self.clips_code.shape[0], num_train_samples))
             else:
                 if num_train_samples is None:
                     assert state_dict is not None, 'No state_dict available, while no dataset is configured.'
@@ -104,7 +109,7 @@ class Voice2PoseModel(nn.Module):
                                                  return_loss)
                 if return_loss:
                     ar = torch.arange(condition_code.shape[0], device=dev)
-                    _, kl, kl_valid = ops.CodeGatherKLFn.apply(condition_code.detach().contiguous(), ar, g.LAMBDA_CLIP_KL)
+                    _, kl, kl_valid = ops.CodeGatherKLFn.apply(condition_code.detach().contiguous(), ar, g.LAMBDA_CLIP_KL, True)
         else:
             condition_code = None
 
@@ -137,8 +142,10 @@ class Voice2PoseModel(nn.Module):
                     e_pred = dataset.transform_normalized_parted2global(poses_pred.detach().clone(), speaker)
                     e_gt = dataset.transform_normalized_parted2global(poses_gt.clone(), speaker)
                 side.uses(e_pred, e_gt)
+                ops.stage_mark("pose_enc:begin")
                 mu_pred, logvar_pred = self.pose_encoder(e_pred)
                 mu_gt, logvar_gt = self.pose_encoder(e_gt)
+                ops.stage_mark("pose_enc:end")
             results.update(mu_pred=mu_pred, mu_gt=mu_gt, logvar_pred=logvar_pred, logvar_gt=logvar_gt)
 
         if hasattr(self, 'netD_pose'):  # LSGAN on motion patches (voice2pose.py:179-208)
@@ -195,10 +202,13 @@ class Voice2Pose(Trainer):
         if code.DIMENSION is not None and not code.EXTERNAL_CODE and code.TRAIN:
             add('optimizerClipCode', [self.model.clips_code], cfg.TRAIN.LR * code.LR_SCALING)
         self.reducer = dp.GradReducer(self.optimizers.values())
+        # DDP-constructor semantics (voice2pose.py:222-223): every rank starts from rank 0's parameters, buffers and Adam state
+        dp.sync_replicas(self.model, list(self.optimizers.values()))
         if self.reducer.active:
             # Gradient buckets in the order backward completes them (the flat buffer is laid out audio encoder L0..L7,
-            # U-Net, decoder): [U-Net + decoder, ~14 MB] when backward reaches the audio encoder, [L5..L7, ~11 MB] when it
-            # leaves L5; the remaining ~3 MB (L0..L4) and the code table go out right before the optimiser step.
+            # U-Net, decoder): [U-Net + decoder, ~14 MB] when backward reaches the audio encoder, then [L5..L7, ~11 MB],
+            # [L3..L4, 2.2 MB] and [L1..L2, 0.5 MB] as backward leaves those blocks; only L0 (2.3 KB) and the code table
+            # (0.5 MB) go out after backward, right before the optimiser step.
             optg = self.optimizers['optimizerG']
             names = [n for n, p in self.model.netG.named_parameters() if p.requires_grad]
             first = next((i for i, n in enumerate(names) if not n.startswith('audio_encoder.')), None)
@@ -210,15 +220,23 @@ class Voice2Pose(Trainer):
                     return None
 
                 self.model.netG.post_encoder_grad_hook = _launch_late_layers
-                l5 = next((i for i, n in enumerate(names) if n.startswith('audio_encoder.specgram_encoder_2d.2.1.')), None)
-                if l5 is not None and all(n.startswith('audio_encoder.') for n in names[l5:first]):
-                    lo5 = optg.offsets[l5]
+                hooks, hi = {}, lo
+                for blk in self.ENCODER_BUCKET_BLOCKS:  # descending: backward order
+                    pre = 'audio_encoder.specgram_encoder_2d.%d.%d.' % (blk // 2, blk % 2)
+                    i0 = next((i for i, n in enumerate(names) if n.startswith(pre)), None)
+                    if i0 is None or not all(n.startswith('audio_encoder.') for n in names[i0:first]):
+                        break
+                    lo_b = optg.offsets[i0]
 
-                    def _launch_l5_to_l7(grad, _optg=optg, _lo=lo5, _hi=lo, _r=reducer):
+                    def _launch_block_range(grad, _optg=optg, _lo=lo_b, _hi=hi, _r=reducer):
                         _r.launch(_optg, _lo, _hi)
                         return None
 
-                    self.model.netG.audio_encoder.grad_bucket_hooks = {5: _launch_l5_to_l7}
+                    hooks[blk] = _launch_block_range
+                    hi = lo_b
+                self.model.netG.audio_encoder.grad_bucket_hooks = hooks
+
+    ENCODER_BUCKET_BLOCKS = (5, 3, 1)  # a hook on the INPUT gradient of these audio-encoder blocks closes a bucket
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, batch, want_final=False):

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 }
 
 
+#ifdef SDT_TUNING  // rejected experiment, kept only in the tuning build (tools/conv_bench.py)
 // ---------------------------------------------------------------------------------------------
 // conv_taps with asynchronous global->LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, two
 // LDS buffers and ONE barrier per K step.  An LDS-DMA writes wave-uniform base + lane*16 B, so a tile is stored as
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(256) void conv_taps_dma_kernel(const float* __restr
         if (off >= 0 && nok) Y[(size_t)off + n] = acc[r] + bv;
     }
 }
+
+#endif  // SDT_TUNING
 
 // ---------------------------------------------------------------------------------------------
 // conv_taps on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 in HBM, fp32 accumulate.
@@ -1161,6 +1164,7 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         }
         return;
     }
+#ifdef SDT_TUNING  // ablation / A-B instantiations (some compute WRONG results by design): tuning build only
     static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // tuning experiments
     if (vec4 && prio == 1)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
@@ -1190,7 +1194,9 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 14>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4)
+    else
+#endif
+    if (vec4)
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
     else
         hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
@@ -1210,8 +1216,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int taps_variant(const sdt_conv_geom* g, bool aligned) {
     const int vec4 = ((g->Cin % BK == 0) && aligned) ? 1 : 0;  // whole 32-channel K chunks: no channel mask in the loop
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    static const int forced = getenv("SDT_CONV_TILE") ? atoi(getenv("SDT_CONV_TILE")) : 0;  // tuning experiments only
+#ifdef SDT_TUNING
+    static const int forced = getenv("SDT_CONV_TILE") ? atoi(getenv("SDT_CONV_TILE")) : 0;
     if (forced == 64064 || forced == 64128 || forced == 128064 || forced == 128128) return forced * 10 + vec4;
+#endif
     // Measured on MI355X (profiles/r01_tile_sweep.txt): the 64x64 tile (54 VGPR + 16 AGPR -> 7 waves/SIMD) beats the
     // 128-wide tiles on every layer of the hot path (92-121 vs 55-113 TFLOP/s): the fp32 MFMA is slow enough that LDS
     // reuse is irrelevant, while occupancy hides the gather latency and the small tile quantises better over 256 CUs.
@@ -1243,9 +1251,11 @@ extern "C" int sdt_conv_taps_splitk_f32(const float* x, const float* w, const fl
     const bool vec4 = var % 10;
     hipStream_t s = (hipStream_t)stream;
     switch (var / 10) {
+#ifdef SDT_TUNING  // the tile sweep of profiles/r01_tile_sweep.txt; production uses 64x64 everywhere
         case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
         case 64128: launch_taps<64, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
         case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
+#endif
         default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
     }
     SDT_LAUNCH_CHECK();
@@ -1270,6 +1280,7 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
     const int M = g->B * g->Ho * g->Wo;
     const size_t ysize = (size_t)g->B * g->Hy * g->Wy * g->Cout;
     dim3 grid(cdiv(M, 64) * cdiv(g->Cout, 64), 1, 1);
+#ifdef SDT_TUNING
     static const int order = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // A/B only
     if (order == 12)
         hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
@@ -1278,6 +1289,7 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
         hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
                            (float*)nullptr, ysize, stats, rows_per_group);
     else
+#endif
         hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
                            (float*)nullptr, ysize, stats, rows_per_group);
     SDT_LAUNCH_CHECK();
@@ -1322,8 +1334,10 @@ static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, con
 
 static int dw_variant(const sdt_conv_geom* g, bool aligned) {
     const int vec4 = ((g->Cin % 4 == 0) && (g->Cout % 4 == 0) && aligned) ? 1 : 0;
-    static const int forced = getenv("SDT_DW_TILE") ? atoi(getenv("SDT_DW_TILE")) : 0;  // tuning experiments only
+#ifdef SDT_TUNING
+    static const int forced = getenv("SDT_DW_TILE") ? atoi(getenv("SDT_DW_TILE")) : 0;
     if (forced == 64064 || forced == 128064 || forced == 64128 || forced == 128128) return forced * 10 + vec4;
+#endif
     // 64x64 everywhere (42 VGPR + 16 AGPR -> 8 waves/SIMD): on par or better than the larger tiles on every layer and
     // a quarter of the atomic traffic per workgroup (profiles/r01_tile_sweep.txt)
     return 64064 * 10 + vec4;
@@ -1338,9 +1352,11 @@ extern "C" int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const
     const bool vec4 = var % 10;
     hipStream_t s = (hipStream_t)stream;
     switch (var / 10) {
+#ifdef SDT_TUNING
         case 128128: launch_dw<128, 128>(vec4, x, dy, dw, *g, s); break;
         case 128064: launch_dw<128, 64>(vec4, x, dy, dw, *g, s); break;
         case 64128: launch_dw<64, 128>(vec4, x, dy, dw, *g, s); break;
+#endif
         default: launch_dw<64, 64>(vec4, x, dy, dw, *g, s); break;
     }
     SDT_LAUNCH_CHECK();

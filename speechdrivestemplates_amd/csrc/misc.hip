@@ -224,8 +224,10 @@ __device__ __forceinline__ int kl_dp(int D) {
     return Dp;
 }
 
+// A row index outside [0, N) (a clip index beyond a table loaded from a smaller checkpoint) never touches memory: the gathered
+// code becomes NaN -- which poisons the prediction and every loss, so the failure is loud -- and backward skips that row.
 __global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
-                                                          int B, int D, float lambda, float* __restrict__ code,
+                                                          int N, int B, int D, float lambda, float* __restrict__ code,
                                                           float* __restrict__ loss, int* __restrict__ valid) {
     __shared__ float sRed[256];
     __shared__ float sTerm[256];
@@ -235,7 +237,10 @@ __global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restric
     const bool active = d < D;
     if (threadIdx.x == 0) sBad = 0;
     if (active)
-        for (int b = g; b < B; b += G) code[(size_t)b * D + d] = table[(size_t)idx[b] * D + d];
+        for (int b = g; b < B; b += G) {
+            const int64_t r = idx[b];
+            code[(size_t)b * D + d] = (r >= 0 && r < N) ? table[(size_t)r * D + d] : __builtin_nanf("");
+        }
     __syncthreads();
     const KlCol c = kl_column_stats([&](int b) { return code[(size_t)b * D + d]; }, B, d, g, G, Dp, active, sRed);
     if (g == 0) {
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void code_kl_fwd_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void code_kl_bwd_kernel(const float* __restrict__ code, const int* __restrict__ valid,
                                                           const float* __restrict__ gout, const int64_t* __restrict__ idx,
-                                                          int B, int D, float lambda, float* __restrict__ dtable) {
+                                                          int N, int B, int D, float lambda, float* __restrict__ dtable) {
     __shared__ float sRed[256];
     if (valid[0] == 0) return;  // uniform
     const int Dp = kl_dp(D), G = 256 / Dp;
@@ -268,7 +273,10 @@ __global__ __launch_bounds__(256) void code_kl_bwd_kernel(const float* __restric
     const float k = gout[0] * lambda * 0.5f / (float)D;
     const float dmu = k * 2.f * c.mu / (float)B;
     const float dvar = k * (1.f - 1.f / c.var) * 2.f / (float)(B - 1);
-    for (int b = g; b < B; b += G) atomicAdd(&dtable[(size_t)idx[b] * D + d], dmu + dvar * (code[(size_t)b * D + d] - c.mu));
+    for (int b = g; b < B; b += G) {
+        const int64_t r = idx[b];
+        if (r >= 0 && r < N) atomicAdd(&dtable[(size_t)r * D + d], dmu + dvar * (code[(size_t)b * D + d] - c.mu));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -479,11 +487,12 @@ __global__ __launch_bounds__(320) void mel_fb_kernel(const float* __restrict__ s
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
-                                                               float* __restrict__ dst, int B, int D) {
+                                                               float* __restrict__ dst, int N, int B, int D) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * D) return;
     const int d = i % D, b = i / D;
-    atomicAdd(&dst[(size_t)idx[b] * D + d], src[i]);
+    const int64_t r = idx[b];
+    if (r >= 0 && r < N) atomicAdd(&dst[(size_t)r * D + d], src[i]);  // rows outside the table are dropped (see code_kl_fwd_kernel)
 }
 
 __global__ __launch_bounds__(256) void time_diff_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T,
@@ -564,17 +573,17 @@ extern "C" int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const flo
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
-extern "C" int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int B, int D, float lambda, float* code_out,
+extern "C" int sdt_code_kl_fwd_f32(const float* table, const int64_t* idx, int N, int B, int D, float lambda, float* code_out,
                                    float* loss, int32_t* valid, void* stream) {
-    SDT_CHECK_ARG(table && idx && code_out && loss && valid && B > 0 && D > 0 && D <= 256, "bad argument");
-    hipLaunchKernelGGL(code_kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, idx, B, D, lambda, code_out, loss, valid);
+    SDT_CHECK_ARG(table && idx && code_out && loss && valid && N > 0 && B > 0 && D > 0 && D <= 256, "bad argument");
+    hipLaunchKernelGGL(code_kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, idx, N, B, D, lambda, code_out, loss, valid);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
-extern "C" int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* gout, const int64_t* idx, int B, int D,
-                                   float lambda, float* dtable, void* stream) {
-    SDT_CHECK_ARG(code && valid && gout && idx && dtable && B > 1 && D > 0 && D <= 256, "bad argument");
-    hipLaunchKernelGGL(code_kl_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, code, valid, gout, idx, B, D, lambda, dtable);
+extern "C" int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* gout, const int64_t* idx, int N, int B,
+                                   int D, float lambda, float* dtable, void* stream) {
+    SDT_CHECK_ARG(code && valid && gout && idx && dtable && N > 0 && B > 1 && D > 0 && D <= 256, "bad argument");
+    hipLaunchKernelGGL(code_kl_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, code, valid, gout, idx, N, B, D, lambda, dtable);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
@@ -619,9 +628,9 @@ extern "C" int sdt_mel_fb_f32(const float* spec, const float* fb, const int32_t*
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
-extern "C" int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int B, int D, void* stream) {
-    SDT_CHECK_ARG(src && idx && dst && B > 0 && D > 0, "bad argument");
-    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, B, D);
+extern "C" int sdt_rows_scatter_add_f32(const float* src, const int64_t* idx, float* dst, int N, int B, int D, void* stream) {
+    SDT_CHECK_ARG(src && idx && dst && N > 0 && B > 0 && D > 0, "bad argument");
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, N, B, D);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -18,6 +18,73 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def broadcast_tensors(tensors, src=0):
+    """Overwrite every tensor of ``tensors`` on every rank with rank ``src``'s contents.  Tensors of one dtype travel in
+    one flattened message (DDP's constructor does the same with its coalesced ``_sync_params_and_buffers``)."""
+    if world_size() == 1:
+        return 0
+    by_dtype = {}
+    for t in tensors:
+        if t is not None and t.numel():
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    n = 0
+    for (_dtype, _dev), group in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.detach().reshape(-1) for t in group])
+        dist.broadcast(flat, src)
+        off = 0
+        with torch.no_grad():
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))  # works for any stride pattern (weights live (Cout,*k,Cin))
+                off += t.numel()
+        n += flat.numel()
+    return n
+
+
+def replica_state(model, optimizers):
+    """Everything that defines a replica: the optimisers' flat parameter / moment / step / lr buffers, every parameter that is
+    not a view into one of them (the no-grad pose encoder, a frozen code table), every registered buffer (BatchNorm running
+    statistics and counters, the mel window / filterbank, pose2pose's per-clip code buffers) and plain-tensor attributes such as
+    external clip codes."""
+    out, owned = [], set()
+    for opt in optimizers:
+        out += [opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.state_dev, opt.lr_dev]
+        lo = opt.flat_param.data_ptr()
+        owned.add((lo, lo + opt.flat_param.numel() * 4))
+    for p in model.parameters():
+        if not any(lo <= p.data_ptr() < hi for lo, hi in owned):
+            out.append(p.data)
+    out += list(model.buffers())
+    ext = getattr(model, 'clips_code', None)
+    if torch.is_tensor(ext) and not isinstance(ext, torch.nn.Parameter):
+        out.append(ext)
+    return out
+
+
+def sync_replicas(model, optimizers, src=0):
+    """DistributedDataParallel's constructor semantics (reference core/pipelines/voice2pose.py:222-223, pose2pose.py:102):
+    rank ``src``'s parameters and buffers -- and here also the Adam state, so a resumed run is consistent too -- replace every
+    other rank's.  Without it ranks that were not seeded identically would apply the same averaged gradient to different
+    weights for the whole run.  Returns the number of elements sent."""
+    if world_size() == 1:
+        return 0
+    n = broadcast_tensors(replica_state(model, optimizers), src)
+    for opt in optimizers:
+        opt.mirrors.mark_dirty()  # weights were rewritten behind the mirrors' back
+        opt._lr_host = float(opt.lr_dev.item())
+        opt.param_groups[0]['lr'] = opt._lr_host
+    return n
+
+
+def sync_buffers(model, src=0):
+    """DDP's ``broadcast_buffers=True`` re-sends rank 0's buffers at the start of EVERY forward.  This engine
+    keeps buffers rank-local during training steps -- no collective on the step's critical path -- and calls this where the
+    difference would otherwise be observable: before validation / test (eval-mode BatchNorm reads the running statistics) and
+    before a checkpoint is written.  Rank 0 never receives in either scheme, so what rank 0 holds and saves is bit-identical
+    to DDP's: its own batches' BatchNorm statistics and, for pose2pose, its own clips' codes (the reference's other ranks'
+    writes to ``clip_code_mu/logvar`` are overwritten by the next broadcast, pose2pose.py:135-137)."""
+    return broadcast_tensors(list(model.buffers()), src)
+
+
 class GradReducer:
     def __init__(self, optimizers, overlap=True):
         self.optimizers = list(optimizers)

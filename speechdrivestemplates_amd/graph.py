@@ -30,22 +30,36 @@ class GraphedStep:
 
     @staticmethod
     def _clone_batch(batch):
-        def cp(v):
+        """Static device copies of every tensor field (``num_frames`` stays where it is: it is read on the host)."""
+        dev = torch.device('cuda', torch.cuda.current_device())
+
+        def cp(k, v):
             if torch.is_tensor(v):
-                return v.clone()
+                return v.clone() if (k == 'num_frames' or v.is_cuda) else v.to(dev)
             if isinstance(v, dict):
-                return {k: cp(x) for k, x in v.items()}
+                return {kk: cp(kk, x) for kk, x in v.items()}
             return v
-        return {k: cp(v) for k, v in batch.items()}
+        return {k: cp(k, v) for k, v in batch.items()}
 
     @staticmethod
     def _copy_into(dst, src):
+        """Refresh the captured graph's static inputs.  Host tensors are copied H2D as well (a DataLoader batch); the one field
+        the step reads on the HOST at capture time, ``num_frames``, and every shape must equal the captured ones -- a replay
+        cannot follow them, so a mismatch raises instead of silently replaying the captured batch."""
         for k, v in src.items():
             if torch.is_tensor(v):
-                if v.is_cuda:
-                    dst[k].copy_(v, non_blocking=True)
+                if v.shape != dst[k].shape or v.dtype != dst[k].dtype:
+                    raise RuntimeError('GraphedStep: field %r changed shape/dtype since capture (%s %s -> %s %s)'
+                                       % (k, tuple(dst[k].shape), dst[k].dtype, tuple(v.shape), v.dtype))
+                if k == 'num_frames':
+                    if not torch.equal(v.cpu(), dst[k].cpu()):
+                        raise RuntimeError('GraphedStep: num_frames differs from the captured value')
+                    continue
+                dst[k].copy_(v, non_blocking=True)
             elif isinstance(v, dict):
                 GraphedStep._copy_into(dst[k], v)
+            elif v != dst[k] and k != 'speaker':
+                raise RuntimeError('GraphedStep: non-tensor field %r differs from the captured value' % k)
 
     def run(self, batch):
         """One training step on ``batch`` (device tensors with the collated layout).  The first ``warmup`` calls run

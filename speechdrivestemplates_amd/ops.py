@@ -273,6 +273,41 @@ class ConvProfiler:
 PROFILER = None  # set to a ConvProfiler instance to time conv launches
 
 
+class StageTimer:
+    """HIP-event windows around the four pieces of the Conv1d stage of a train step (bench.py's ``roofline_conv1d`` leg):
+    generator 1-D forward and backward chains on the main stream, the no-grad pose-encoder passes and the deferred 1-D
+    weight-gradient batch on the side stream.  ``mark`` records on torch's current stream.  Off by default."""
+
+    def __init__(self):
+        self.marks = []  # (name, event)
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def windows_us(self):
+        torch.cuda.synchronize()
+        out, open_ = {}, {}
+        for name, e in self.marks:
+            base, edge = name.rsplit(":", 1)
+            if edge == "begin":
+                open_[base] = e
+            elif base in open_:
+                d = out.setdefault(base, [0, 0.0])
+                d[0] += 1
+                d[1] += open_.pop(base).elapsed_time(e) * 1e3
+        return out
+
+
+STAGES = None  # set to a StageTimer instance to time the Conv1d stage windows
+
+
+def stage_mark(name):
+    if STAGES is not None:
+        STAGES.mark(name)
+
+
 def _conv_launch(kind, is2d, g, call):
     if PROFILER is None:
         check(call())
@@ -513,8 +548,10 @@ def flush_deferred_dw():
     side = _side_stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
+        stage_mark("dw1d:begin")
         for x_cl, gy, w, stride, pad in _DEFERRED:
             conv_weight_grad(x_cl, gy, w, stride, pad)
+        stage_mark("dw1d:end")
     for x_cl, gy, _w, _s, _p2 in _DEFERRED:
         gy.record_stream(side)
         x_cl.record_stream(side)
@@ -877,16 +914,24 @@ class CodeGatherKLFn(torch.autograd.Function):
     The gradient of both outputs is scatter-ACCUMULATED into the dense ``table.grad``."""
 
     @staticmethod
-    def forward(ctx, table, idx, lam):
+    def forward(ctx, table, idx, lam, allow_single=False):
         _req_cuda(table, idx)
         B, D = idx.shape[0], table.shape[1]
-        code = torch.empty((B, D), device=table.device, dtype=torch.float32)
-        loss = torch.empty((), device=table.device, dtype=torch.float32)
-        valid = torch.empty((), device=table.device, dtype=torch.int32)
+        table = table.contiguous()
         idx = idx.contiguous()
         if B > 1:
-            check(_lib.load().sdt_code_kl_fwd_f32(_p(table), _p(idx), B, D, lam, _p(code), _p(loss), _p(valid), _stream()))
-        else:  # a single sample has no batch variance (torch.var -> nan != 0 -> the reference adds a nan term)
+            code = torch.empty((B, D), device=table.device, dtype=torch.float32)
+            loss = torch.empty((), device=table.device, dtype=torch.float32)
+            valid = torch.empty((), device=table.device, dtype=torch.int32)
+            check(_lib.load().sdt_code_kl_fwd_f32(_p(table), _p(idx), table.shape[0], B, D, lam, _p(code), _p(loss), _p(valid),
+                                                  _stream()))
+        elif allow_single and not table.requires_grad:
+            # validation / test with a last batch of one clip: torch.var of a single sample is nan, nan != 0, and the
+            # reference adds that nan KL term to the batch's losses (voice2pose.py:152-157) -- mirrored, no crash mid-run
+            code = table[idx].clone()
+            loss = torch.full((), float('nan'), device=table.device, dtype=torch.float32)
+            valid = torch.ones((), device=table.device, dtype=torch.int32)
+        else:  # training batches come from a drop_last loader (trainer.py:75-77): B == 1 there is a configuration error
             raise RuntimeError("clip-code KL needs a batch of at least 2 clips")
         ctx.save_for_backward(code, valid, idx, table)
         ctx.lam = lam
@@ -898,18 +943,19 @@ class CodeGatherKLFn(torch.autograd.Function):
     def backward(ctx, gcode, gloss, _gvalid):
         code, valid, idx, table = ctx.saved_tensors
         if not table.requires_grad:
-            return None, None, None
+            return None, None, None, None
         lib = _lib.load()
         B, D = code.shape
+        N = table.shape[0]
         gt = grad_buffer(table)
         st = _stream()
         if gcode is not None:
             gcode = gcode.contiguous()
-            check(lib.sdt_rows_scatter_add_f32(_p(gcode), _p(idx), _p(gt), B, D, st))
+            check(lib.sdt_rows_scatter_add_f32(_p(gcode), _p(idx), _p(gt), N, B, D, st))
         if gloss is not None:
             gloss = gloss.contiguous()
-            check(lib.sdt_code_kl_bwd_f32(_p(code), _p(valid), _p(gloss), _p(idx), B, D, ctx.lam, _p(gt), st))
-        return None, None, None
+            check(lib.sdt_code_kl_bwd_f32(_p(code), _p(valid), _p(gloss), _p(idx), N, B, D, ctx.lam, _p(gt), st))
+        return None, None, None, None
 
 
 class TimeDiffFn(torch.autograd.Function):

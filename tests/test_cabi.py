@@ -23,3 +23,13 @@ def test_plain_c_program_links_and_calls_the_library(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "C ABI OK" in out.stdout and "last error:" in out.stdout
+
+
+def test_product_library_has_no_tuning_switches():
+    """The ablation / A-B instantiations of the conv kernels (some compute wrong results by design) are compiled only with
+    -DSDT_TUNING into a separate library; the shipped one must not even contain the names of the environment switches."""
+    from speechdrivestemplates_amd import _lib
+    _lib.load()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"SDT_CONV_PRIO", b"SDT_CONV_TILE", b"SDT_DW_TILE", b"conv_taps_dma_kernel"):
+        assert name not in blob, name

@@ -107,3 +107,124 @@ def test_two_rank_gradient_exchange_matches_single_process():
     assert touched0 == touched1 == [0, 1, 2, 3], (touched0, touched1)  # rows of BOTH ranks, present on both
     assert mean_rank == 0.5  # rank 0 holds the mean over ranks after the packed reduce
     assert abs(mean_loss - 0.5 * (loss0 + loss1)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Replica synchronisation (DDP-constructor semantics, reference voice2pose.py:222-223) with DIFFERENT per-rank seeds
+# ------------------------------------------------------------------------------------------------------------------
+class _CpuFlatAdam:
+    """CPU stand-in with optim.FlatAdam's attribute surface (the real one launches a HIP kernel): parameters re-homed
+    into one flat buffer in the kernels' (Cout,k,Cin) memory order, torch's Adam rule on the flat views."""
+
+    class _Mirrors:
+        dirty = False
+
+        def mark_dirty(self):
+            self.dirty = True
+
+    def __init__(self, params, lr):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        self.flat_param, self.flat_grad = torch.zeros(n), torch.zeros(n)
+        self.exp_avg, self.exp_avg_sq = torch.zeros(n), torch.zeros(n)
+        self.state_dev, self.lr_dev = torch.zeros(2, dtype=torch.int64), torch.tensor([lr])
+        self.param_groups, self._lr_host, self.grad_scale, self.mirrors = [dict(lr=lr)], lr, 1.0, self._Mirrors()
+        off = 0
+        self.views = []
+        for p in self.params:
+            perm = [0] + list(range(2, p.dim())) + [1] if p.dim() >= 3 else list(range(p.dim()))
+            inv = [perm.index(d) for d in range(p.dim())]
+            shape = [p.shape[d] for d in perm]
+            view = self.flat_param[off:off + p.numel()].view(shape)
+            view.copy_(p.data.permute(perm))
+            p.data = view.permute(inv)  # a strided view, like FlatAdam's
+            self.views.append((off, shape, inv))
+            off += p.numel()
+
+    def step(self):
+        self.state_dev[0] += 1
+        t = int(self.state_dev[0])
+        g = self.flat_grad * self.grad_scale
+        self.exp_avg.mul_(0.9).add_(g, alpha=0.1)
+        self.exp_avg_sq.mul_(0.999).addcmul_(g, g, value=0.001)
+        denom = (self.exp_avg_sq / (1 - 0.999 ** t)).sqrt_().add_(1e-8)
+        self.flat_param.addcdiv_(self.exp_avg / (1 - 0.9 ** t), denom, value=-float(self.lr_dev))
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from speechdrivestemplates_amd import dp
+    torch.manual_seed(100 + rank)  # deliberately different initialisation per rank
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv1d(6, 8, 3, padding=1, bias=False)
+            self.bn = torch.nn.BatchNorm1d(8)
+            self.head = torch.nn.Conv1d(8, 4, 1)
+            self.frozen = torch.nn.Conv1d(4, 4, 1)  # a module without an optimiser (the no-grad pose encoder's role)
+            self.register_buffer("codes", torch.randn(5, 3))
+
+        def forward(self, x):
+            return self.frozen(self.head(torch.relu(self.bn(self.conv(x)))))
+
+    net = Net()
+    with torch.no_grad():
+        net.bn.running_mean.normal_()
+    opt = _CpuFlatAdam(list(net.conv.parameters()) + list(net.bn.parameters()) + list(net.head.parameters()), lr=1e-2 * (1 + rank))
+    opt.exp_avg.normal_()  # pretend a resumed optimiser state that differs per rank
+    opt.state_dev[0] = 3 + rank
+    before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    n_sent = dp.sync_replicas(net, [opt])
+    assert n_sent > 0 and opt.mirrors.dirty
+    # the strided parameter views still alias the flat buffer after the broadcast
+    assert net.conv.weight.data_ptr() == opt.flat_param.data_ptr()
+    state = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [b.detach().double().reshape(-1).float() for b in net.buffers()]
+                      + [opt.exp_avg, opt.exp_avg_sq, opt.state_dev.float(), opt.lr_dev])
+    # two data-parallel steps: per-rank batch, summed gradients, 1/world folded into the update
+    red = dp.GradReducer([opt], overlap=False)
+    x_all = torch.randn(2 * world, 6, 10, generator=torch.Generator().manual_seed(7))
+    for step in range(2):
+        for p in net.parameters():
+            p.grad = None
+        net.train()
+        loss = net(x_all[rank * 2:(rank + 1) * 2] + step).pow(2).mean()
+        loss.backward()
+        off = 0
+        for p, (o, shape, inv) in zip(opt.params, opt.views):
+            perm = [inv.index(d) for d in range(p.dim())]
+            opt.flat_grad[o:o + p.numel()].view(shape).copy_(p.grad.permute(perm))
+        red.all_reduce()
+        opt.step()
+    weights = opt.flat_param.clone()
+    bn_stats = net.bn.running_mean.clone()  # rank-local during training ...
+    dp.sync_buffers(net)  # ... and taken from rank 0 before validation / checkpoint
+    q.put((rank, before.numpy(), state.numpy(), weights.numpy(), bn_stats.numpy(), net.bn.running_mean.numpy().copy(), float(opt._lr_host)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_replicas_start_identical_despite_different_seeds_and_stay_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=250) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, before0, state0, w0, bn_local0, bn_synced0, lr0), (_, before1, state1, w1, bn_local1, bn_synced1, lr1) = res
+    import numpy as np
+    assert not np.array_equal(before0, before1)  # the seeds really differed
+    assert np.array_equal(state0, state1)  # parameters (incl. the optimiser-less module), buffers, Adam moments, step, lr
+    assert np.array_equal(state0[:before0.size], before0)  # ... and they are rank 0's
+    assert lr0 == lr1 == pytest.approx(1e-2)
+    assert np.array_equal(w0, w1)  # same averaged gradient applied to the same weights: replicas stay identical
+    assert not np.array_equal(bn_local0, bn_local1)  # BatchNorm running statistics are per-rank during training (no SyncBN) ...
+    assert np.array_equal(bn_synced0, bn_local0) and np.array_equal(bn_synced1, bn_local0)  # ... rank 0's win at sync points

@@ -80,7 +80,8 @@ def test_two_ranks_one_gpu_match_single_process_full_batch():
         assert p.exitcode == 0
     ref_sd, ref_losses, _ = _run(1, 0)
     (_, sd0, l0, launches0), (_, sd1, l1, _) = res
-    assert len(launches0) == 3 * STEPS  # per step: U-Net/decoder and L5..L7 from the backward hooks, then the L0..L4 range
+    # per step: U-Net/decoder, L5..L7, L3..L4, L1..L2 from the backward hooks, then the L0 range before the optimiser step
+    assert len(launches0) == 5 * STEPS, launches0
     for k, ref in ref_sd.items():
         a, b = torch.from_numpy(sd0[k]), torch.from_numpy(sd1[k])
         assert torch.equal(a, b), k  # both ranks applied the same averaged gradient with the same kernel
@@ -93,3 +94,52 @@ def test_two_ranks_one_gpu_match_single_process_full_batch():
     # step-0 loss of the full batch is the mean of the two half-batch losses; step-1 losses agree after the update
     assert abs(0.5 * (l0[0] + l1[0]) - ref_losses[0]) <= 2e-6 * abs(ref_losses[0]) + 1e-7
     assert abs(0.5 * (l0[1] + l1[1]) - ref_losses[1]) <= 2e-3 * abs(ref_losses[1])
+
+
+def _seed_worker(rank, world, port, q):
+    """Random (module-default) initialisation under a DIFFERENT torch seed per rank, as a launcher that forgets to seed would
+    produce: setup_optimizer must make the replicas identical (rank 0's weights) and they must stay identical."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, REPO)
+    from oracle import sdt_oracle as O
+    from __graft_entry__ import make_pipeline
+    torch.manual_seed(1234 + rank)
+    for cfg_name in ("voice2pose_sdt_bp", "voice2pose_s2g"):
+        pipe, _ = make_pipeline(cfg_name, N_CLIPS, batch_global=2 * B_RANK)
+        w_init = pipe.optimizers["optimizerG"].flat_param.detach().cpu().clone()
+        for step in range(STEPS):
+            full = O.make_batch(B_RANK * 2, N_CLIPS, step=step, seed=1)
+            if cfg_name == "voice2pose_s2g":
+                full["speaker"] = ["synthetic"] * (2 * B_RANK)
+            losses, _ = pipe.forward_backward(_slice(full, rank * B_RANK, (rank + 1) * B_RANK))
+            pipe.optimizer_updates(losses)
+        torch.cuda.synchronize()
+        out = {k: v.detach().cpu().numpy() for k, v in pipe.model.state_dict().items() if v.is_floating_point()}
+        q.put((rank, cfg_name, w_init.numpy(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_differently_seeded_ranks_are_synchronised_at_construction():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in range(4)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for cfg_name in ("voice2pose_sdt_bp", "voice2pose_s2g"):
+        (r0, _, init0, sd0), (r1, _, init1, sd1) = sorted((r for r in res if r[1] == cfg_name), key=lambda t: t[0])
+        assert np.array_equal(init0, init1), cfg_name  # rank 1 trains rank 0's initial weights, not its own draw
+        for k in sd0:
+            if "running_" in k:
+                continue  # BatchNorm running statistics are rank-local by design (no SyncBN; DESIGN.md section 4)
+            assert np.array_equal(sd0[k], sd1[k]), (cfg_name, k)
+        if cfg_name == "voice2pose_s2g":  # per-rank batch statistics: the buffers do differ
+            assert any(not np.array_equal(sd0[k], sd1[k]) for k in sd0 if "running_mean" in k)

@@ -1,10 +1,14 @@
 """GPU parity tests, one per kernel family: each libsdt_hip.so entry point (called through the C ABI via
 speechdrivestemplates_amd.ops) against a float64 torch-CPU statement of the same reference operator on
 seeded inputs.  Tolerances are relative to the reference's max magnitude and written next to each check."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+from conftest import REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -331,6 +335,26 @@ def test_code_gather_kl(ops):
     ref[idx] = gcode
     check("zero-var: only gather grad", td0.grad, ref, 1e-7)
     assert O.clip_code_kl(t0[idx], 0.1) is None
+    # a clip index beyond the table (an EXTERNAL_CODE table from a smaller checkpoint): the reference raises IndexError; the
+    # kernels must not touch memory outside the table -- the gathered row is NaN (loud) and its gradient row is dropped
+    bad = idx.clone()
+    bad[2] = N + 7
+    td1 = torch.nn.Parameter(table.float().to(DEV))
+    guard = torch.full((4 * N * D,), 3.0, device=DEV)  # the table's neighbourhood in the allocator: must stay untouched
+    c1, k1, v1 = ops.CodeGatherKLFn.apply(td1, bad.to(DEV), 0.1)
+    assert torch.isnan(c1[2]).all() and torch.isfinite(c1[[0, 1, 3, 4, 5, 6, 7]]).all() and torch.isnan(k1)
+    (c1 * gcode.float().to(DEV)).sum().backward()
+    ok = [i for i in range(B) if i != 2]
+    ref1 = torch.zeros(N, D, dtype=torch.float64)
+    ref1[idx[ok]] = gcode[ok]
+    check("out-of-range row: gradient dropped", td1.grad, ref1, 1e-7)
+    assert bool((guard == 3.0).all())
+    # B == 1 outside training (last validation batch of one clip): the reference's torch.var gives nan and the nan KL term is
+    # added (voice2pose.py:152-157) -- no exception; in training it stays a configuration error
+    c2, k2, v2 = ops.CodeGatherKLFn.apply(table.float().to(DEV), idx[:1].to(DEV), 0.1, True)
+    assert torch.equal(c2.cpu(), table.float()[idx[:1]]) and torch.isnan(k2) and int(v2) == 1
+    with pytest.raises(RuntimeError):
+        ops.CodeGatherKLFn.apply(td, idx[:1].to(DEV), 0.1)
 
 
 def test_final_metrics(ops):
@@ -566,3 +590,28 @@ def test_conv_epilogue_statistics_match_the_separate_pass(ops, norm, groups):
         e64, esep = l2(outs[0][i], ref), l2(outs[0][i], outs[1][i])
         print("  %s fused block %s: L2 error vs float64 %.2e, vs separate pass %.2e" % (norm, name, e64, esep))
         assert e64 < 3e-3 and esep < 1e-5, (name, e64, esep)  # the kink flips are shared by both fp32 paths
+
+
+def test_tuning_environment_switches_are_ignored_by_the_product_library(tmp_path):
+    """SDT_CONV_PRIO=3 used to select a "no global loads" ablation kernel (wrong results) inside libsdt_hip.so.  Those
+    instantiations now live in the -DSDT_TUNING build only: with the variable set, the product library still convolves
+    correctly."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from speechdrivestemplates_amd import ops
+torch.manual_seed(0)
+x = torch.randn(2, 20, 30, 64, device="cuda")
+w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(64, 64, 3, 3, device="cuda") * 0.05))
+y = ops.conv_forward(x, w, None, 1, 1)
+ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.detach().double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+print("ERR", err)
+assert err < 3e-6, err
+''' % REPO
+    for var in ("SDT_CONV_PRIO", "SDT_CONV_TILE"):
+        env = dict(os.environ, **{var: "3" if var == "SDT_CONV_PRIO" else "128128"})
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (var, out.stdout[-2000:], out.stderr[-2000:])

@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """Micro-benchmark of the implicit-GEMM conv kernels on the hot path's layer shapes (B=32 by default).
-   python tools/conv_bench.py [--only L2] [--reps 20] [--roles fwd,dX,dW]"""
+   python tools/conv_bench.py [--only L2] [--reps 20] [--roles fwd,dX,dW]
+The SDT_CONV_PRIO / SDT_CONV_TILE / SDT_DW_TILE experiment switches exist only in the -DSDT_TUNING library: build it with
+`python __graft_entry__.py --tuning` and run this tool with --tuning (or SDT_HIP_LIB=.../libsdt_hip_tuning.so)."""
 import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+if "--tuning" in sys.argv:  # must be set before the package binds the library
+    os.environ["SDT_HIP_LIB"] = os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
 import torch  # noqa: E402
 
 from speechdrivestemplates_amd import ops  # noqa: E402
@@ -21,6 +26,7 @@ LAYERS = [  # name, Hi, Wi, Cin, Cout, kh, kw, s, p
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--tuning", action="store_true", help="load the -DSDT_TUNING library (experiment switches live there)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--roles", default="fwd,dX,dW")

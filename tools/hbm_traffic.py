@@ -12,7 +12,12 @@ included): an upper bound on HBM bytes."""
 import collections
 import csv
 import json
+import os
+import subprocess
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 
 
 def per_kernel(path, counter):
@@ -42,7 +47,16 @@ def main():
     total = {k: (v["fetch_x2_mb_per_launch"] + v["write_mb_per_launch"]) * v["launches"] for k, v in kernels.items()}
     order = sorted(kernels, key=lambda k: -total[k])
     dom = next(k for k in order if k.startswith("conv_taps_kernel"))
+    from bench import kernel_source_digest
+    try:
+        head = subprocess.run(["git", "-C", REPO, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        head = None
+    if head is None and os.path.exists(os.path.join(REPO, "gpurun_out", "git_head.txt")):
+        head = open(os.path.join(REPO, "gpurun_out", "git_head.txt")).read().strip()
     res = {"command": cmd,
+           # bench.py cites this file only while the kernel sources still hash to this digest
+           "kernel_source_digest": kernel_source_digest(), "git_head": head,
            "note": "TCC fabric-side counters (include Infinity-Cache hits): upper bound on HBM bytes. FETCH_SIZE under-reports wide "
                    "coalesced streams by 2x on gfx950 (MI355X_MICROARCH.md): traffic = 2*FETCH + WRITE.",
            "dominant_kernel": dom,
