@@ -65,6 +65,26 @@ int sdt_conv_taps_splitk_hint(const sdt_conv_geom* g);
 int sdt_conv_taps_splitk_f32(const float* x, const float* w, const float* bias, float* y,
                              const sdt_conv_geom* g, int splitk, float* partial, void* stream);
 int sdt_splitk_reduce_f32(const float* partial, const float* bias, float* y, int64_t n, int cout, int splitk, void* stream);
+/* Input gradient of a strided convolution in ONE launch: `ncls` (1..4) output parity classes -- geometries that share X (= dY),
+ * W (= transposed weights) and the Y (= dX) tensor and write disjoint output positions (ATen's conv backward-data,
+ * building_blocks.py:15-22,31-38).  Same split-K contract as sdt_conv_taps_splitk_f32.
+ * nb != NULL (fp32 math, splitk == 1, Cin % 32 == 0): the epilogue also accumulates the per-(group, channel) sums the backward
+ * of the InstanceNorm2d / BatchNorm + LeakyReLU that produced this conv's input needs (building_blocks.py:24-26,46), so that
+ * sdt_colnorm_bwd_f32(stats_ready = 1) skips its statistics pass over dz and y:
+ *   sums[(grp*C + n)*2 + 0] += sum gg,  [..+1] += sum gg*yhat,  gg = dX * act'(gamma*yhat + beta), yhat = (y - mean)*rstd
+ * y = raw output of the conv below (same shape as dX), grp = batch item (groups == B) or 0 (groups == 1); sums zero on entry. */
+typedef struct sdt_norm_bwd {
+    const float* y;
+    const float* mean;  /* [groups*C] */
+    const float* rstd;  /* [groups*C] */
+    const float* gamma; /* [C] or NULL */
+    const float* beta;  /* [C] or NULL */
+    double* sums;       /* [groups*C*2] */
+    float slope;
+    int32_t groups;
+} sdt_norm_bwd;
+int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_conv_geom* geoms, int ncls, int splitk,
+                            float* partial, const sdt_norm_bwd* nb, void* stream);
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);
@@ -118,10 +138,12 @@ int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, flo
 int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
                          int64_t rows, int C, float eps, float slope, void* stream);
-/* bwd: dy <- d(loss)/dy given dz; dgamma/dbeta (nullable) are ACCUMULATED. dy may alias dz. */
+/* bwd: dy <- d(loss)/dy given dz; dgamma/dbeta (nullable) are ACCUMULATED. dy may alias dz.
+ * stats_ready != 0: sums already holds sum gg, sum gg*yhat per (g, c) (accumulated by the epilogue of the input-gradient
+ * conv that produced dz, sdt_conv_taps_multi_f32 with nb) -- the statistics pass over dz and y is skipped. */
 int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, float* dgamma,
-                        float* dbeta, int G, int64_t R, int C, float slope, void* stream);
+                        float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* stream);
 
 /*
  * First audio-encoder block fused for Cin == 1: Conv2d(1,64,k3,s1,p1,bias=False) -> InstanceNorm2d (groups = B) or

@@ -20,6 +20,12 @@ class ConvGeom(C.Structure):
                  "ntaps", "Tw")] + [("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wt", C.c_int32 * MAX_TAPS)]
 
 
+class NormBwd(C.Structure):
+    """Mirror of ``sdt_norm_bwd`` (include/sdt_hip.h)."""
+    _fields_ = [("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("sums", C.c_void_p), ("slope", C.c_float), ("groups", C.c_int32)]
+
+
 class WtDesc(C.Structure):
     """Mirror of ``sdt_wt_desc`` (include/sdt_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32),
@@ -46,7 +52,8 @@ SIGNATURES = {
     "sdt_conv_taps_stats_supported": [_G, _i],
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
-    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p],
+    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p],
+    "sdt_conv_taps_multi_f32": [_p, _p, _p, _p, _i, _i, _p, _p, _p],
     "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],

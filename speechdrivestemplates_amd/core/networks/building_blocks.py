@@ -44,8 +44,10 @@ class ConvNormRelu(nn.Module):
         return (self.conv_type == '2d' and c.in_channels == 1 and c.out_channels == 64 and tuple(c.kernel_size) == (3, 3)
                 and self.stride == 1 and self.padding == 1 and (self.norm_type == 'IN' or self.training))
 
-    def forward_cl(self, x_cl):
-        """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last."""
+    def forward_cl(self, x_cl, in_holder=None, out_holder=None):
+        """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last.
+        ``in_holder`` / ``out_holder`` (ops.NormBwdHolder, 2-D blocks of a strictly sequential chain only): ``x_cl`` is the output of
+        the normalisation that filled ``in_holder`` and has no other consumer; this block's normalisation fills ``out_holder``."""
         if self._is_l0_block():  # single-channel mel image: conv + norm + activation fused, output written once
             n = self.norm
             if self.norm_type == 'IN':
@@ -58,21 +60,21 @@ class ConvNormRelu(nn.Module):
             groups = x_cl.shape[0] if self.norm_type == 'IN' else 1
             if ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups):
                 # the conv's epilogue accumulates the normalisation statistics: y is not re-read for them
-                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups)
+                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)
                 n = self.norm
                 if self.norm_type == 'IN':
-                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums)
+                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums, out_holder)
                 return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
-                                              self.slope, sums)
-        y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding)
+                                              self.slope, sums, out_holder)
+        y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding, in_holder)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W
-                return ops.ColNormActFn.apply(y, None, None, None, None, None, y.shape[0], self.slope)
+                return ops.ColNormActFn.apply(y, None, None, None, None, None, y.shape[0], self.slope, None, out_holder)
             return ops.RowNormActFn.apply(y, self.slope)  # InstanceNorm1d on the permuted tensor == norm over C
         n = self.norm
         if self.training:
             return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
-                                          self.slope)
+                                          self.slope, None, out_holder if self.conv_type == '2d' else None)
         if torch.is_grad_enabled() and y.requires_grad:
             raise RuntimeError("eval-mode BatchNorm is an inference-only path in this engine (wrap in torch.no_grad())")
         return ops.colnorm_eval(y, n.weight, n.bias, n.running_mean, n.running_var, self.slope)

@@ -1,6 +1,7 @@
 """Generator networks with the reference's class names, constructor (cfg), forward signatures and
 state_dict keys (core/networks/keypoints_generation/generator.py:8-117), built from layer tables and run
 channels-last through the gfx950 kernels."""
+import torch
 from torch import nn
 
 from .... import ops
@@ -30,12 +31,15 @@ class AudioEncoder(nn.Module):
         x = mel.unsqueeze(-1)  # (B,H,W,1): the mel image is already channels-last with C=1
         hooks = getattr(self, 'grad_bucket_hooks', None)  # {flat block index: hook on that block's INPUT gradient}
         i = 0
+        holder = None  # the chain is strictly sequential: each block's output feeds exactly the next block's conv
         for stage in self.specgram_encoder_2d:
             for block in stage:
                 if hooks and i in hooks and x.requires_grad:
                     # fires in backward once blocks i.. have produced their weight gradients (dp.GradReducer buckets)
                     x.register_hook(hooks[i])
-                x = block.forward_cl(x)
+                nxt = ops.NormBwdHolder() if (i > 0 and torch.is_grad_enabled()) else None  # block 0 is the fused L0 kernel
+                x = block.forward_cl(x, holder, nxt)
+                holder = nxt if (nxt is not None and nxt.y is not None) else None
                 i += 1
         return x
 

@@ -20,6 +20,28 @@
 // (checked on the host), so SDT_OOB + (in-row offset) is always past num_records and the load returns zeros.
 #define SDT_OOB 0x80000000u
 
+// Up to 4 geometries per launch: the output parity classes of a strided layer's input gradient run as ONE grid
+// (blockIdx.y = class) instead of 4 (2 in the 1-D stage) short launches -- one prologue / tail / launch boundary instead of four.
+#define SDT_MAX_CLASSES 4
+struct geom_pack {
+    sdt_conv_geom g[SDT_MAX_CLASSES];
+};
+// Epilogue of an input-gradient launch that also accumulates the statistics of the normalisation BACKWARD that consumes it
+// (what colstats_kernel<true> would compute in a separate pass over dz and y):
+//   sums[(grp*C + n)*2 + {0,1}] += sum gg, sum gg*yhat,   gg = dz * act'(gamma*yhat + beta),  yhat = (y - mean)*rstd
+// y = raw forward output of the layer below (same shape as the dz tensor this launch writes), grp = batch item (groups == B,
+// InstanceNorm) or 0 (groups == 1, BatchNorm).  sums == nullptr: off.
+struct norm_bwd_args {
+    const float* y;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    double* sums;
+    float slope;
+    int groups;
+};
+
 // ---------------------------------------------------------------------------------------------
 // stats != nullptr: the epilogue also accumulates sum(y) and sum(y^2) per (group, output channel) into ``stats`` (fp64
 // atomics; the buffer must be zero on entry), group = output row index / rows_per_group -- the statistics pass of the
@@ -29,11 +51,13 @@
 template <int BM, int BN, bool VEC4, int PRIO = 0>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
-                                                        const sdt_conv_geom g, const int splitk,
+                                                        const geom_pack gp, const int splitk,
                                                         float* __restrict__ partial, const size_t ysize,
-                                                        double* __restrict__ stats = nullptr, const int rows_per_group = 0) {
+                                                        double* __restrict__ stats, const int rows_per_group,
+                                                        const norm_bwd_args nb) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;
+    const sdt_conv_geom& g = gp.g[blockIdx.y];  // uniform: the class this workgroup belongs to
     __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
     __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
     __shared__ int sOut[BM];
@@ -58,6 +82,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     // share input rows across vertical taps run on the same XCD close in time, so A is fetched into that L2 once
     // (measured before this ordering: L2-miss traffic 9-16x the input bytes on the Cout=256 layers).
     const int nnb = (g.Cout + BN - 1) / BN;
+    if ((int)blockIdx.x >= nmb * nnb) return;  // the grid is sized for the largest class of the launch
     const int lin = xcd_remap(blockIdx.x, nmb * nnb);
     const int m0 = (lin / nnb) * BM;
     const int n0 = (lin % nnb) * BN;
@@ -382,6 +407,55 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     atomicAdd(d, (double)s0);
                     atomicAdd(d + 1, (double)q0);
                     if (mb < m0 + BM && mb < M) {
+                        atomicAdd(d + 2 * (size_t)g.Cout, (double)s1);
+                        atomicAdd(d + 2 * (size_t)g.Cout + 1, (double)q1);
+                    }
+                }
+            }
+            if (nb.sums != nullptr) {  // uniform; statistics of the normalisation backward that consumes this gradient
+                const int rpg = nb.groups == 1 ? M : g.Ho * g.Wo;  // >= BM (host-checked): a tile touches at most two groups
+                const int g0 = m0 / rpg;
+                const int mb = (g0 + 1) * rpg;
+                const bool two = mb < m0 + BM && mb < M;
+                float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f;
+                if (nok) {
+                    mu0 = nb.mean[(size_t)g0 * g.Cout + n];
+                    rs0 = nb.rstd[(size_t)g0 * g.Cout + n];
+                    if (two) {
+                        mu1 = nb.mean[(size_t)(g0 + 1) * g.Cout + n];
+                        rs1 = nb.rstd[(size_t)(g0 + 1) * g.Cout + n];
+                    }
+                    if (nb.gamma != nullptr) ga = nb.gamma[n];
+                    if (nb.beta != nullptr) be = nb.beta[n];
+                }
+                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int off = sOut[row];
+                    if (off >= 0 && nok) {
+                        const float yv = nb.y[(size_t)off + n];
+                        const bool second = m0 + row >= mb;
+                        const float yh = (yv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
+                        const float gg = acc[tm][tn][r] * act_grad(yh * ga + be, nb.slope);
+                        if (!second) {
+                            s0 += gg;
+                            q0 = fmaf(gg, yh, q0);
+                        } else {
+                            s1 += gg;
+                            q1 = fmaf(gg, yh, q1);
+                        }
+                    }
+                }
+                s0 += __shfl_xor(s0, 32, 64);
+                q0 += __shfl_xor(q0, 32, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                q1 += __shfl_xor(q1, 32, 64);
+                if (lane < 32 && nok) {
+                    double* d = nb.sums + ((size_t)g0 * g.Cout + n) * 2;
+                    atomicAdd(d, (double)s0);
+                    atomicAdd(d + 1, (double)q0);
+                    if (two) {
                         atomicAdd(d + 2 * (size_t)g.Cout, (double)s1);
                         atomicAdd(d + 2 * (size_t)g.Cout + 1, (double)q1);
                     }
@@ -1150,56 +1224,57 @@ extern "C" int sdt_set_conv_math(int mode) {
 }
 extern "C" int sdt_get_conv_math(void) { return g_conv_math; }
 
+static const norm_bwd_args kNoNormBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+
+static geom_pack pack_of(const sdt_conv_geom* const* gs, int n) {
+    geom_pack gp;
+    for (int i = 0; i < SDT_MAX_CLASSES; ++i) gp.g[i] = *gs[i < n ? i : 0];
+    return gp;
+}
+
+// One launch for ``ncls`` geometries that share X, W and Y (blockIdx.y = class; the x extent covers the largest class).
 template <int BM, int BN>
 static void launch_taps(bool vec4, const float* x, const float* w, const float* bias, float* y,
-                        const sdt_conv_geom& g, int splitk, float* partial, hipStream_t s) {
-    const int M = g.B * g.Ho * g.Wo;
+                        const sdt_conv_geom* const* gs, int ncls, int splitk, float* partial, const norm_bwd_args& nb, hipStream_t s) {
+    const sdt_conv_geom& g = *gs[0];
     const size_t ysize = (size_t)g.B * g.Hy * g.Wy * g.Cout;
-    dim3 grid(cdiv(M, BM) * cdiv(g.Cout, BN), 1, splitk);
-    if (vec4 && g_conv_math != SDT_MATH_F32) {
+    int tiles = 0;
+    for (int c = 0; c < ncls; ++c) tiles = std::max(tiles, cdiv(gs[c]->B * gs[c]->Ho * gs[c]->Wo, BM) * cdiv(gs[c]->Cout, BN));
+    dim3 grid(tiles, ncls, splitk);
+    const geom_pack gp = pack_of(gs, ncls);
+    if (vec4 && g_conv_math != SDT_MATH_F32 && ncls == 1 && nb.sums == nullptr) {
         switch (g_conv_math) {
-            case SDT_MATH_BF16: hipLaunchKernelGGL((conv_taps_bf_kernel<1, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
-            case SDT_MATH_BF16X3: hipLaunchKernelGGL((conv_taps_bf_kernel<3, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
-            default: hipLaunchKernelGGL((conv_taps_bf_kernel<6, BM, BN>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+            case SDT_MATH_BF16: hipLaunchKernelGGL((conv_taps_bf_kernel<1, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+            case SDT_MATH_BF16X3: hipLaunchKernelGGL((conv_taps_bf_kernel<3, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
+            default: hipLaunchKernelGGL((conv_taps_bf_kernel<6, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
         }
         return;
     }
+#define SDT_TAPS(PRIO) hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, PRIO>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize, (double*)nullptr, 0, nb)
 #ifdef SDT_TUNING  // ablation / A-B instantiations (some compute WRONG results by design): tuning build only
-    static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // tuning experiments
-    if (vec4 && prio == 1)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 2)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 2>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 3)  // ablation: no global loads in the K loop (wrong results, timing only)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 3>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 4)  // ablation: no barriers (wrong results, timing only)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 4>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 5)  // experiment: two accumulators per 32x32 sub-tile
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 5>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 6)  // ablation: two accumulators, no global loads
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 6>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 7)  // ablation: no global loads, no LDS stores
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 7>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 8)  // ablation: no global loads, no LDS traffic at all (MFMA + prologue/epilogue only)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 8>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 10 && BM == 64 && BN == 64)  // experiment: asynchronous global->LDS staging
-        hipLaunchKernelGGL(conv_taps_dma_kernel, grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 11)  // A/B: tap culling also on 1-D launches (the previous behaviour)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 11>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 12)  // A/B: live taps in table (dy-major) order, the previous behaviour
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 12>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 16)  // A/B: tap culling also on launches with <= 4 taps (the previous behaviour)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 16>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 14)  // A/B: row-residue tap order on every launch
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 14>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
-    else if (vec4 && prio == 9)  // ablation: as 8, and no barriers after the first K step
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 9>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;
+    if (vec4 && prio == 1) SDT_TAPS(1);
+    else if (vec4 && prio == 2) SDT_TAPS(2);
+    else if (vec4 && prio == 3) SDT_TAPS(3);   // ablation: no global loads in the K loop (wrong results, timing only)
+    else if (vec4 && prio == 4) SDT_TAPS(4);   // ablation: no barriers (wrong results, timing only)
+    else if (vec4 && prio == 5) SDT_TAPS(5);   // experiment: two accumulators per 32x32 sub-tile
+    else if (vec4 && prio == 6) SDT_TAPS(6);   // ablation: two accumulators, no global loads
+    else if (vec4 && prio == 7) SDT_TAPS(7);   // ablation: no global loads, no LDS stores
+    else if (vec4 && prio == 8) SDT_TAPS(8);   // ablation: no global loads, no LDS traffic at all
+    else if (vec4 && prio == 9) SDT_TAPS(9);   // ablation: as 8, and no barriers after the first K step
+    else if (vec4 && prio == 10 && BM == 64 && BN == 64 && ncls == 1)  // experiment: asynchronous global->LDS staging
+        hipLaunchKernelGGL(conv_taps_dma_kernel, dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+    else if (vec4 && prio == 11) SDT_TAPS(11);  // A/B: tap culling also on 1-D launches (the previous behaviour)
+    else if (vec4 && prio == 12) SDT_TAPS(12);  // A/B: live taps in table (dy-major) order
+    else if (vec4 && prio == 14) SDT_TAPS(14);  // A/B: row-residue tap order on every launch
+    else if (vec4 && prio == 16) SDT_TAPS(16);  // A/B: tap culling also on launches with <= 4 taps
     else
 #endif
     if (vec4)
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+        SDT_TAPS(0);
     else
-        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize);
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, false>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize, (double*)nullptr, 0, nb);
+#undef SDT_TAPS
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -1241,25 +1316,61 @@ extern "C" int sdt_conv_taps_splitk_hint(const sdt_conv_geom* g) {
     return std::max(k, 1);
 }
 
+static int taps_dispatch(const float* x, const float* w, const float* bias, float* y, const sdt_conv_geom* const* gs, int ncls,
+                         int splitk, float* partial, const norm_bwd_args& nb, void* stream) {
+    const int var = taps_variant(gs[0], (((uintptr_t)x | (uintptr_t)w) % 16) == 0);
+    const bool vec4 = var % 10;
+    hipStream_t s = (hipStream_t)stream;
+    switch (var / 10) {
+#ifdef SDT_TUNING  // the tile sweep of profiles/r01_tile_sweep.txt; production uses 64x64 everywhere
+        case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, gs, ncls, splitk, partial, nb, s); break;
+        case 64128: launch_taps<64, 128>(vec4, x, w, bias, y, gs, ncls, splitk, partial, nb, s); break;
+        case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, gs, ncls, splitk, partial, nb, s); break;
+#endif
+        default: launch_taps<64, 64>(vec4, x, w, bias, y, gs, ncls, splitk, partial, nb, s); break;
+    }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
 extern "C" int sdt_conv_taps_splitk_f32(const float* x, const float* w, const float* bias, float* y,
                                         const sdt_conv_geom* g, int splitk, float* partial, void* stream) {
     int rc = check_geom(g);
     if (rc) return rc;
     SDT_CHECK_ARG(x && w && y, "null pointer");
     SDT_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || partial != nullptr), "bad split-K arguments");
-    const int var = taps_variant(g, (((uintptr_t)x | (uintptr_t)w) % 16) == 0);
-    const bool vec4 = var % 10;
-    hipStream_t s = (hipStream_t)stream;
-    switch (var / 10) {
-#ifdef SDT_TUNING  // the tile sweep of profiles/r01_tile_sweep.txt; production uses 64x64 everywhere
-        case 128064: launch_taps<128, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
-        case 64128: launch_taps<64, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
-        case 128128: launch_taps<128, 128>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
-#endif
-        default: launch_taps<64, 64>(vec4, x, w, bias, y, *g, splitk, partial, s); break;
+    return taps_dispatch(x, w, bias, y, &g, 1, splitk, partial, kNoNormBwd, stream);
+}
+
+// Input gradient of a (possibly strided) convolution in ONE launch: ``ncls`` output parity classes (sdt_conv_geom each; same
+// X = dY, W = transposed weights and Y = dX tensor, disjoint output positions).  Optionally the epilogue accumulates the
+// statistics of the normalisation backward that consumes dX (see sdt_norm_bwd in include/sdt_hip.h).
+extern "C" int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_conv_geom* geoms, int ncls, int splitk,
+                                       float* partial, const sdt_norm_bwd* nbw, void* stream) {
+    SDT_CHECK_ARG(geoms && ncls >= 1 && ncls <= SDT_MAX_CLASSES, "1..4 geometries per launch");
+    const sdt_conv_geom* gs[SDT_MAX_CLASSES];
+    for (int c = 0; c < ncls; ++c) {
+        gs[c] = geoms + c;
+        int rc = check_geom(gs[c]);
+        if (rc) return rc;
+        SDT_CHECK_ARG(gs[c]->B == gs[0]->B && gs[c]->Hi == gs[0]->Hi && gs[c]->Wi == gs[0]->Wi && gs[c]->Cin == gs[0]->Cin &&
+                          gs[c]->Hy == gs[0]->Hy && gs[c]->Wy == gs[0]->Wy && gs[c]->Cout == gs[0]->Cout && gs[c]->Tw == gs[0]->Tw,
+                      "the classes of one launch must share the X, W and Y tensors");
     }
-    SDT_LAUNCH_CHECK();
-    return SDT_OK;
+    SDT_CHECK_ARG(x && w && y, "null pointer");
+    SDT_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || partial != nullptr), "bad split-K arguments");
+    SDT_CHECK_ARG(g_conv_math == SDT_MATH_F32 || (ncls == 1 && nbw == nullptr), "multi-class / fused-statistics launches exist for fp32 math only");
+    norm_bwd_args nb = kNoNormBwd;
+    if (nbw != nullptr) {
+        SDT_CHECK_ARG(nbw->y && nbw->mean && nbw->rstd && nbw->sums, "null pointer in sdt_norm_bwd");
+        SDT_CHECK_ARG(splitk == 1 && (gs[0]->Cin % BK == 0), "fused backward statistics need an unsplit vector-path launch");
+        SDT_CHECK_ARG(nbw->groups == 1 || nbw->groups == gs[0]->B, "groups must be 1 (BatchNorm) or B (InstanceNorm)");
+        for (int c = 0; c < ncls; ++c)
+            SDT_CHECK_ARG(nbw->groups == 1 ? (int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo >= 64 : gs[c]->Ho * gs[c]->Wo >= 64,
+                          "a group must span at least one 64-row tile");
+        nb = {nbw->y, nbw->mean, nbw->rstd, nbw->gamma, nbw->beta, nbw->sums, nbw->slope, nbw->groups};
+    }
+    return taps_dispatch(x, w, nullptr, y, gs, ncls, splitk, partial, nb, stream);
 }
 
 // Forward conv + per-(group, channel) sum / sum-of-squares of its output in the epilogue (64x64 tile, vector path, fp32 math).
@@ -1280,18 +1391,19 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
     const int M = g->B * g->Ho * g->Wo;
     const size_t ysize = (size_t)g->B * g->Hy * g->Wy * g->Cout;
     dim3 grid(cdiv(M, 64) * cdiv(g->Cout, 64), 1, 1);
+    const geom_pack gp = pack_of(&g, 1);
 #ifdef SDT_TUNING
     static const int order = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // A/B only
     if (order == 12)
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
-                           (float*)nullptr, ysize, stats, rows_per_group);
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     else if (order == 14)
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
-                           (float*)nullptr, ysize, stats, rows_per_group);
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     else
 #endif
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, *g, 1,
-                           (float*)nullptr, ysize, stats, rows_per_group);
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+                           (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -12,6 +12,7 @@
 #include "common.h"
 
 #define MAXC 1024
+#define UNR 4  // rows (16-byte vectors) in flight per thread in the streaming passes
 
 // ---------------------------------------------------------------------------------------------
 template <bool BWD>
@@ -32,26 +33,37 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         const int64_t r1 = min(R, r0 + rows_per_block);
         const size_t base = (size_t)g * R * C + 4 * cv;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-        f32x4 mu, rs, ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BWD) {
             mu = *(const f32x4*)(mean + (size_t)g * C + 4 * cv);
             rs = *(const f32x4*)(rstd + (size_t)g * C + 4 * cv);
             if (gamma) ga = *(const f32x4*)(gamma + 4 * cv);
             if (beta) be = *(const f32x4*)(beta + 4 * cv);
         }
-        for (int64_t r = r0 + rr; r < r1; r += rpp) {
-            const f32x4 v = *(const f32x4*)(a + base + (size_t)r * C);
-            if constexpr (!BWD) {
-                s += v;
-                q += v * v;
-            } else {
-                const f32x4 yv = *(const f32x4*)(y + base + (size_t)r * C);
+        // UNR rows in flight per thread (16-byte loads issued back to back before any of them is used): with one load per
+        // loop trip a workgroup keeps only 4 KB in flight and the pass runs at ~2.5 TB/s whatever the grid
+        for (int64_t r = r0 + rr; r < r1; r += (int64_t)UNR * rpp) {
+            f32x4 v[UNR], yv[UNR];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float yh = (yv[e] - mu[e]) * rs[e];
-                    const float gg = v[e] * act_grad(yh * ga[e] + be[e], slope);
-                    s[e] += gg;
-                    q[e] += gg * yh;
+            for (int j = 0; j < UNR; ++j) {
+                const int64_t rj = r + (int64_t)j * rpp;
+                const bool ok = rj < r1;
+                v[j] = ok ? *(const f32x4*)(a + base + (size_t)rj * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (BWD) yv[j] = ok ? *(const f32x4*)(y + base + (size_t)rj * C) : mu;  // masked rows: dz == 0
+            }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                if constexpr (!BWD) {
+                    s += v[j];
+                    q += v[j] * v[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yh = (yv[j][e] - mu[e]) * rs[e];
+                        const float gg = v[j][e] * act_grad(yh * ga[e] + be[e], slope);
+                        s[e] += gg;
+                        q[e] += gg * yh;
+                    }
                 }
             }
         }
@@ -110,12 +122,23 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + rows_per_block);
     const size_t base = (size_t)g * R * C + 4 * cv;
-    for (int64_t r = r0 + rr; r < r1; r += rpp) {
-        const f32x4 v = *(const f32x4*)(y + base + (size_t)r * C);
-        f32x4 o;
+    for (int64_t r = r0 + rr; r < r1; r += (int64_t)UNR * rpp) {
+        f32x4 v[UNR];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
-        *(f32x4*)(z + base + (size_t)r * C) = o;
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t rj = r + (int64_t)j * rpp;
+            if (rj < r1) v[j] = *(const f32x4*)(y + base + (size_t)rj * C);
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t rj = r + (int64_t)j * rpp;
+            if (rj < r1) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[j][e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
+                *(f32x4*)(z + base + (size_t)rj * C) = o;
+            }
+        }
     }
 }
 
@@ -167,17 +190,30 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + rows_per_block);
     const size_t base = (size_t)g * R * C + 4 * cv;
-    for (int64_t r = r0 + rr; r < r1; r += rpp) {
-        const f32x4 gz = *(const f32x4*)(dz + base + (size_t)r * C);
-        const f32x4 yv = *(const f32x4*)(y + base + (size_t)r * C);
-        f32x4 o;
+    for (int64_t r = r0 + rr; r < r1; r += (int64_t)UNR * rpp) {
+        f32x4 gz[UNR], yv[UNR];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float yh = (yv[e] - mu[e]) * rs[e];
-            const float gg = gz[e] * act_grad(yh * ga[e] + be[e], slope);
-            o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t rj = r + (int64_t)j * rpp;
+            if (rj < r1) {
+                gz[j] = *(const f32x4*)(dz + base + (size_t)rj * C);
+                yv[j] = *(const f32x4*)(y + base + (size_t)rj * C);
+            }
         }
-        *(f32x4*)(dy + base + (size_t)r * C) = o;
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t rj = r + (int64_t)j * rpp;
+            if (rj < r1) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yh = (yv[j][e] - mu[e]) * rs[e];
+                    const float gg = gz[j][e] * act_grad(yh * ga[e] + be[e], slope);
+                    o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
+                }
+                *(f32x4*)(dy + base + (size_t)rj * C) = o;
+            }
+        }
     }
 }
 
@@ -269,15 +305,17 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-static int colnorm_rows_per_block(int C, int G, int64_t R) {
-    // <= 64 rows per thread (fp32 partials stay accurate); for short row counts shrink the chunk so that the
-    // launch still spreads over >= ~256 workgroups instead of serialising a long dependent loop in a few of them
+static int colnorm_rows_per_block(int C, int G, int64_t R, bool stats) {
+    // Streaming passes: ~2048 workgroups over all groups (8 per CU = every wave slot) with UNR 16-byte loads in flight per
+    // thread, i.e. >= 32 KB in flight per CU -- what it takes to cover HBM latency at several TB/s.  A workgroup takes at least
+    // one full unrolled trip (UNR * rpp rows) and at most 64 rows per thread (fp32 partial sums stay accurate).
     const int rpp = 256 / (C >> 2);
-    // one group (BatchNorm): every workgroup funnels 2*C fp64 atomics into the same addresses -> fewer, longer workgroups
-    // ~512 workgroups over all groups (measured on the train step: 256 -> 3747, 512 -> 3783, 1024 -> 3785, 2048 -> 3718 clips/s)
-    const int64_t want = cdiv64(R, G == 1 ? 64 : std::max(1, 512 / G));
-    const int64_t rpb = cdiv64(want, rpp) * rpp;
-    return (int)std::min<int64_t>(std::max<int64_t>(rpb, rpp), (int64_t)rpp * 64);
+    // statistics of ONE group (BatchNorm): every workgroup funnels 2*C fp64 atomics into the same addresses -> fewer, longer ones
+    const int64_t target = (stats && G == 1) ? 512 : 2048;
+    const int64_t want = cdiv64(R, std::max<int64_t>(1, target / G));
+    const int64_t unit = (int64_t)UNR * rpp;
+    const int64_t rpb = cdiv64(want, unit) * unit;
+    return (int)std::min<int64_t>(std::max<int64_t>(rpb, unit), (int64_t)rpp * 64);
 }
 static int check_colnorm(int G, int64_t R, int C) {
     SDT_CHECK_ARG(G > 0 && R > 0, "non-positive dims");
@@ -293,11 +331,14 @@ extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float
     if (rc) return rc;
     SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = colnorm_rows_per_block(C, G, R);
+    if (!stats_ready) {  // otherwise the producing conv's epilogue already accumulated them (sdt_conv_taps_stats_f32)
+        const int rps = colnorm_rows_per_block(C, G, R, true);
+        hipLaunchKernelGGL((colstats_kernel<false>), dim3((unsigned)cdiv64(R, rps), G), dim3(256), 0, s, y, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums,
+                           R, C, rps);
+    }
+    const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    if (!stats_ready)  // otherwise the producing conv's epilogue already accumulated them (sdt_conv_taps_stats_f32)
-        hipLaunchKernelGGL((colstats_kernel<false>), grid, dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rpb);
     hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
                        running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope);
     SDT_LAUNCH_CHECK();
@@ -320,15 +361,19 @@ extern "C" int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma
 
 extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                   int G, int64_t R, int C, float slope, void* stream) {
+                                   int G, int64_t R, int C, float slope, int stats_ready, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(dz && y && dy && sums && mean && rstd, "null pointer");
     SDT_CHECK_ARG(!(dgamma || dbeta) || G == 1, "affine gradients need G == 1");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = colnorm_rows_per_block(C, G, R);
+    if (!stats_ready) {
+        const int rps = colnorm_rows_per_block(C, G, R, true);
+        hipLaunchKernelGGL((colstats_kernel<true>), dim3((unsigned)cdiv64(R, rps), G), dim3(256), 0, s, dz, y, mean, rstd, gamma,
+                           beta, slope, sums, R, C, rps);
+    }
+    const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    hipLaunchKernelGGL((colstats_kernel<true>), grid, dim3(256), 0, s, dz, y, mean, rstd, gamma, beta, slope, sums, R, C, rpb);
     hipLaunchKernelGGL(colnorm_apply_bwd_kernel, grid, dim3(256), 0, s, dz, y, dy, sums, mean, rstd, gamma, beta, dgamma,
                        dbeta, R, C, rpb, slope);
     SDT_LAUNCH_CHECK();

@@ -229,6 +229,29 @@ def dx_geoms_1d(B, Wi, Cin, Cout, k, s, p):
     return out
 
 
+@functools.lru_cache(maxsize=None)
+def dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, s, p, one_d):
+    """The parity-class geometries of an input gradient as one contiguous ``sdt_conv_geom[n]`` array for
+    sdt_conv_taps_multi_f32 (None when a class has no taps, or there are more than 4 classes)."""
+    geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, s, p) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, s, p)
+    gs = [g for g, _ in geoms]
+    if any(g is None for g in gs) or len(gs) > 4:
+        return None
+    return (ConvGeom * len(gs))(*gs), len(gs), gs
+
+
+class NormBwdHolder:
+    """Hand-over between a column normalisation (InstanceNorm2d / BatchNorm + activation) and the convolution that consumes its
+    output, for ONE-consumer chains (the audio encoder): the consumer's input-gradient launch accumulates the statistics the
+    normalisation's backward needs in its epilogue (sdt_conv_taps_multi_f32 with sdt_norm_bwd) and leaves them in ``sums``; the
+    normalisation's backward then skips its statistics pass over dz and y."""
+    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums")
+
+    def __init__(self):
+        self.y = self.mean = self.rstd = self.gamma = self.beta = self.sums = None
+        self.groups, self.slope = 0, 0.0
+
+
 class ConvProfiler:
     """Optional HIP-event timing of every MFMA conv launch (bench.py's roofline leg).  Events are recorded on the
     stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
@@ -318,6 +341,23 @@ def _conv_launch(kind, is2d, g, call):
     flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
     # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, fp32
     nbytes = 4.0 * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
+    e0, e1 = PROFILER.event(), PROFILER.event()
+    e0.record()
+    check(call())
+    e1.record()
+    PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
+
+
+def _conv_launch_multi(kind, is2d, gs, call):
+    """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient)"""
+    if PROFILER is None:
+        check(call())
+        return
+    lib = _lib.load()
+    var = lib.sdt_conv_taps_variant(gs[0])
+    flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for g in gs)
+    g0 = gs[0]
+    nbytes = 4.0 * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin)
     e0, e1 = PROFILER.event(), PROFILER.event()
     e0.record()
     check(call())
@@ -427,8 +467,13 @@ class WeightMirrors:
         return wt
 
 
-def conv_input_grad(gy_cl, w, x_shape, stride, pad):
-    """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights (one per output parity class)."""
+FUSE_DX_CLASSES = True   # one launch for all output parity classes of a strided layer's input gradient (fp32 math)
+FUSE_BWD_STATS = True    # normalisation-backward statistics in the input-gradient epilogue (fp32 math, 2-D chains)
+
+
+def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None):
+    """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights -- one geometry per output parity class, all
+    classes in ONE launch in fp32 math.  ``norm_holder``: the NormBwdHolder of the normalisation that produced x (see there)."""
     lib = _lib.load()
     gy4 = _as4(gy_cl)
     one_d = w.dim() == 3
@@ -442,13 +487,28 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad):
         wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
         check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
     dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
+    pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
+    if pack is not None:
+        arr, n, gs = pack
+        k = max(_splitk_hint(lib, g) for g in gs)
+        part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
+        nb = None
+        if (norm_holder is not None and FUSE_BWD_STATS and k == 1 and not one_d and Cout % 32 == 0 and norm_holder.y is not None
+                and tuple(norm_holder.y.shape) == tuple(dx.shape)
+                and all((g.B * g.Ho * g.Wo if norm_holder.groups == 1 else g.Ho * g.Wo) >= 64 for g in gs)):
+            h = norm_holder
+            h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
+            nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+        _conv_launch_multi("dX", not one_d, gs,
+                           lambda: lib.sdt_conv_taps_multi_f32(_p(gy4), _p(wt), _p(dx), arr, n, k, _p(part), nb, st))
+        if k > 1:
+            check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
+        return dx.squeeze(1) if one_d else dx
     geoms = dx_geoms_1d(B, Wi, Cin, Cout, kw, stride, pad) if one_d else dx_geoms(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad)
     k = 1
     if all(g is not None for g, _ in geoms):
         k = max(_splitk_hint(lib, g) for g, _ in geoms)
     part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
-    # (launching the parity classes of a big strided 2-D gradient on alternating streams was measured: 3784 vs 3816 clips/s,
-    #  no gain on top of the weight-gradient side stream)
     for g, (py, px) in geoms:
         if g is None:  # parity class that no tap reaches: the gradient is zero there
             dx[:, py::(1 if one_d else stride), px::stride].zero_()
@@ -576,19 +636,20 @@ class ConvFn(torch.autograd.Function):
     """nn.Conv1d/nn.Conv2d (building_blocks.py:15-22,31-38; generator.py:103) on channels-last tensors."""
 
     @staticmethod
-    def forward(ctx, x_cl, w, bias, stride, pad):
+    def forward(ctx, x_cl, w, bias, stride, pad, in_holder=None):
         x_cl = x_cl.contiguous()
         ctx.save_for_backward(x_cl, w, bias)
-        ctx.stride, ctx.pad = stride, pad
+        ctx.stride, ctx.pad, ctx.in_holder = stride, pad, in_holder
         return conv_forward(x_cl, w, bias, stride, pad)
 
     @staticmethod
     def backward(ctx, gy):
         x_cl, w, bias = ctx.saved_tensors
-        return _conv_backward(x_cl, w, bias, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0]), None, None, None, None
+        return (_conv_backward(x_cl, w, bias, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder),
+                None, None, None, None, None)
 
 
-def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx):
+def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None):
     """Weight / bias gradients accumulated into ``.grad``; returns dX (or None)."""
     if w.requires_grad:
         # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
@@ -608,7 +669,7 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx):
     if bias is not None and bias.requires_grad:
         gb = grad_buffer(bias)
         check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
-    return conv_input_grad(gy, w, x_cl.shape, stride, pad) if need_dx else None
+    return conv_input_grad(gy, w, x_cl.shape, stride, pad, in_holder) if need_dx else None
 
 
 class ConvStatsFn(torch.autograd.Function):
@@ -617,10 +678,11 @@ class ConvStatsFn(torch.autograd.Function):
     ``sums`` goes to ColNormActFn(..., sums).  Use only when ``conv_stats_fusable`` says so."""
 
     @staticmethod
-    def forward(ctx, x_cl, w, stride, pad, groups):
+    def forward(ctx, x_cl, w, stride, pad, groups, in_holder=None):
         _req_cuda(x_cl, w)
         lib = _lib.load()
         x_cl = x_cl.contiguous()
+        ctx.in_holder = in_holder
         g = conv_geom_for(x_cl.shape, w, stride, pad)
         y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
         sums = _ARENA.take(2 * groups * g.Cout, x_cl.device)
@@ -636,7 +698,8 @@ class ConvStatsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gsums):
         x_cl, w = ctx.saved_tensors
-        return _conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0]), None, None, None, None
+        return (_conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder),
+                None, None, None, None, None)
 
 
 def conv_stats_fusable(x_cl, w, stride, pad, groups):
@@ -705,7 +768,7 @@ class ColNormActFn(torch.autograd.Function):
     """InstanceNorm2d (groups = batch) or training-mode BatchNorm (groups = 1) + LeakyReLU/ReLU."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None):
+    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None, holder=None):
         _req_cuda(y)
         lib = _lib.load()
         y = y.contiguous()
@@ -720,7 +783,10 @@ class ColNormActFn(torch.autograd.Function):
         check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
                                       _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _stream()))
         ctx.save_for_backward(y, mean, rstd, gamma, beta)
-        ctx.groups, ctx.slope = groups, slope
+        ctx.groups, ctx.slope, ctx.holder = groups, slope, holder
+        if holder is not None:  # what the consuming conv's input-gradient epilogue needs (NormBwdHolder)
+            holder.y, holder.mean, holder.rstd, holder.gamma, holder.beta = y, mean, rstd, gamma, beta
+            holder.groups, holder.slope, holder.sums = groups, slope, None
         return z
 
     @staticmethod
@@ -731,12 +797,16 @@ class ColNormActFn(torch.autograd.Function):
         C = y.shape[-1]
         R = y.numel() // C // ctx.groups
         dy = torch.empty_like(y)
-        sums = _ARENA.take(2 * ctx.groups * C, y.device)
+        h = ctx.holder
+        ready = h is not None and h.sums is not None  # accumulated by the epilogue of the conv that produced gz
+        sums = h.sums if ready else _ARENA.take(2 * ctx.groups * C, y.device)
+        if h is not None:
+            h.sums = None
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
         check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
-                                      ctx.groups, R, C, ctx.slope, _stream()))
-        return dy, None, None, None, None, None, None, None, None
+                                      ctx.groups, R, C, ctx.slope, int(ready), _stream()))
+        return dy, None, None, None, None, None, None, None, None, None
 
 
 class L0BlockFn(torch.autograd.Function):

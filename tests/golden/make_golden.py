@@ -138,13 +138,13 @@ def run_reference_model(cfg_name, B, n_clips, steps, code_std, dtype=torch.float
             out[f"s{step}/loss/{k}"] = np.array(v.item())
         for k, v in metrics.items():
             out[f"s{step}/metric/{k}"] = np.array(v.item())
-        out[f"s{step}/pred"] = results["poses_pred_batch"].detach().float().numpy() if step == 0 else sl(results["poses_pred_batch"])
+        out[f"s{step}/pred"] = (results["poses_pred_batch"].detach().numpy().astype(np.float64 if dtype == torch.float64 else np.float32)
+                                if step == 0 else sl(results["poses_pred_batch"]))
         out[f"s{step}/final_pred"] = sl(fin_p)
         for k in ("mu_pred", "mu_gt", "logvar_pred", "logvar_gt"):
             out[f"s{step}/{k}"] = results[k].detach().numpy()
-        if step == 0:
-            for k, g in grads.items():
-                out[f"s0/grad/{k}"] = sl(g)
+        for k, g in grads.items():  # every step (step 0 was the round-1 fixture; later steps feed the fp64-calibrated checks)
+            out[f"s{step}/grad/{k}"] = sl(g)
     if ext is not None:
         os.unlink(cfg.VOICE2POSE.POSE_ENCODER.AE_CHECKPOINT)
         assert torch.equal(model.clips_code, ext)
@@ -155,14 +155,16 @@ def run_reference_model(cfg_name, B, n_clips, steps, code_std, dtype=torch.float
     return out
 
 
-def run_reference_pose2pose(B, n_clips, steps):
+def run_reference_pose2pose(B, n_clips, steps, dtype=torch.float32):
     """Replays pose2pose.py:124-149 around the imported Pose2PoseModel (reparameterisation noise injected)."""
     from core.pipelines.pose2pose import Pose2PoseModel
     cfg = O.cfg_named("pose2pose")
-    st0 = O.make_pose2pose_state(cfg, n_clips, seed=0)
+    st0 = O.make_pose2pose_state(cfg, n_clips, seed=0, dtype=dtype)
     model = Pose2PoseModel(cfg, None, n_clips)
-    st0["mel_transfm.spectrogram.window"] = O.mel_window()
-    st0["mel_transfm.mel_scale.fb"] = O.mel_filterbank()
+    if dtype == torch.float64:
+        model = model.double()
+    st0["mel_transfm.spectrogram.window"] = O.mel_window(dtype)
+    st0["mel_transfm.mel_scale.fb"] = O.mel_filterbank(dtype)
     r = model.load_state_dict(clone_state(st0), strict=True)
     assert not r.missing_keys and not r.unexpected_keys
     model.train()
@@ -171,8 +173,8 @@ def run_reference_pose2pose(B, n_clips, steps):
     out = {}
     real_randn = torch.randn
     for step in range(steps):
-        batch = O.make_batch(B, n_clips, step=step, seed=1)
-        eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((B, 32)).astype(np.float32))
+        batch = O.make_batch(B, n_clips, step=step, seed=1, dtype=dtype)
+        eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((B, 32)).astype(np.float32)).to(dtype)
         torch.randn = lambda *a, **k: eps.clone()
         try:
             losses, results = model(batch)
@@ -186,15 +188,16 @@ def run_reference_pose2pose(B, n_clips, steps):
         model.clip_code_logvar[idx] = results["clip_code_logvar"].detach()
         opt.zero_grad()
         losses["loss"].backward(retain_graph=True)
-        if step == 0:
-            for k, p in model.named_parameters():
-                out[f"s0/grad/{k}"] = sl(p.grad)
+        for k, p in model.named_parameters():
+            out[f"s{step}/grad/{k}"] = sl(p.grad)
         opt.step()
         for k, v in losses.items():
             out[f"s{step}/loss/{k}"] = np.array(v.item())
         for k, v in metrics.items():
             out[f"s{step}/metric/{k}"] = np.array(v.item())
         out[f"s{step}/pred"] = sl(results["poses_pred_batch"])
+        if step == 0:  # the full step-0 prediction: lets a test count L1 sign decisions that differ between two fp32 runs
+            out["s0/pred_full"] = results["poses_pred_batch"].detach().numpy()
         out[f"s{step}/mu"] = results["clip_code_mu"].detach().numpy()
     for k, v in model.state_dict().items():
         out[f"final/{k}"] = sl(v) if v.is_floating_point() else np.array(v.item())
@@ -312,7 +315,41 @@ def main():
         if k.startswith("s0/"):
             traj[f"voice2pose_sdt_bp_f64/{k}"] = v
     np.savez_compressed(os.path.join(HERE, "trajectories_B4.npz"), **traj)
-    for f in ("modules_B2.npz", "trajectories_B4.npz", "speaker_stat_oliver.npz"):
+
+    # ---- (4) float64 runs of the REFERENCE for every config, all 3 steps: the "truth" that calibrates every fp32 tolerance
+    # (|HIP - f64| is compared with |reference fp32 - f64| per loss, per prediction and per gradient tensor, per step)
+    t64 = {}
+    for name, Bm, code_std in (("voice2pose_sdt_bp", 4, 0.5), ("voice2pose_sdt_bp_zero", 4, 0.0),
+                               ("voice2pose_s2g", 4, 0.0), ("voice2pose_sdt_vae", 4, 0.0)):
+        res = run_reference_model(name.replace("_zero", ""), Bm, 16, 3, code_std, dtype=torch.float64)
+        for k, v in res.items():
+            if k.startswith("final"):
+                continue
+            t64[f"{name}/{k}"] = v.astype(np.float64) if k.endswith("/pred") else v
+        print(name, "f64", {k: float(v) for k, v in res.items() if "/loss/G_loss" in k})
+    res = run_reference_pose2pose(4, 16, 3, dtype=torch.float64)
+    for k, v in res.items():
+        if not k.startswith("final"):
+            t64[f"pose2pose/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "trajectories_B4_f64.npz"), **t64)
+
+    # ---- (5) Frechet gesture distance (core/utils/fgd.py:59-64) on seeded code sets -------------------------------
+    from core.utils.fgd import compute_fgd
+    fg = {}
+    rng = np.random.Generator(np.random.PCG64(11))
+    for tag, n, d in (("n200_d32", 200, 32), ("n64_d64", 64, 64), ("n500_d32", 500, 32)):
+        a = rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, d)
+        b = rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, d) + 0.3 * rng.standard_normal(d)
+        mix = rng.standard_normal((d, d)) / np.sqrt(d)
+        b = b @ (np.eye(d) + 0.3 * mix)  # correlated dimensions: a non-diagonal covariance product
+        fg[tag + "/a"], fg[tag + "/b"] = a, b
+        fg[tag + "/fgd_ab"] = compute_fgd(a, b).numpy()  # float32, as the reference returns it
+        fg[tag + "/fgd_aa"] = compute_fgd(a, a).numpy()
+    a = rng.standard_normal((20, 32))  # fewer samples than dimensions: singular covariances (the jitter / complex branch)
+    b = rng.standard_normal((20, 32)) + 0.5
+    fg["n20_d32/a"], fg["n20_d32/b"], fg["n20_d32/fgd_ab"] = a, b, compute_fgd(a, b).numpy()
+    np.savez_compressed(os.path.join(HERE, "fgd.npz"), **fg)
+    for f in ("modules_B2.npz", "trajectories_B4.npz", "trajectories_B4_f64.npz", "fgd.npz", "speaker_stat_oliver.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -1,0 +1,367 @@
+"""Parity at BASELINE's full size (32 clips per GPU) against the CPU oracle itself, with float64-calibrated tolerances.
+
+Round 1 tied the B=32 kernels together only through identities (adjoints, linearity, permutation) -- a consistently wrong
+linear map passes all of them.  Here the HIP path is compared with the ORACLE on the same 32-clip batch:
+
+  * one forward + backward of sdt_bp (learned clip codes + KL), sdt_vae (external codes) and pose2pose at B=32 against the
+    oracle in float64 AND against the oracle's own fp32 run of the same step (1.5 s + a few seconds of CPU);
+  * every conv layer shape at B=32: batch items 0 and 31 of forward / input-gradient against a float64 F.conv of that single
+    item (no cross-sample terms), and the weight gradient of a cotangent that is non-zero on items {0, 31} only;
+  * the bf16 product mode (BASELINE config 4) at B=32 with its own, stated, bf16 tolerances, and 'bf16x6' held to the fp32 bar;
+  * the 3-step B=4 trajectories of every config against float64 runs of the REFERENCE (tests/golden/trajectories_B4_f64.npz).
+
+How "as close to float64 as the fp32 reference" is measured
+-----------------------------------------------------------
+Forward quantities (losses, prediction) are continuous in the rounding noise: each one has to satisfy
+        |HIP - f64| <= K_FWD * |ref_fp32 - f64| + floor.
+Gradients are NOT: the network is piecewise linear (|.| loss, LeakyReLU), so two fp32 runs whose forward passes differ by 1e-6
+take a different branch at a handful of elements, and ONE such event moves whole gradient tensors by 1e-3..1e-1 of their
+max-norm.  tools/debug/p2p_flip.py shows it on the pose2pose B=4 fixture: the HIP prediction is as accurate as the fp32
+reference's (6.6e-6 vs 5.1e-6 of float64) yet sign(pred - gt) differs at exactly 1 of 61952 elements, and that single sign is
+the whole "100x worse" gradient gap (the head-bias gradient is off by exactly 2/N at one channel); at B=32 per-tensor ratios
+|HIP-f64| / |ref32-f64| scatter from 0.03 to 1500 in BOTH directions (profiles/r02_parity_tables.txt).  Therefore:
+  1. where the oracle runs next to the kernels (B=32) the float64 gradient is evaluated at the SAME L1 sign decisions as the
+     fp32 run it is compared with (loss = mean(s * (pred - gt)), s = that run's own signs) -- this removes the loss-level events;
+  2. the remaining events (LeakyReLU branches inside the network) hit individual tensors of either run at random, so the
+     comparison is between the two error DISTRIBUTIONS over the gradient tensors of a step:
+        median_k e_hip[k] <= K_MED * median_k e_ref[k],   max_k e_hip[k] <= K_MAX * max_k e_ref[k],
+        ||g_hip - g_f64||_2 / ||g_f64||_2 <= K_L2 * (same for ref32)           (whole gradient, all tensors concatenated)
+     with e[k] = max|g[k] - g_f64[k]| / max|g_f64[k]|;
+  3. on the B=4 fixtures (no oracle in the loop, float64 gradients stored at the float64 run's own signs) L1 sign decisions
+     that differ from the float64 run are COUNTED from the stored full predictions and each one is allowed its measured
+     worst-case effect (FLIP_ALLOW of a tensor's max-norm); with zero differing decisions the bar is the one of item 2.
+Every run appends its full per-tensor table to $SDT_PARITY_TABLES (committed as profiles/r02_parity_tables.txt).
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from oracle import sdt_oracle as O
+from test_model_gpu import _make_pipeline, sl
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+K_FWD = 3.0   # per forward quantity: HIP at most this many times further from float64 than the fp32 reference
+K_MED, K_MAX, K_L2 = 2.0, 3.0, 2.0  # gradient error distributions over the tensors of a step (see module docstring)
+FLIP_ALLOW = 0.1  # B=4 fixtures: measured worst effect of ONE differing L1 sign on a gradient tensor (8.8e-2 of max, head weight)
+N_CLIPS = 64
+
+
+def _relmax(a, ref):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+    ref = ref.detach().double().cpu() if torch.is_tensor(ref) else torch.as_tensor(np.asarray(ref, dtype=np.float64))
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    assert torch.isfinite(a).all()
+    return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def _oracle_grads(cfg_name, state32, batch32, dtype, eps32=None, l1_signs=None):
+    """One forward + backward of the oracle on copies of ``state32`` / ``batch32`` cast to ``dtype`` (float64 runs see exactly
+    the fp32 weights and inputs the other runs see).  ``l1_signs``: evaluate the regression term at these fixed sign decisions,
+    mean(s * (pred - gt)) -- equal to mean|pred - gt| wherever s = sign(pred - gt).  Returns (losses, prediction, {name: grad})."""
+    cfg = O.cfg_named(cfg_name)
+    st = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in state32.items()}
+    batch = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch32.items()}
+    if cfg_name == "pose2pose":
+        O.OraclePose2Pose(cfg, st)
+        losses, res = O.pose2pose_forward(st, batch, cfg, eps32.to(dtype), True)
+        total, reg_key, lam, pref = "loss", "reg_loss", cfg.POSE2POSE.LAMBDA_REG, "ae."
+    else:
+        O.OracleVoice2Pose(cfg, st)
+        losses, res = O.voice2pose_forward(st, batch, cfg, True)
+        total, reg_key, lam, pref = "G_loss", "G_reg_loss", cfg.VOICE2POSE.GENERATOR.LAMBDA_REG, ("netG.", "clips_code")
+    loss = losses[total]
+    if l1_signs is not None:
+        lin = (l1_signs.to(dtype) * (res["poses_pred_batch"] - batch["poses"])).mean() * lam
+        loss = loss - losses[reg_key] + lin
+    loss.backward()
+    grads = {k: v.grad.detach() for k, v in st.items() if v.requires_grad and v.grad is not None and k.startswith(pref)}
+    return {k: v.detach() for k, v in losses.items()}, res["poses_pred_batch"].detach(), grads
+
+
+def _dump(lines):
+    print("\n".join("  " + ln for ln in lines))
+    dump = os.environ.get("SDT_PARITY_TABLES")
+    if dump:
+        with open(dump, "a") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def _check_forward(title, rows):
+    """rows: (name, hip, ref32, f64, floor_rel)."""
+    lines, bad = ["%s -- forward quantities, per quantity |hip-f64| <= %.0f x |ref32-f64| + floor:" % (title, K_FWD)], []
+    for name, hip, r32, f64, floor in rows:
+        eh, er = _relmax(hip, f64), _relmax(r32, f64)
+        ok = eh <= K_FWD * er + floor
+        lines.append("      %-44s hip %.3e  ref32 %.3e  ratio %6.2f%s" % (name, eh, er, eh / max(er, 1e-30), "" if ok else "  FAIL"))
+        if not ok:
+            bad.append((name, eh, er))
+    _dump(lines)
+    assert not bad, (title, bad)
+
+
+def _check_grad_distributions(title, e_hip, e_ref, l2_hip=None, l2_ref=None, allow=0.0):
+    """e_hip / e_ref: {tensor name: max|g - g_f64| / max|g_f64|}.  ``allow``: extra absolute allowance on every statistic (B=4
+    fixtures: FLIP_ALLOW per counted differing L1 sign decision)."""
+    names = sorted(e_ref)
+    eh, er = np.array([e_hip[k] for k in names]), np.array([e_ref[k] for k in names])
+    med_h, med_r, max_h, max_r = np.median(eh), np.median(er), eh.max(), er.max()
+    lines = ["%s -- gradient error distributions over %d tensors (allowance %.1e):" % (title, len(names), allow),
+             "      median  hip %.3e  ref32 %.3e  (bar %.0fx)      max  hip %.3e  ref32 %.3e  (bar %.0fx)"
+             % (med_h, med_r, K_MED, max_h, max_r, K_MAX)]
+    ok = med_h <= K_MED * med_r + allow and max_h <= K_MAX * max_r + allow
+    if l2_hip is not None:
+        lines.append("      whole-gradient relative L2 error  hip %.3e  ref32 %.3e  (bar %.0fx)" % (l2_hip, l2_ref, K_L2))
+        ok = ok and l2_hip <= K_L2 * l2_ref + allow
+    for k, a, b in zip(names, eh, er):
+        lines.append("      %-60s hip %.3e  ref32 %.3e  ratio %8.2f" % (k, a, b, a / max(b, 1e-30)))
+    _dump(lines)
+    assert ok, (title, "median", med_h, med_r, "max", max_h, max_r, "L2", l2_hip, l2_ref)
+
+
+def _flat_l2(ga, gb, names):
+    num = sum(float(((ga[k].double().cpu() - gb[k].double().cpu()) ** 2).sum()) for k in names)
+    den = sum(float((gb[k].double().cpu() ** 2).sum()) for k in names)
+    return (num / den) ** 0.5
+
+
+def _b32_run(cfg_name, code_std, conv_math="f32"):
+    """HIP forward+backward at B=32 in ``conv_math`` plus the oracle in fp32 and in float64 (the latter twice: at the HIP run's
+    and at the fp32 oracle's L1 sign decisions)."""
+    from speechdrivestemplates_amd import ops
+    B = 32
+    ocfg = O.cfg_named(cfg_name)
+    batch = O.make_batch(B, N_CLIPS, step=3, seed=11)
+    eps = None
+    ops.set_conv_math(conv_math)
+    try:
+        pipe, _ = _make_pipeline(cfg_name, N_CLIPS, code_std)
+        if cfg_name == "pose2pose":
+            state = O.make_pose2pose_state(ocfg, N_CLIPS, seed=0)
+            eps = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal((B, 32)).astype(np.float32))
+            real_randn = torch.randn
+            torch.randn = lambda *a, **k: eps.clone().to(DEV)
+            try:
+                losses, results = pipe.forward_backward(batch)
+            finally:
+                torch.randn = real_randn
+            pred_hip, loss_keys = results["poses_pred_batch"], ("reg_loss", "kl_loss", "loss")
+        else:
+            state = O.make_voice2pose_state(ocfg, N_CLIPS, seed=0, code_std=code_std)
+            if ocfg.VOICE2POSE.GENERATOR.CLIP_CODE.EXTERNAL_CODE:
+                state["clips_code"] = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((N_CLIPS, 32)).astype(np.float32))
+            losses, results = pipe.forward_backward(batch)
+            pred_hip, loss_keys = results["poses_pred_normalized"], ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_math("f32")
+    grads_hip = {k: p.grad.detach().clone() for k, p in pipe.model.named_parameters() if p.grad is not None}
+    gt = batch["poses"]
+    t0 = time.time()
+    l32, p32, g32 = _oracle_grads(cfg_name, state, batch, torch.float32, eps)
+    t1 = time.time()
+    s_hip = torch.sign(pred_hip.detach().cpu() - gt)
+    s_ref = torch.sign(p32 - gt)
+    l64, p64, g64_hip = _oracle_grads(cfg_name, state, batch, torch.float64, eps, l1_signs=s_hip)
+    _, _, g64_ref = _oracle_grads(cfg_name, state, batch, torch.float64, eps, l1_signs=s_ref)
+    n_flip_hip = int((s_hip != torch.sign(p64 - gt.double())).sum())
+    n_flip_ref = int((s_ref != torch.sign(p64 - gt.double())).sum())
+    print("  oracle B=32 forward+backward: fp32 %.1f s, float64 2 x %.1f s; L1 sign decisions differing from float64: hip %d, ref32 %d of %d"
+          % (t1 - t0, (time.time() - t1) / 2, n_flip_hip, n_flip_ref, gt.numel()))
+    return dict(losses=losses, loss_keys=loss_keys, pred_hip=pred_hip, grads_hip=grads_hip, l32=l32, p32=p32, g32=g32, l64=l64, p64=p64,
+                g64_hip=g64_hip, g64_ref=g64_ref, batch=batch)
+
+
+def _b32_check(title, r, metrics=True):
+    _check_forward(title, [("loss " + k, r["losses"][k].detach().reshape(1), r["l32"][k].reshape(1), r["l64"][k].reshape(1), 3e-7)
+                           for k in r["loss_keys"]] + [("prediction (32,64,2,121)", r["pred_hip"], r["p32"], r["p64"], 2e-7)])
+    names = sorted(r["g64_hip"])
+    assert set(names) <= set(r["grads_hip"]), sorted(set(names) - set(r["grads_hip"]))[:5]
+    e_hip = {k: _relmax(r["grads_hip"][k], r["g64_hip"][k]) for k in names}
+    e_ref = {k: _relmax(r["g32"][k], r["g64_ref"][k]) for k in names}
+    _check_grad_distributions(title, e_hip, e_ref, _flat_l2(r["grads_hip"], r["g64_hip"], names), _flat_l2(r["g32"], r["g64_ref"], names))
+    if metrics:  # float64 metrics of the step
+        fin_p = O.get_final_results(r["p64"].clone(), r["batch"]["speaker_stat"], True)
+        fin_g = O.get_final_results(r["batch"]["poses"].double(), r["batch"]["speaker_stat"], True)
+        m64 = O.evaluate_step(fin_p, fin_g)
+        assert abs(float(r["losses"]["L2_dist"]) - float(m64["L2_dist"])) <= 1e-5 * float(m64["L2_dist"])
+        assert abs(float(r["losses"]["lip_sync_error_n"]) - float(m64["lip_sync_error_n"])) <= 2e-4 * float(m64["lip_sync_error_n"])
+
+
+@pytest.mark.parametrize("cfg_name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_vae", 0.0), ("pose2pose", 0.0)])
+def test_b32_forward_backward_vs_oracle_f64_calibrated(cfg_name, code_std):
+    _b32_check("%s B=32 (fp32 MFMA) vs float64 oracle" % cfg_name, _b32_run(cfg_name, code_std))
+
+
+def test_b32_bf16_mode_vs_oracle():
+    """BASELINE config 4 (sdt_bp, bf16): conv products from bf16-rounded operands, fp32 accumulation and fp32 everywhere else.
+    Stated bf16 tolerances at 32 clips per GPU, against the float64 oracle (evaluated at the run's own L1 sign decisions):
+    prediction 4e-2 of max, losses 2e-2, every gradient tensor within 25 % of its max-norm and with cosine similarity >= 0.97 to
+    the float64 gradient (bf16 has 8 significand bits: 2^-9 = 2e-3 per product, amplified through 25 normalised layers)."""
+    from speechdrivestemplates_amd import ops
+    B, cfg_name = 32, "voice2pose_sdt_bp"
+    ocfg = O.cfg_named(cfg_name)
+    state = O.make_voice2pose_state(ocfg, N_CLIPS, seed=0, code_std=0.5)
+    batch = O.make_batch(B, N_CLIPS, step=3, seed=11)
+    ops.set_conv_math("bf16")
+    try:
+        pipe, _ = _make_pipeline(cfg_name, N_CLIPS, 0.5)
+        losses, results = pipe.forward_backward(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_math("f32")
+    grads_hip = {k: p.grad.detach().double().cpu() for k, p in pipe.model.named_parameters() if p.grad is not None}
+    s_hip = torch.sign(results["poses_pred_normalized"].detach().cpu() - batch["poses"])
+    l64, p64, g64 = _oracle_grads(cfg_name, state, batch, torch.float64, l1_signs=s_hip)
+    e = _relmax(results["poses_pred_normalized"], p64)
+    rows = []
+    for k, ref in g64.items():
+        got = grads_hip[k]
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        cos = (F.cosine_similarity(got.reshape(1, -1), ref.reshape(1, -1)).item()) if ref.numel() > 1 else 1.0
+        rows.append((k, rel, cos))
+    lines = ["voice2pose_sdt_bp B=32 (bf16 products) vs float64 oracle: prediction rel-max-err %.3e; losses %s" % (
+        e, {k: "%.2e" % abs(float(losses[k]) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
+    lines += ["      %-60s rel-max-err %.3e  cosine %.5f" % r for r in rows]
+    _dump(lines)
+    assert e <= 4e-2, e
+    for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss"):
+        a, b = float(losses[k]), float(l64[k])
+        assert abs(a - b) <= 2e-2 * abs(b), (k, a, b)
+    worst_rel, worst_cos = max(r[1] for r in rows), min(r[2] for r in rows)
+    print("  bf16 B=32: worst gradient rel-max-err %.3e, worst cosine %.5f" % (worst_rel, worst_cos))
+    assert worst_rel <= 0.25 and worst_cos >= 0.97, [r for r in rows if r[1] > 0.25 or r[2] < 0.97]
+
+
+def test_b32_bf16x6_mode_meets_the_fp32_bar():
+    """'bf16x6' (operands split exactly into three bf16 pieces, six MFMA products, fp32 accumulation) claims fp32-equivalent
+    products: at B=32 it has to pass the SAME float64-calibrated checks as the exact-fp32 MFMA path."""
+    _b32_check("voice2pose_sdt_bp B=32 (bf16x6 products) vs float64 oracle", _b32_run("voice2pose_sdt_bp", 0.5, conv_math="bf16x6"))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# every conv layer shape at B=32: single batch items against float64
+# ----------------------------------------------------------------------------------------------------------------------
+CONV_B32 = [  # name, Hi, Wi, Cin, Cout, kh, kw, s, p  (Hi == 1: Conv1d)
+    ("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1, 1), ("L3", 40, 213, 128, 128, 4, 4, 2, 1),
+    ("L4", 20, 106, 128, 256, 3, 3, 1, 1), ("L5", 20, 106, 256, 256, 4, 4, 2, 1), ("L6", 10, 53, 256, 256, 3, 3, 1, 1),
+    ("L7", 10, 53, 256, 256, 6, 3, 1, 0),
+    ("unet e0 288->256 k3 T64", 1, 64, 288, 256, 1, 3, 1, 1), ("unet k4s2 T64", 1, 64, 256, 256, 1, 4, 2, 1),
+    ("unet k4s2 T4", 1, 4, 256, 256, 1, 4, 2, 1), ("unet k3 T8", 1, 8, 256, 256, 1, 3, 1, 1),
+    ("head 256->242 k1", 1, 64, 256, 242, 1, 1, 1, 0), ("pose-enc 242->256 k3", 1, 64, 242, 256, 1, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_B32, ids=[c[0] for c in CONV_B32])
+def test_conv_b32_single_items_vs_float64(case):
+    from speechdrivestemplates_amd import ops
+    tag, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    B, items = 32, (0, 31)
+    one_d = Hi == 1
+    gen = torch.Generator().manual_seed(1000 + sum(map(ord, tag)))
+    xs, ws = ((B, Wi, Cin), (Cout, Cin, kw)) if one_d else ((B, Hi, Wi, Cin), (Cout, Cin, kh, kw))
+    x = torch.randn(xs, generator=gen)
+    w = torch.randn(ws, generator=gen) * (2.0 / (Cin * kh * kw)) ** 0.5
+    xd = x.to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w).to(DEV))
+    yd = ops.conv_forward(xd, wd, None, s, p)
+    gy = torch.randn(yd.shape, generator=gen)
+    gyd = gy.to(DEV)
+    dxd = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
+    mask = torch.zeros(B, *([1] * (gy.dim() - 1)))
+    mask[list(items)] = 1.0
+    ops.conv_weight_grad(xd, (gy * mask).to(DEV).contiguous(), wd, s, p)
+    torch.cuda.synchronize()
+    conv = F.conv1d if one_d else F.conv2d
+    dw_ref = torch.zeros_like(w, dtype=torch.float64)
+    for b in items:
+        xb = (x[b:b + 1].permute(0, 2, 1) if one_d else x[b:b + 1].permute(0, 3, 1, 2)).double().requires_grad_(True)
+        wb = w.double().requires_grad_(True)
+        yb = conv(xb, wb, None, s, p)
+        gb = (gy[b:b + 1].permute(0, 2, 1) if one_d else gy[b:b + 1].permute(0, 3, 1, 2)).double()
+        yb.backward(gb)
+        y_cl = yb.detach().permute(0, 2, 1) if one_d else yb.detach().permute(0, 2, 3, 1)
+        dx_cl = xb.grad.permute(0, 2, 1) if one_d else xb.grad.permute(0, 2, 3, 1)
+        assert _relmax(yd[b:b + 1], y_cl) < 3e-6, (tag, "fwd item", b, _relmax(yd[b:b + 1], y_cl))
+        assert _relmax(dxd[b:b + 1], dx_cl) < 3e-6, (tag, "dX item", b, _relmax(dxd[b:b + 1], dx_cl))
+        dw_ref += wb.grad
+    e = _relmax(wd.grad, dw_ref)
+    print("  %-28s B=32 items %s: dW (masked cotangent) rel-max-err %.2e" % (tag, items, e))
+    assert e < 5e-6, (tag, "dW", e)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 3-step B=4 trajectories of every config: fp64-calibrated per step and per gradient tensor
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_f64():
+    return dict(np.load(os.path.join(GOLDEN, "trajectories_B4_f64.npz")))
+
+
+def _sample_err(got, f64):
+    got, f64 = np.asarray(got, dtype=np.float64), np.asarray(f64, dtype=np.float64)
+    return float(np.abs(got - f64).max() / max(np.abs(f64).max(), 1e-30))
+
+
+@pytest.mark.parametrize("name,code_std", [("voice2pose_sdt_bp", 0.5), ("voice2pose_sdt_bp_zero", 0.0), ("voice2pose_s2g", 0.0),
+                                           ("voice2pose_sdt_vae", 0.0), ("pose2pose", 0.0)])
+def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, golden_f64, name, code_std):
+    """Replaces round 1's flat gradient tolerance (2e-2 of max on 64 samples, whatever the tensor): every step of the 3-step run
+    is compared with the REFERENCE's float64 run of the same trajectory.
+      step 0 (identical weights on all three sides): losses and prediction per quantity within K_FWD of the reference's own
+        fp32-vs-float64 distance; the 64 stored samples of every gradient tensor through the distribution check of the module
+        docstring, with FLIP_ALLOW for every L1 sign decision that differs from the float64 run (counted from the stored full
+        predictions; the reference's fp32 run is given the same accounting);
+      steps 1-2: the three runs have taken different-but-equivalent Adam steps (|dw| = lr * sign(g) on the first steps, so fp32
+        noise on near-zero gradients flips update signs); the distributions are compared, not individual tensors."""
+    cfg_name = name.replace("_zero", "")
+    pipe, cfg = _make_pipeline(cfg_name, 16, code_std)
+    g32 = {k[len(name) + 1:]: v for k, v in golden_traj.items() if k.startswith(name + "/")}
+    g64 = {k[len(name) + 1:]: v for k, v in golden_f64.items() if k.startswith(name + "/")}
+    real_randn = torch.randn
+    for step in range(3):
+        batch = O.make_batch(4, 16, step=step, seed=1)
+        if cfg_name == "voice2pose_s2g":
+            batch["speaker"] = ["oliver"] * 4
+        if cfg_name == "pose2pose":
+            eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((4, 32)).astype(np.float32)).to(DEV)
+            torch.randn = lambda *a, **k: eps.clone()
+        try:
+            losses, results = pipe.forward_backward(batch)
+        finally:
+            torch.randn = real_randn
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in pipe.model.named_parameters() if p.grad is not None}
+        pred = (results["poses_pred_normalized"] if "poses_pred_normalized" in results else results["poses_pred_batch"]).detach().cpu()
+        title = "%s B=4 step %d vs float64 reference" % (name, step)
+        n_flip = 0
+        if step == 0:
+            full32 = g32["s0/pred_full"] if "s0/pred_full" in g32 else g32["s0/pred"]
+            full64 = g64["s0/pred_full"] if "s0/pred_full" in g64 else g64["s0/pred"]
+            rows = [("loss " + k.split("/")[-1], [float(losses[k.split("/")[-1]])], [float(g32[k])], [float(g64[k])], 3e-7)
+                    for k in g32 if k.startswith("s0/loss/") and k in g64 and k.split("/")[-1] in losses]
+            rows.append(("prediction", pred.numpy(), full32, full64, 2e-7))
+            _check_forward(title, rows)
+            gt = batch["poses"].double().numpy()
+            s64 = np.sign(full64 - gt)
+            n_flip = int((np.sign(pred.double().numpy() - gt) != s64).sum())
+            n_flip_ref = int((np.sign(full32.astype(np.float64) - gt) != s64).sum())
+            print("  %s: L1 sign decisions differing from the float64 run: hip %d, reference fp32 %d (of %d)" % (title, n_flip, n_flip_ref, gt.size))
+        keys = [k for k in g64 if k.startswith("s%d/grad/" % step) and not k.startswith("s%d/grad/Dstep:" % step)
+                and k in g32 and k.split("/grad/")[1] in grads]
+        e_hip = {k.split("/grad/")[1]: _sample_err(sl(grads[k.split("/grad/")[1]])[:64], g64[k][:64]) for k in keys}
+        e_ref = {k.split("/grad/")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
+        _check_grad_distributions(title, e_hip, e_ref, allow=FLIP_ALLOW * n_flip if step == 0 else 0.0)
+        pipe.optimizer_updates(losses)
+        if cfg_name == "voice2pose_s2g":  # second backward (discriminator step): its gradients exist after optimizer_updates
+            torch.cuda.synchronize()
+            params = dict(pipe.model.named_parameters())
+            keys = [k for k in g64 if k.startswith("s%d/grad/Dstep:" % step) and k in g32]
+            e_hip = {k.split("Dstep:")[1]: _sample_err(sl(params[k.split("Dstep:")[1]].grad)[:64], g64[k][:64]) for k in keys}
+            e_ref = {k.split("Dstep:")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
+            _check_grad_distributions(title + " (discriminator step)", e_hip, e_ref)

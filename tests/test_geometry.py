@@ -173,3 +173,23 @@ def test_fgd_matches_closed_form():
     got = compute_fgd(a, b)
     assert abs(got - exact) < 0.03 * exact, (got, exact)
     assert abs(compute_fgd(a, b) - compute_fgd(b, a)) < 1e-9 and abs(compute_fgd(a, a)) < 1e-8
+
+
+def test_fgd_matches_reference_fixture():
+    """compute_fgd against outputs of the reference's own core/utils/fgd.py:59-64 (tests/golden/make_golden.py section 5):
+    full-rank, correlated and rank-deficient (n < d: singular covariance product) code sets."""
+    import os
+
+    import numpy as np
+
+    from conftest import GOLDEN
+    from speechdrivestemplates_amd.fgd import compute_fgd
+    g = dict(np.load(os.path.join(GOLDEN, "fgd.npz")))
+    tags = sorted({k.split("/")[0] for k in g})
+    assert len(tags) == 4
+    for tag in tags:
+        ref = float(g[tag + "/fgd_ab"][0])  # the reference returns a float32 tensor
+        got = compute_fgd(g[tag + "/a"], g[tag + "/b"])
+        assert abs(got - ref) <= 2e-6 * abs(ref) + 1e-6, (tag, got, ref)
+        if tag + "/fgd_aa" in g:
+            assert abs(compute_fgd(g[tag + "/a"], g[tag + "/a"]) - float(g[tag + "/fgd_aa"][0])) <= 1e-5, tag

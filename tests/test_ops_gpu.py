@@ -615,3 +615,57 @@ assert err < 3e-6, err
         env = dict(os.environ, **{var: "3" if var == "SDT_CONV_PRIO" else "128128"})
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (var, out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("norm,stride", [("IN", 2), ("IN", 1), ("BN", 2)])
+def test_fused_dx_classes_and_backward_statistics(ops, norm, stride):
+    """An input gradient is ONE launch over its output parity classes (sdt_conv_taps_multi_f32) and, in a sequential 2-D chain,
+    its epilogue accumulates the statistics of the normalisation backward below it (sdt_norm_bwd) so that colstats<true> is
+    skipped.  Both against float64 autograd of the same two-block chain, and against the unfused launches."""
+    from speechdrivestemplates_amd.core.networks.building_blocks import ConvNormRelu
+    torch.manual_seed(3)
+    B, H, W = 3, 21, 50  # odd sizes: the parity classes have different extents
+    blk1 = ConvNormRelu('2d', 32, 64, downsample=False, norm=norm, leaky=True).to(DEV).train()
+    blk2 = ConvNormRelu('2d', 64, 32, downsample=(stride == 2), norm=norm, leaky=True).to(DEV).train()
+    x = torch.randn(B, H, W, 32, device=DEV)
+    gout = None
+    res = {}
+    for fused in (False, True):
+        ops.FUSE_DX_CLASSES = ops.FUSE_BWD_STATS = fused
+        try:
+            for b in (blk1, blk2):
+                for p in b.parameters():
+                    p.grad = None
+            xin = x.clone().requires_grad_(True)
+            h1, h2 = ops.NormBwdHolder(), ops.NormBwdHolder()
+            z1 = blk1.forward_cl(xin, None, h1)
+            z2 = blk2.forward_cl(z1, h1, h2)
+            if gout is None:
+                gout = torch.randn_like(z2)
+            z2.backward(gout)
+            torch.cuda.synchronize()
+            res[fused] = [xin.grad.clone()] + [p.grad.clone() for b in (blk1, blk2) for p in b.parameters()]
+        finally:
+            ops.FUSE_DX_CLASSES = ops.FUSE_BWD_STATS = True
+    for a, b in zip(res[True], res[False]):
+        check("fused vs unfused launches", a, b, 2e-5)
+    # float64 reference of the chain
+    def ref_block(blk, t):
+        w = blk.conv.weight.detach().double().cpu().requires_grad_(True)
+        y = F.conv2d(t, w, None, blk.stride, blk.padding)
+        if norm == "IN":
+            y = F.instance_norm(y, eps=1e-5)
+            extra = []
+        else:
+            ga = blk.norm.weight.detach().double().cpu().requires_grad_(True)
+            be = blk.norm.bias.detach().double().cpu().requires_grad_(True)
+            y = F.batch_norm(y, None, None, ga, be, True, 0.1, 1e-5)
+            extra = [ga, be]
+        return F.leaky_relu(y, 0.2), [w] + extra
+    xr = x.detach().double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    z1r, p1 = ref_block(blk1, xr)
+    z2r, p2 = ref_block(blk2, z1r)
+    z2r.backward(gout.double().cpu().permute(0, 3, 1, 2))
+    check("chain dX vs float64", res[True][0], xr.grad.permute(0, 2, 3, 1), 2e-4)
+    for got, ref in zip(res[True][1:], [p.grad for p in p1 + p2]):
+        check("chain parameter gradient vs float64", got, ref, 5e-4)
