@@ -53,7 +53,7 @@ SIGNATURES = {
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p],
-    "sdt_conv_taps_multi_f32": [_p, _p, _p, _p, _i, _i, _p, _p, _p],
+    "sdt_conv_taps_multi_f32": [_p, _p, _p, _p, _i, _i, _p, C.POINTER(NormBwd), _p],
     "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],

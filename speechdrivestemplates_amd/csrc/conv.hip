@@ -48,7 +48,9 @@ struct norm_bwd_args {
 // InstanceNorm2d / BatchNorm that follows (sdt_colnorm_fwd_f32 with stats_ready = 1) then never reads y.
 // rows_per_group >= BM, so a tile touches at most two groups.  (A run-time switch, not a template argument: one kernel
 // symbol for every forward / input-gradient launch; the branch is uniform and outside the K loop.)
-template <int BM, int BN, bool VEC4, int PRIO = 0>
+// EPI selects the epilogue at compile time (each statistics epilogue costs registers: a run-time switch took the plain kernel
+// from 7 to 5 waves per SIMD): 0 = store only, 1 = + forward statistics (stats), 2 = + normalisation-backward statistics (nb).
+template <int BM, int BN, bool VEC4, int PRIO = 0, int EPI = 0>
 __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         const geom_pack gp, const int splitk,
@@ -57,7 +59,16 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                                                         const norm_bwd_args nb) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;
-    const sdt_conv_geom& g = gp.g[blockIdx.y];  // uniform: the class this workgroup belongs to
+    // the class this workgroup belongs to (uniform).  Its scalar fields are pinned into SGPRs: read through the dynamically
+    // indexed kernel-argument pack they otherwise end up in VGPRs (+8-10 VGPRs = one wave per SIMD less)
+    const sdt_conv_geom& gt = gp.g[blockIdx.y];  // tap tables
+    struct {
+        int B, Hi, Wi, Cin, Ho, Wo, Hy, Wy, Cout, sy, sx, osy, osx, ooy, oox, ntaps, Tw;
+    } g;
+#define SDT_SGPR(f) g.f = __builtin_amdgcn_readfirstlane(gt.f)
+    SDT_SGPR(B); SDT_SGPR(Hi); SDT_SGPR(Wi); SDT_SGPR(Cin); SDT_SGPR(Ho); SDT_SGPR(Wo); SDT_SGPR(Hy); SDT_SGPR(Wy); SDT_SGPR(Cout);
+    SDT_SGPR(sy); SDT_SGPR(sx); SDT_SGPR(osy); SDT_SGPR(osx); SDT_SGPR(ooy); SDT_SGPR(oox); SDT_SGPR(ntaps); SDT_SGPR(Tw);
+#undef SDT_SGPR
     __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
     __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
     __shared__ int sOut[BM];
@@ -88,9 +99,9 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     const int n0 = (lin % nnb) * BN;
 
     if (tid < g.ntaps) {
-        sTap[tid] = g.dy[tid];
-        sTap[SDT_MAX_TAPS + tid] = g.dx[tid];
-        sTap[2 * SDT_MAX_TAPS + tid] = g.wt[tid];
+        sTap[tid] = gt.dy[tid];
+        sTap[SDT_MAX_TAPS + tid] = gt.dx[tid];
+        sTap[2 * SDT_MAX_TAPS + tid] = gt.wt[tid];
     }
     if (tid < SDT_MAX_TAPS) sFlag[tid] = 0;
     if (tid < BM) {
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 const int off = sOut[row];
                 if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
             }
-            if (stats != nullptr) {
+            if constexpr (EPI == 1) {
                 const int g0 = m0 / rows_per_group;
                 const int mb = (g0 + 1) * rows_per_group;  // first row of the next group
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     }
                 }
             }
-            if (nb.sums != nullptr) {  // uniform; statistics of the normalisation backward that consumes this gradient
+            if constexpr (EPI == 2) {  // statistics of the normalisation backward that consumes this gradient
                 const int rpg = nb.groups == 1 ? M : g.Ho * g.Wo;  // >= BM (host-checked): a tile touches at most two groups
                 const int g0 = m0 / rpg;
                 const int mb = (g0 + 1) * rpg;
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     if (nb.beta != nullptr) be = nb.beta[n];
                 }
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-#pragma unroll
+#pragma unroll 4
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int off = sOut[row];
@@ -1251,6 +1262,10 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
         return;
     }
 #define SDT_TAPS(PRIO) hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, PRIO>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize, (double*)nullptr, 0, nb)
+    if (nb.sums != nullptr) {  // host-checked: vector path, fp32 math, no split-K
+        hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, 0, 2>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize, (double*)nullptr, 0, nb);
+        return;
+    }
 #ifdef SDT_TUNING  // ablation / A-B instantiations (some compute WRONG results by design): tuning build only
     static const int prio = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;
     if (vec4 && prio == 1) SDT_TAPS(1);
@@ -1395,14 +1410,14 @@ extern "C" int sdt_conv_taps_stats_f32(const float* x, const float* w, const flo
 #ifdef SDT_TUNING
     static const int order = getenv("SDT_CONV_PRIO") ? atoi(getenv("SDT_CONV_PRIO")) : 0;  // A/B only
     if (order == 12)
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 12, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
                            (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     else if (order == 14)
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 14, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
                            (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     else
 #endif
-        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
+        hipLaunchKernelGGL((conv_taps_kernel<64, 64, true, 0, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, gp, 1,
                            (float*)nullptr, ysize, stats, rows_per_group, kNoNormBwd);
     SDT_LAUNCH_CHECK();
     return SDT_OK;

@@ -81,6 +81,22 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+
+def _collect(procs, q, n, timeout):
+    """n results from the worker queue; fails fast (instead of waiting out the timeout) when a worker has died"""
+    import queue as _queue
+    import time as _time
+    out, t0 = [], _time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "worker exited with %s" % dead
+            assert _time.time() - t0 < timeout, "timed out waiting for the workers"
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -97,7 +113,7 @@ def test_two_rank_gradient_exchange_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=500) for _ in procs)
+    res = sorted(_collect(procs, q, len(procs), 500))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -215,7 +231,7 @@ def test_replicas_start_identical_despite_different_seeds_and_stay_identical():
     procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=250) for _ in procs), key=lambda t: t[0])
+    res = sorted(_collect(procs, q, len(procs), 250), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

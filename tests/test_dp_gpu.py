@@ -15,6 +15,8 @@ import torch.multiprocessing as mp
 from conftest import REPO
 from test_dp_gloo import _free_port
 
+from test_dp_gloo import _collect  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 CFG, N_CLIPS, B_RANK, STEPS = "voice2pose_sdt_vae", 16, 2, 2
@@ -74,7 +76,7 @@ def test_two_ranks_one_gpu_match_single_process_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=800) for _ in procs), key=lambda t: t[0])
+    res = sorted(_collect(procs, q, len(procs), 800), key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -130,7 +132,7 @@ def test_differently_seeded_ranks_are_synchronised_at_construction():
     procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=800) for _ in range(4)]
+    res = _collect(procs, q, 4, 800)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
