@@ -114,6 +114,33 @@ typedef struct sdt_wt_desc {
 } sdt_wt_desc;
 int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int total_tiles, void* stream);
 
+/*
+ * fp32-equivalent conv products on the bf16 MFMA from PRE-SPLIT operands (csrc/presplit.hip): an fp32 value is split exactly
+ * into three bf16 pieces by truncation (x = x1 + x2 + x3) and a product is the six MFMA products a1b1, a1b2, a2b1, a2b2, a1b3,
+ * a3b1 accumulated in fp32 (dropped terms < 2^-23 |ab|).  A "planes" tensor is [3][n] bf16, plane-major, n = numel of the fp32
+ * tensor it mirrors, same element order.  Replaces the same ATen convolution calls as sdt_conv_taps_f32
+ * (building_blocks.py:15-22) for 2-D layers with Cin % 32 == 0; fp32 storage and accumulation are unchanged.
+ *   sdt_split_planes_f32    : x (n floats, n % 8 == 0) -> planes (standalone split; the normalisation kernels emit planes themselves)
+ *   sdt_weight_planes_batched: planes of W (cout,taps,cin) AND of its (cin,taps,cout) mirror for many layers in one launch;
+ *                              tile_begin / total_tiles as in sdt_weight_transpose_batched_f32
+ *   sdt_conv_taps_pre_f32   : forward conv (ncls = 1; stats != NULL accumulates the forward statistics as
+ *                              sdt_conv_taps_stats_f32) or input gradient (ncls parity classes; nb != NULL accumulates the
+ *                              normalisation-backward statistics as sdt_conv_taps_multi_f32) from x planes and w planes.
+ */
+typedef struct sdt_wp_desc {
+    const float* w; /* (cout, taps, cin) fp32 */
+    void* wp;       /* [3](cout, taps, cin) bf16 */
+    void* wtp;      /* [3](cin, taps, cout) bf16 */
+    int32_t cout, taps, cin, tile_begin;
+} sdt_wp_desc;
+int sdt_split_planes_f32(const float* x, void* planes, int64_t n, void* stream);
+int sdt_weight_planes_batched(const sdt_wp_desc* table, int n_layers, int total_tiles, void* stream);
+int sdt_conv_taps_pre_f32(const void* x_planes, int64_t x_plane_elems, const void* w_planes, int64_t w_plane_elems, float* y,
+                          const sdt_conv_geom* geoms, int ncls, double* stats, int rows_per_group, const sdt_norm_bwd* nb,
+                          void* stream);
+/* developer switch: force the tile of sdt_conv_taps_pre_f32 (0 = automatic, 64064, 128064, 128128) */
+int sdt_set_pre_tile(int tile);
+
 /* out[c] += sum_rows x[row, c]  (bias gradient of the k1 head conv, generator.py:103). */
 int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream);
 
@@ -127,6 +154,8 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
  * num_batches_tracked (nullable) is the
  * BatchNorm int64 counter, incremented on the device.  gamma/beta/running_* may be NULL (IN).
  * stats_ready != 0: sums already holds sum(y), sum(y^2) per (g, c) (sdt_conv_taps_stats_f32) -- the statistics pass is skipped.
+ * z_planes / dy_planes (nullable): the output is ALSO written as three bf16 planes [3][G*R*C] (exact split, csrc/presplit.hip)
+ * for sdt_conv_taps_pre_f32.
  * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
  * momentum (unbiased variance), as nn.BatchNorm does in training mode.
  * eval: z = act(gamma*(y-running_mean)/sqrt(running_var+eps)+beta).
@@ -134,7 +163,7 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
 int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                        float slope, int stats_ready, void* stream);
+                        float slope, int stats_ready, void* z_planes, void* stream);
 int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
                          int64_t rows, int C, float eps, float slope, void* stream);
@@ -143,7 +172,7 @@ int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const flo
  * conv that produced dz, sdt_conv_taps_multi_f32 with nb) -- the statistics pass over dz and y is skipped. */
 int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, float* dgamma,
-                        float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* stream);
+                        float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* dy_planes, void* stream);
 
 /*
  * First audio-encoder block fused for Cin == 1: Conv2d(1,64,k3,s1,p1,bias=False) -> InstanceNorm2d (groups = B) or
@@ -159,7 +188,7 @@ int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums
 int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
-                         float slope, void* stream);
+                         float slope, void* z_planes /* nullable: z also as [3][B*H*W*64] bf16 planes */, void* stream);
 int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, const double* mom, double* sums, float* dw, float* dgamma,
                          float* dbeta, int B, int H, int W, int groups, float slope, void* stream);

@@ -26,6 +26,12 @@ class NormBwd(C.Structure):
                 ("sums", C.c_void_p), ("slope", C.c_float), ("groups", C.c_int32)]
 
 
+class WpDesc(C.Structure):
+    """Mirror of ``sdt_wp_desc`` (include/sdt_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wtp", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32),
+                ("cin", C.c_int32), ("tile_begin", C.c_int32)]
+
+
 class WtDesc(C.Structure):
     """Mirror of ``sdt_wt_desc`` (include/sdt_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32),
@@ -48,13 +54,17 @@ SIGNATURES = {
     "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],
     "sdt_set_conv_math": [_i],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
-    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p],
+    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p, _p],
     "sdt_conv_taps_stats_supported": [_G, _i],
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
-    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p],
-    "sdt_conv_taps_multi_f32": [_p, _p, _p, _p, _i, _i, _p, C.POINTER(NormBwd), _p],
-    "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
+    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p, _p],
+    "sdt_split_planes_f32": [_p, _p, _i64, _p],
+    "sdt_weight_planes_batched": [_p, _i, _i, _p],
+    "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
+    "sdt_set_pre_tile": [_i],
+    "sdt_conv_taps_multi_f32": [_p, _p, _p, _G, _i, _i, _p, C.POINTER(NormBwd), _p],
+    "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_rownorm_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i, _f, _p],

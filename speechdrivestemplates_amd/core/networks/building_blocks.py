@@ -51,21 +51,24 @@ class ConvNormRelu(nn.Module):
         if self._is_l0_block():  # single-channel mel image: conv + norm + activation fused, output written once
             n = self.norm
             if self.norm_type == 'IN':
-                return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, None, None, None, None, None, x_cl.shape[0], self.slope)
+                return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, None, None, None, None, None, x_cl.shape[0], self.slope,
+                                           out_holder)
             return ops.L0BlockFn.apply(x_cl.squeeze(-1), self.conv.weight, n.weight, n.bias, n.running_mean, n.running_var,
-                                       n.num_batches_tracked, 1, self.slope)
+                                       n.num_batches_tracked, 1, self.slope, out_holder)
         if self.norm_type == 'IN' and self.conv_type == '1d':  # conv (+ split-K reduction) + norm over C + activation
             return ops.ConvRowNormFn.apply(x_cl, self.conv.weight, self.stride, self.padding, self.slope)
         if self.conv_type == '2d' and (self.norm_type == 'IN' or self.training):
             groups = x_cl.shape[0] if self.norm_type == 'IN' else 1
-            if ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups):
+            if (ops.presplit_usable(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)
+                    or ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups)):
                 # the conv's epilogue accumulates the normalisation statistics: y is not re-read for them
-                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)
+                link = ops.BlockLink() if (ops.presplit_on() and torch.is_grad_enabled()) else None
+                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder, link)
                 n = self.norm
                 if self.norm_type == 'IN':
-                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums, out_holder)
+                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums, out_holder, link)
                 return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
-                                              self.slope, sums, out_holder)
+                                              self.slope, sums, out_holder, link)
         y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding, in_holder)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W

@@ -37,9 +37,10 @@ class AudioEncoder(nn.Module):
                 if hooks and i in hooks and x.requires_grad:
                     # fires in backward once blocks i.. have produced their weight gradients (dp.GradReducer buckets)
                     x.register_hook(hooks[i])
-                nxt = ops.NormBwdHolder() if (i > 0 and torch.is_grad_enabled()) else None  # block 0 is the fused L0 kernel
+                last = i == 7  # the last block feeds the resize, not a conv: nobody would use its hand-over
+                nxt = ops.NormBwdHolder() if (not last and (torch.is_grad_enabled() or ops.presplit_on())) else None
                 x = block.forward_cl(x, holder, nxt)
-                holder = nxt if (nxt is not None and nxt.y is not None) else None
+                holder = nxt if (nxt is not None and (nxt.y is not None or nxt.zp is not None)) else None
                 i += 1
         return x
 

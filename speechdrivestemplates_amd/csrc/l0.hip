@@ -158,7 +158,8 @@ __device__ __forceinline__ f32x4 l0_yhat(const L0Thread& t, const float (&nb)[L0
 __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ mel, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ z, int H, int W, int groups, float slope) {
+                                                     float* __restrict__ z, int H, int W, int groups, float slope,
+                                                     __bf16* __restrict__ zp, size_t plane) {
     const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, groups == 1 ? 0 : b, cq);
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_fwd(yh[e] * t.ga[e] + t.be[e], slope);
         *(f32x4*)(out + (size_t)x * L0_C) = o;
+        if (zp != nullptr) store_planes4(o, zp + (out - z) + (size_t)x * L0_C, plane);  // exact 3-way bf16 split (presplit.hip)
     }
 }
 
@@ -304,7 +306,7 @@ static int l0_ppb(int HW) { return std::max(1024, std::min(4096, cdiv(HW, 8) / 2
 extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
-                                    float slope, void* stream) {
+                                    float slope, void* z_planes, void* stream) {
     SDT_CHECK_ARG(mel && w && z && mom && mean && rstd, "null pointer");
     SDT_CHECK_ARG(B > 0 && H > 0 && W > 0 && (groups == B || groups == 1), "bad dims (groups must be B or 1)");
     SDT_CHECK_ARG((int64_t)B * H * W * L0_C * 4 < (1ll << 40), "tensor too large");
@@ -315,7 +317,8 @@ extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, 
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_finalize_kernel, dim3(cdiv(groups * L0_C, 64)), dim3(64), 0, s, mom, w, mean, rstd, running_mean,
                        running_var, num_batches_tracked, B, groups, n, eps, momentum);
-    hipLaunchKernelGGL(l0_fwd_kernel, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, z, H, W, groups, slope);
+    hipLaunchKernelGGL(l0_fwd_kernel, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, z, H, W, groups, slope,
+                       (__bf16*)z_planes, (size_t)B * H * W * L0_C);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
                                                                 const float* __restrict__ beta, float* __restrict__ rmean,
                                                                 float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                                                 int64_t R, int C, int rows_per_block, float eps,
-                                                                float momentum, float slope) {
+                                                                float momentum, float slope, __bf16* __restrict__ zp,
+                                                                size_t plane) {
     const int tid = threadIdx.x, g = blockIdx.y;
     const int tpr = C >> 2, rpp = 256 / tpr;
     const int cv = tid % tpr, rr = tid / tpr;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[j][e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
                 *(f32x4*)(z + base + (size_t)rj * C) = o;
+                if (zp != nullptr) store_planes4(o, zp + base + (size_t)rj * C, plane);  // exact 3-way bf16 split (presplit.hip)
             }
         }
     }
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int64_t R, int C, int rows_per_block, float slope) {
+                                                                int64_t R, int C, int rows_per_block, float slope,
+                                                                __bf16* __restrict__ dyp, size_t plane) {
     const int tid = threadIdx.x, g = blockIdx.y;
     const int tpr = C >> 2, rpp = 256 / tpr;
     const int cv = tid % tpr, rr = tid / tpr;
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
                     o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
                 }
                 *(f32x4*)(dy + base + (size_t)rj * C) = o;
+                if (dyp != nullptr) store_planes4(o, dyp + base + (size_t)rj * C, plane);
             }
         }
     }
@@ -326,7 +330,7 @@ static int check_colnorm(int G, int64_t R, int C) {
 extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                                   float slope, int stats_ready, void* stream) {
+                                   float slope, int stats_ready, void* z_planes, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
@@ -339,8 +343,9 @@ extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float
     }
     const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
+    SDT_CHECK_ARG(z_planes == nullptr || ((uintptr_t)z_planes % 8 == 0), "planes must be 8-byte aligned");
     hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
-                       running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope);
+                       running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope, (__bf16*)z_planes, (size_t)G * R * C);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
@@ -361,7 +366,7 @@ extern "C" int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma
 
 extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                   int G, int64_t R, int C, float slope, int stats_ready, void* stream) {
+                                   int G, int64_t R, int C, float slope, int stats_ready, void* dy_planes, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(dz && y && dy && sums && mean && rstd, "null pointer");
@@ -375,7 +380,7 @@ extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, d
     const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
     hipLaunchKernelGGL(colnorm_apply_bwd_kernel, grid, dim3(256), 0, s, dz, y, dy, sums, mean, rstd, gamma, beta, dgamma,
-                       dbeta, R, C, rpb, slope);
+                       dbeta, R, C, rpb, slope, (__bf16*)dy_planes, (size_t)G * R * C);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

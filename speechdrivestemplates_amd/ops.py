@@ -245,11 +245,26 @@ class NormBwdHolder:
     output, for ONE-consumer chains (the audio encoder): the consumer's input-gradient launch accumulates the statistics the
     normalisation's backward needs in its epilogue (sdt_conv_taps_multi_f32 with sdt_norm_bwd) and leaves them in ``sums``; the
     normalisation's backward then skips its statistics pass over dz and y."""
-    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums")
+    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums", "zp")
 
     def __init__(self):
         self.y = self.mean = self.rstd = self.gamma = self.beta = self.sums = None
         self.groups, self.slope = 0, 0.0
+        self.zp = None  # bf16 planes [3][numel] of the normalisation's OUTPUT z (pre-split pipeline, presplit.hip)
+
+
+class BlockLink:
+    """Hand-over inside one conv + normalisation block in the pre-split pipeline: the normalisation's backward leaves the bf16
+    planes of dy here for the convolution's backward that autograd runs next."""
+    __slots__ = ("gy_planes",)
+
+    def __init__(self):
+        self.gy_planes = None
+
+
+def planes_like(t):
+    """uninitialised [3][numel] bf16 planes for an fp32 tensor"""
+    return torch.empty((3, t.numel()), device=t.device, dtype=torch.bfloat16)
 
 
 class ConvProfiler:
@@ -348,7 +363,7 @@ def _conv_launch(kind, is2d, g, call):
     PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
-def _conv_launch_multi(kind, is2d, gs, call):
+def _conv_launch_multi(kind, is2d, gs, call, pre=False):
     """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient)"""
     if PROFILER is None:
         check(call())
@@ -362,7 +377,8 @@ def _conv_launch_multi(kind, is2d, gs, call):
     e0.record()
     check(call())
     e1.record()
-    PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
+    name = "conv_taps_pre_kernel (bf16x6 products, pre-split operands)" if pre else ConvProfiler.kernel_name(kind, var)
+    PROFILER.records.append((name, kind, is2d, flops, nbytes, e0, e1))
 
 
 def _splitk_hint(lib, g):
@@ -392,6 +408,11 @@ def conv_forward(x_cl, w, bias, stride, pad):
 
 
 CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+PRESPLIT = True  # in 'bf16x6' mode the 2-D chain runs on PRE-SPLIT bf16 planes (sdt_conv_taps_pre_f32) where producers emit them
+
+
+def presplit_on():
+    return PRESPLIT and _CONV_MATH_NOW[0] == 6
 _CONV_MATH_NOW = [0]  # mirror of the library's process-wide setting (only set_conv_math changes it)
 
 
@@ -418,6 +439,8 @@ class WeightMirrors:
     def __init__(self, params):
         import ctypes as C
         self.entries, descs, tiles = [], [], 0
+        pdescs, ptiles = [], 0
+        self.planes_dirty = True
         for p in params:
             if p.dim() not in (3, 4):
                 continue
@@ -427,9 +450,18 @@ class WeightMirrors:
             cout, taps, cin = ws.shape
             wt = torch.empty((cin, taps, cout), device=p.device, dtype=torch.float32)
             descs.append(_lib.WtDesc(ws.data_ptr(), wt.data_ptr(), cout, taps, cin, tiles))
+            planes = None
+            if p.dim() == 4 and cin % 32 == 0 and cout % 32 == 0:  # 2-D layers the pre-split conv kernel can take
+                planes = (torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16),
+                          torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16))
+                pdescs.append(_lib.WpDesc(ws.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), cout, taps, cin, ptiles))
+                ptiles += ((cin + 31) // 32) * ((cout + 31) // 32) * taps
             tiles += ((cin + 31) // 32) * ((cout + 31) // 32) * taps
-            self.entries.append([p, wt, -1])
-        self.total_tiles = tiles
+            self.entries.append([p, wt, -1, planes])
+        self.total_tiles, self.total_ptiles, self.n_planes = tiles, ptiles, len(pdescs)
+        if pdescs:
+            parr = (_lib.WpDesc * len(pdescs))(*pdescs)
+            self.ptable = torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.entries[0][0].device)
         if descs:
             arr = (_lib.WtDesc * len(descs))(*descs)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
@@ -449,6 +481,30 @@ class WeightMirrors:
 
     def mark_dirty(self):
         self.dirty = True
+        self.planes_dirty = True
+
+    def refresh_planes(self):
+        """bf16 planes of every 2-D weight and of its mirror (pre-split pipeline): one launch per optimiser step, on first use"""
+        if self.n_planes:
+            check(_lib.load().sdt_weight_planes_batched(_p(self.ptable), self.n_planes, self.total_ptiles, _stream()))
+        self.planes_version = [e[0]._version for e in self.entries]
+        self.planes_dirty = False
+
+    @staticmethod
+    def lookup_planes(w):
+        """(planes of W, planes of the (Cin,taps,Cout) mirror) or None"""
+        hit = WeightMirrors._by_ptr.get(w.data_ptr())
+        if hit is None:
+            return None
+        owner = hit[0]()
+        if owner is None:
+            return None
+        e = owner.entries[hit[1]]
+        if e[3] is None or e[0].data_ptr() != w.data_ptr() or e[0].shape != w.shape:
+            return None
+        if owner.planes_dirty or owner.planes_version[hit[1]] != e[0]._version:
+            owner.refresh_planes()
+        return e[3]
 
     @staticmethod
     def lookup(w):
@@ -459,7 +515,7 @@ class WeightMirrors:
         if owner is None:
             del WeightMirrors._by_ptr[w.data_ptr()]
             return None
-        p, wt, version = owner.entries[hit[1]]
+        p, wt, version = owner.entries[hit[1]][:3]
         if p.data_ptr() != w.data_ptr() or p.shape != w.shape:
             return None
         if owner.dirty or version != p._version:
@@ -471,7 +527,7 @@ FUSE_DX_CLASSES = True   # one launch for all output parity classes of a strided
 FUSE_BWD_STATS = True    # normalisation-backward statistics in the input-gradient epilogue (fp32 math, 2-D chains)
 
 
-def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None):
+def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=None):
     """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights -- one geometry per output parity class, all
     classes in ONE launch in fp32 math.  ``norm_holder``: the NormBwdHolder of the normalisation that produced x (see there)."""
     lib = _lib.load()
@@ -487,6 +543,23 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None):
         wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
         check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
     dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
+    if gy_planes is not None and presplit_on() and not one_d and Cout % 32 == 0:
+        # pre-split pipeline: gy arrives as bf16 planes (written by the normalisation backward), the weights' mirror planes are
+        # refreshed once per optimiser step; all parity classes in one launch, backward statistics in the epilogue
+        wpl = WeightMirrors.lookup_planes(w)
+        pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, False)
+        if wpl is not None and pack is not None:
+            arr, n, gs = pack
+            nb = None
+            h = norm_holder
+            if (h is not None and FUSE_BWD_STATS and h.y is not None and tuple(h.y.shape) == tuple(dx.shape)
+                    and all((g.B * g.Ho * g.Wo if h.groups == 1 else g.Ho * g.Wo) >= 128 for g in gs)):
+                h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
+                nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+            _conv_launch_multi("dX", True, gs,
+                               lambda: lib.sdt_conv_taps_pre_f32(_p(gy_planes), gy_planes.shape[1], _p(wpl[1]), wpl[1].shape[1], _p(dx),
+                                                                 arr, n, None, 0, nb, st), pre=True)
+            return dx
     pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
     if pack is not None:
         arr, n, gs = pack
@@ -649,7 +722,7 @@ class ConvFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
-def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None):
+def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None, gy_planes=None):
     """Weight / bias gradients accumulated into ``.grad``; returns dX (or None)."""
     if w.requires_grad:
         # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
@@ -669,26 +742,47 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None):
     if bias is not None and bias.requires_grad:
         gb = grad_buffer(bias)
         check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
-    return conv_input_grad(gy, w, x_cl.shape, stride, pad, in_holder) if need_dx else None
+    return conv_input_grad(gy, w, x_cl.shape, stride, pad, in_holder, gy_planes) if need_dx else None
+
+
+def presplit_usable(x_cl, w, stride, pad, groups, in_holder):
+    """True when a 2-D conv + column-norm block can run its forward conv on pre-split operands: 'bf16x6' math, the producer of
+    x left its bf16 planes in ``in_holder``, the weight has planes, dense geometry with >= 128 rows per statistics group."""
+    if not presplit_on() or in_holder is None or in_holder.zp is None or x_cl.dim() != 4 or w.dim() != 4:
+        return False
+    if x_cl.shape[-1] % 32 or w.shape[0] % 32 or in_holder.zp.shape[1] != x_cl.numel():
+        return False
+    g = conv_geom_for(x_cl.shape, w, stride, pad)
+    m = g.B * g.Ho * g.Wo
+    return m % groups == 0 and m // groups >= 128 and WeightMirrors.lookup_planes(w) is not None
 
 
 class ConvStatsFn(torch.autograd.Function):
     """Bias-free forward conv whose epilogue also accumulates the per-(group, channel) sum / sum of squares of its output
-    (sdt_conv_taps_stats_f32) -- the statistics pass of the InstanceNorm2d / BatchNorm that follows.  Returns (y, sums);
-    ``sums`` goes to ColNormActFn(..., sums).  Use only when ``conv_stats_fusable`` says so."""
+    (sdt_conv_taps_stats_f32, or sdt_conv_taps_pre_f32 on pre-split operands) -- the statistics pass of the InstanceNorm2d /
+    BatchNorm that follows.  Returns (y, sums); ``sums`` goes to ColNormActFn(..., sums).  Use only when ``conv_stats_fusable``
+    or ``presplit_usable`` says so."""
 
     @staticmethod
-    def forward(ctx, x_cl, w, stride, pad, groups, in_holder=None):
+    def forward(ctx, x_cl, w, stride, pad, groups, in_holder=None, link=None):
         _req_cuda(x_cl, w)
         lib = _lib.load()
+        pre = presplit_usable(x_cl, w, stride, pad, groups, in_holder)
         x_cl = x_cl.contiguous()
-        ctx.in_holder = in_holder
+        ctx.in_holder, ctx.link = in_holder, link
         g = conv_geom_for(x_cl.shape, w, stride, pad)
         y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
         sums = _ARENA.take(2 * groups * g.Cout, x_cl.device)
         rpg = g.B * g.Ho * g.Wo // groups
         ws, st = weight_storage(w), _stream()
-        _conv_launch("fwd", True, g, lambda: lib.sdt_conv_taps_stats_f32(_p(x_cl), _p(ws), None, _p(y), g, _p(sums), rpg, st))
+        if pre:
+            wpl, xp = WeightMirrors.lookup_planes(w), in_holder.zp
+            _conv_launch_multi("fwd", True, [g],
+                               lambda: lib.sdt_conv_taps_pre_f32(_p(xp), xp.shape[1], _p(wpl[0]), wpl[0].shape[1], _p(y), g, 1, _p(sums),
+                                                                 rpg, None, st), pre=True)
+            in_holder.zp = None  # x has exactly one consumer in this chain: the planes can go back to the allocator
+        else:
+            _conv_launch("fwd", True, g, lambda: lib.sdt_conv_taps_stats_f32(_p(x_cl), _p(ws), None, _p(y), g, _p(sums), rpg, st))
         ctx.save_for_backward(x_cl, w)
         ctx.stride, ctx.pad = stride, pad
         ctx.mark_non_differentiable(sums)
@@ -698,8 +792,11 @@ class ConvStatsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gsums):
         x_cl, w = ctx.saved_tensors
-        return (_conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder),
-                None, None, None, None, None)
+        gyp = None
+        if ctx.link is not None:
+            gyp, ctx.link.gy_planes = ctx.link.gy_planes, None
+        return (_conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder, gyp),
+                None, None, None, None, None, None)
 
 
 def conv_stats_fusable(x_cl, w, stride, pad, groups):
@@ -768,7 +865,7 @@ class ColNormActFn(torch.autograd.Function):
     """InstanceNorm2d (groups = batch) or training-mode BatchNorm (groups = 1) + LeakyReLU/ReLU."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None, holder=None):
+    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None, holder=None, link=None):
         _req_cuda(y)
         lib = _lib.load()
         y = y.contiguous()
@@ -780,13 +877,15 @@ class ColNormActFn(torch.autograd.Function):
             sums = _ARENA.take(2 * groups * C, y.device)
         mean = torch.empty(groups * C, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        # pre-split pipeline: z is also written as bf16 planes for the next block's conv (dropped there after use)
+        zp = planes_like(z) if (holder is not None and presplit_on() and y.dim() == 4 and C % 32 == 0) else None
         check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
-                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _stream()))
+                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _p(zp), _stream()))
         ctx.save_for_backward(y, mean, rstd, gamma, beta)
-        ctx.groups, ctx.slope, ctx.holder = groups, slope, holder
+        ctx.groups, ctx.slope, ctx.holder, ctx.link = groups, slope, holder, link
         if holder is not None:  # what the consuming conv's input-gradient epilogue needs (NormBwdHolder)
             holder.y, holder.mean, holder.rstd, holder.gamma, holder.beta = y, mean, rstd, gamma, beta
-            holder.groups, holder.slope, holder.sums = groups, slope, None
+            holder.groups, holder.slope, holder.sums, holder.zp = groups, slope, None, zp
         return z
 
     @staticmethod
@@ -804,9 +903,12 @@ class ColNormActFn(torch.autograd.Function):
             h.sums = None
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
+        dyp = planes_like(dy) if (ctx.link is not None and presplit_on() and y.dim() == 4 and C % 32 == 0) else None
         check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
-                                      ctx.groups, R, C, ctx.slope, int(ready), _stream()))
-        return dy, None, None, None, None, None, None, None, None, None
+                                      ctx.groups, R, C, ctx.slope, int(ready), _p(dyp), _stream()))
+        if ctx.link is not None:
+            ctx.link.gy_planes = dyp  # picked up by the block's conv backward, which autograd runs next
+        return dy, None, None, None, None, None, None, None, None, None, None
 
 
 class L0BlockFn(torch.autograd.Function):
@@ -814,7 +916,7 @@ class L0BlockFn(torch.autograd.Function):
     (first block of the audio encoder, generator.py:16).  mel (B,H,W) -> z (B,H,W,64) channels-last."""
 
     @staticmethod
-    def forward(ctx, mel, w, gamma, beta, rmean, rvar, nbt, groups, slope):
+    def forward(ctx, mel, w, gamma, beta, rmean, rvar, nbt, groups, slope, holder=None):
         _req_cuda(mel, w)
         lib = _lib.load()
         mel = mel.contiguous()
@@ -826,8 +928,11 @@ class L0BlockFn(torch.autograd.Function):
         mom = _ARENA.take(54 * B, mel.device)
         mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        zp = planes_like(z) if (holder is not None and presplit_on()) else None
         check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
-                                       _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _stream()))
+                                       _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _p(zp), _stream()))
+        if holder is not None:
+            holder.zp = zp  # no backward statistics hand-over for this block (its backward is one fused pass)
         ctx.save_for_backward(mel, w, mean, rstd, gamma, beta, mom)
         ctx.groups, ctx.slope = groups, slope
         return z
@@ -846,7 +951,7 @@ class L0BlockFn(torch.autograd.Function):
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
         check(lib.sdt_l0_block_bwd_f32(_p(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mom), _p(sums),
                                        _p(gw), _p(dg), _p(db), B, H, W, ctx.groups, ctx.slope, _stream()))
-        return None, None, None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None, None, None
 
 
 def colnorm_eval(y, gamma, beta, rmean, rvar, slope):
