@@ -117,10 +117,11 @@ int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int
 /*
  * fp32-equivalent conv products on the bf16 MFMA from PRE-SPLIT operands (csrc/presplit.hip): an fp32 value is split exactly
  * into three bf16 pieces by truncation (x = x1 + x2 + x3) and a product is the six MFMA products a1b1, a1b2, a2b1, a2b2, a1b3,
- * a3b1 accumulated in fp32 (dropped terms < 2^-23 |ab|).  A "planes" tensor is [3][n] bf16, plane-major, n = numel of the fp32
- * tensor it mirrors, same element order.  Replaces the same ATen convolution calls as sdt_conv_taps_f32
+ * a3b1 accumulated in fp32 (dropped terms < 2^-23 |ab|).  A "planes" tensor holds 3*n bf16 for the n elements of a channels-last
+ * fp32 tensor (rows, C), C % 32 == 0: piece p of element (row, c) at row*3C + (c/32)*96 + p*32 + c%32 (the three pieces of a
+ * 32-channel chunk are adjacent 64-byte runs, so a K step of the conv kernel reads 192 contiguous bytes per row).  Replaces the same ATen convolution calls as sdt_conv_taps_f32
  * (building_blocks.py:15-22) for 2-D layers with Cin % 32 == 0; fp32 storage and accumulation are unchanged.
- *   sdt_split_planes_f32    : x (n floats, n % 8 == 0) -> planes (standalone split; the normalisation kernels emit planes themselves)
+ *   sdt_split_planes_f32    : x (n floats = rows x C) -> planes (standalone split; the normalisation kernels emit planes themselves)
  *   sdt_weight_planes_batched: planes of W (cout,taps,cin) AND of its (cin,taps,cout) mirror for many layers in one launch;
  *                              tile_begin / total_tiles as in sdt_weight_transpose_batched_f32
  *   sdt_conv_taps_pre_f32   : forward conv (ncls = 1; stats != NULL accumulates the forward statistics as
@@ -133,7 +134,7 @@ typedef struct sdt_wp_desc {
     void* wtp;      /* [3](cin, taps, cout) bf16 */
     int32_t cout, taps, cin, tile_begin;
 } sdt_wp_desc;
-int sdt_split_planes_f32(const float* x, void* planes, int64_t n, void* stream);
+int sdt_split_planes_f32(const float* x, void* planes, int64_t n, int C, void* stream);
 int sdt_weight_planes_batched(const sdt_wp_desc* table, int n_layers, int total_tiles, void* stream);
 int sdt_conv_taps_pre_f32(const void* x_planes, int64_t x_plane_elems, const void* w_planes, int64_t w_plane_elems, float* y,
                           const sdt_conv_geom* geoms, int ncls, double* stats, int rows_per_group, const sdt_norm_bwd* nb,

@@ -59,7 +59,7 @@ SIGNATURES = {
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p, _p],
-    "sdt_split_planes_f32": [_p, _p, _i64, _p],
+    "sdt_split_planes_f32": [_p, _p, _i64, _i, _p],
     "sdt_weight_planes_batched": [_p, _i, _i, _p],
     "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
     "sdt_set_pre_tile": [_i],

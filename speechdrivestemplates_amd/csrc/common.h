@@ -70,15 +70,20 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
     b = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(x2) >> 16));
     c = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r2) >> 16));
 }
-// four consecutive elements -> the three planes (8-byte store per plane); dst points at the elements' position in plane 0
-__device__ __forceinline__ void store_planes4(const f32x4 v, __bf16* __restrict__ dst, size_t plane_stride) {
+// "Planes" layout (presplit.hip): the three bf16 pieces of a channels-last tensor (rows, C), C % 32 == 0, are interleaved per row
+// and per 32-channel chunk: element (row, c, piece p) lives at  row*3C + (c/32)*96 + p*32 + (c%32).  A K step of the conv kernel
+// (one 32-channel chunk of a row) then reads 192 CONTIGUOUS bytes -- with one plane-major array per piece it read three 64-byte
+// half-lines from three distant addresses, wasting half of every 128-byte L2 line it touched.
+__device__ __forceinline__ size_t planes_index(size_t row, int c, int C) { return row * (size_t)(3 * C) + (size_t)((c >> 5) * 96 + (c & 31)); }
+// four consecutive channels c..c+3 (c % 4 == 0) of one row -> the three pieces (8-byte store each); dst = planes + planes_index(row, c, C)
+__device__ __forceinline__ void store_planes4(const f32x4 v, __bf16* __restrict__ dst) {
     f32x4 r = v;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         sdt_u32x2 w;
         w[0] = sdt_pack_hi16(r[0], r[1]);
         w[1] = sdt_pack_hi16(r[2], r[3]);
-        *(sdt_u32x2*)(dst + p * plane_stride) = w;
+        *(sdt_u32x2*)(dst + p * 32) = w;
         if (p < 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = r[e] - sdt_trunc_bf16(r[e]);

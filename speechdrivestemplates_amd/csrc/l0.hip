@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_fwd(yh[e] * t.ga[e] + t.be[e], slope);
         *(f32x4*)(out + (size_t)x * L0_C) = o;
-        if (zp != nullptr) store_planes4(o, zp + (out - z) + (size_t)x * L0_C, plane);  // exact 3-way bf16 split (presplit.hip)
+        if (zp != nullptr) store_planes4(o, zp + planes_index((size_t)(b * H + y) * W + x, 4 * cq, L0_C));  // exact 3-way bf16 split
     }
 }
 

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[j][e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
                 *(f32x4*)(z + base + (size_t)rj * C) = o;
-                if (zp != nullptr) store_planes4(o, zp + base + (size_t)rj * C, plane);  // exact 3-way bf16 split (presplit.hip)
+                if (zp != nullptr) store_planes4(o, zp + planes_index((size_t)g * R + rj, 4 * cv, C));  // exact 3-way bf16 split (presplit.hip)
             }
         }
     }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
                     o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
                 }
                 *(f32x4*)(dy + base + (size_t)rj * C) = o;
-                if (dyp != nullptr) store_planes4(o, dyp + base + (size_t)rj * C, plane);
+                if (dyp != nullptr) store_planes4(o, dyp + planes_index((size_t)g * R + rj, 4 * cv, C));
             }
         }
     }

@@ -11,7 +11,8 @@
 //   gradients     colnorm_apply_bwd writes dy as three bf16 planes                                         (norm.hip)
 //   weights       weight_planes_batched_kernel: W and its (Cin,taps,Cout) mirror, once per optimiser step  (here)
 // and conv_taps_pre_kernel below is a pure bf16-MFMA implicit GEMM: 16-byte plane loads -> swizzled LDS -> ds_read_b128
-// fragments -> 6 MFMAs per (32x32x16) block.  A "planes" tensor is [3][numel] bf16, plane-major.
+// fragments -> 6 MFMAs per (32x32x16) block.  A "planes" tensor holds 3 * numel bf16 in the interleaved layout of common.h
+// (planes_index): per row and 32-channel chunk, the three pieces are adjacent 64-byte runs.
 //
 // Same tap-table contract, tap culling, XCD remap, multi-class launches and statistics epilogues as conv_taps_kernel.
 #include <stdlib.h>
@@ -45,24 +46,31 @@ struct norm_bwd_args_p {
 __device__ __forceinline__ int ptile_off(int row, int c) { return row * BKP + ((c ^ ((row >> 2) & 3)) << 3); }
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __restrict__ Xp, const size_t xplane,
+// Workgroup = WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile as 32x32 accumulators.
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF>
+__global__ __launch_bounds__(64 * WM * WN) void conv_taps_pre_kernel(const __bf16* __restrict__ Xp, const size_t xplane,
                                                             const __bf16* __restrict__ Wp, const size_t wplane,
                                                             float* __restrict__ Y, const geom_pack_p gp,
                                                             double* __restrict__ stats, const int rows_per_group,
                                                             const norm_bwd_args_p nb) {
-    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 accumulator tiles per wave (2x2 waves)
-    constexpr int RA = BM / 64, RB = BN / 64;   // 16-row groups per wave: wave w stages rows [16 (w + 4 i), +16) of each operand tile
+    constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;            // 32x32 accumulator tiles per wave
+    constexpr int RA = BM / 16 / NW, RB = BN / 16 / NW;    // 16-row groups per wave: wave w stages rows [16 (w + NW i), +16) of each tile
+    static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile / wave grid mismatch");
     constexpr int PLANEA = BM * BKP, PLANEB = BN * BKP;
-    // Staging is asynchronous global -> LDS (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass (the LDS write
-    // port was the bound of the register-staged form: 24 KB of ds_write_b128 per K step at ~80 B/clk), two LDS buffers and ONE
-    // barrier per K step.  An LDS-DMA writes wave-uniform base + lane * 16 B, so a wave instruction fills 16 rows x 64 B of one
-    // plane and the bank swizzle moves to the SOURCE side: lane (row, position q) fetches chunk q ^ ((row >> 2) & 3) of its row.
-    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3 * PLANEA];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3 * PLANEB];
-    __shared__ int sOut[BM];
-    __shared__ int sTap[3 * SDT_MAX_TAPS];
-    __shared__ int sLive[SDT_MAX_TAPS + 1];
+    // Staging is asynchronous global -> LDS (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  An LDS-DMA
+    // writes wave-uniform base + lane * 16 B, so a wave instruction fills 16 rows x 64 B of one piece and the bank swizzle moves
+    // to the SOURCE side: lane (row, position q) fetches chunk q ^ ((row >> 2) & 3) of its row.  The operand tiles live in a ring
+    // of NBUF LDS buffers: the DMA of K step s + NBUF - 1 is issued while step s computes, a wave waits only for its OLDEST
+    // outstanding step (counted s_waitcnt vmcnt) and there is ONE raw s_barrier per step -- __syncthreads() would drain every
+    // DMA in flight (hipcc emits vmcnt(0) in front of it), and so would a second __shared__ object next to the ring (hipcc then
+    // waits vmcnt(0) before every ds_read): everything sits in ONE LDS array (cdna_hip_programming.md section 5).
+    constexpr int STAGE = 3 * (PLANEA + PLANEB);                       // bf16 elements per ring slot: A pieces, then B pieces
+    constexpr int MISC_INTS = BM + 3 * SDT_MAX_TAPS + SDT_MAX_TAPS + 1;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NBUF * STAGE + 2 * MISC_INTS + 8];
+    int* const sOut = (int*)(smem + NBUF * STAGE);
+    int* const sTap = sOut + BM;
+    int* const sLive = sTap + 3 * SDT_MAX_TAPS;
 
     const sdt_conv_geom& gt = gp.g[blockIdx.y];
     struct {
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
 #undef SDT_SGPR
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int M = g.B * g.Ho * g.Wo;
     const int nmb = (M + BM - 1) / BM;
     const int nnb = (g.Cout + BN - 1) / BN;
@@ -89,21 +97,21 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
         sTap[2 * SDT_MAX_TAPS + tid] = gt.wt[tid];
     }
     if (tid <= SDT_MAX_TAPS) sLive[tid] = 0;
-    if (tid < BM) {
-        int m = m0 + tid, off = -1;
+    for (int rr = tid; rr < BM; rr += 64 * NW) {
+        int m = m0 + rr, off = -1;
         if (m < M) {
             int ox = m % g.Wo, t = m / g.Wo;
             int oy = t % g.Ho, b = t / g.Ho;
             off = ((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout;
         }
-        sOut[tid] = off;
+        sOut[rr] = off;
     }
     // loader mapping: lane = (row within the 16-row group, 16-byte position); wave w owns the row groups w + 4 i
     const int kc4 = lane & 3, r0 = wave * 16 + (lane >> 2);
     int rbH[RA], riy[RA], rix[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = m0 + r0 + 64 * i;
+        int m = m0 + r0 + 16 * NW * i;
         if (m < M) {
             int ox = m % g.Wo, t = m / g.Wo;
             int oy = t % g.Ho, b = t / g.Ho;
@@ -139,31 +147,33 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
     const int nkc = g.Cin / BKP;
     const int nsteps = ntl * nkc;
 
-    // one buffer resource per operand covering all three planes; byte offsets; masked rows use SDT_OOB (hardware returns zeros)
+    // planes layout (common.h planes_index): a row is 3*Cin bf16 = 6*Cin bytes, a 32-channel chunk 192 bytes = three 64-byte pieces;
+    // byte offsets; masked rows use SDT_OOB (hardware returns zeros)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, (int)(3u * (unsigned)xplane * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)(3u * (unsigned)wplane * 2u), 0x00020000);
-    const int xps = (int)((unsigned)xplane * 2u), wps = (int)((unsigned)wplane * 2u);  // plane strides in bytes (uniform)
     unsigned aoff[RA], boff[RB], abase[RA], bbase[RB];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) abase[i] = (unsigned)(((rbH[i] + riy[i]) * g.Wi + rix[i]) * g.Cin) * 2u;
+    for (int i = 0; i < RA; ++i) abase[i] = (unsigned)(((rbH[i] + riy[i]) * g.Wi + rix[i]) * g.Cin) * 6u;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = n0 + r0 + 64 * i;
-        bbase[i] = n < g.Cout ? (unsigned)(n * g.Tw * g.Cin) * 2u : SDT_OOB;
+        const int n = n0 + r0 + 16 * NW * i;
+        bbase[i] = n < g.Cout ? (unsigned)(n * g.Tw * g.Cin) * 6u : SDT_OOB;
     }
     int cur_tl = -1, nxt_tl = 0, nxt_kc = 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned swz = (unsigned)((kc4 ^ ((r0 >> 2) & 3)) * 16);  // byte offset of the chunk this lane fetches (rows r0 + 64 i share it)
     auto issue = [&](int buf) {
+        __bf16* const sa = smem + buf * STAGE;
+        __bf16* const sb = sa + 3 * PLANEA;
         const int tl = nxt_tl, kc = nxt_kc;
         if (++nxt_kc == nkc) nxt_kc = 0, ++nxt_tl;
-        const int cs = kc * BKP * 2;
+        const int cs = kc * 192;  // byte offset of the 32-channel chunk inside a row
         if (tl != cur_tl) {
             cur_tl = tl;
             const int t = sLive[tl];
             const int dy = sTap[t], dx = sTap[SDT_MAX_TAPS + t], wt = sTap[2 * SDT_MAX_TAPS + t];
-            const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 2u + swz;
-            const unsigned bshift = (unsigned)(wt * g.Cin) * 2u + swz;
+            const unsigned ashift = (unsigned)((dy * g.Wi + dx) * g.Cin) * 6u + swz;
+            const unsigned bshift = (unsigned)(wt * g.Cin) * 6u + swz;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
@@ -172,41 +182,60 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
 #pragma unroll
             for (int i = 0; i < RB; ++i) boff[i] = bbase[i] == SDT_OOB ? SDT_OOB : bbase[i] + bshift;
         }
-        // each instruction: 1 KiB = 16 rows x 64 B of one plane, lane * 16 B apart, at rows 16 (wave + 4 i) of the tile
+        // each instruction: 1 KiB = 16 rows x 64 B of one plane, lane * 16 B apart, at rows 16 (wave + NW i) of the tile
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(&sA[buf][p * PLANEA + (wave * 16 + 64 * i) * BKP]), 16, (int)aoff[i],
-                                                         cs + p * xps, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(sa + p * PLANEA + (wave * 16 + 16 * NW * i) * BKP), 16, (int)aoff[i],
+                                                         cs + p * 64, 0, 0);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(&sB[buf][p * PLANEB + (wave * 16 + 64 * i) * BKP]), 16, (int)boff[i],
-                                                         cs + p * wps, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(sb + p * PLANEB + (wave * 16 + 16 * NW * i) * BKP), 16, (int)boff[i],
+                                                         cs + p * 64, 0, 0);
         }
     };
 
-    f32x16 acc[TM][TN], accl[TM][TN];
+    // Accumulators.  The bf16 MFMA issues every 32 cycles but a DEPENDENT one (same accumulator) waits 64: five correction products
+    // chained into one accumulator ran the whole K loop at half rate.  The six products of a block are therefore issued
+    // product-major over the wave's tiles (consecutive MFMAs hit different accumulators), and a wave that owns a single tile keeps
+    // THREE accumulators (large term | a0b1, a1b1, a2b0 | a1b0, a0b2) so that no accumulator is reused within two issue slots.
+    constexpr int NA = (TM * TN == 1) ? 3 : 2;
+    f32x16 acc[NA][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, accl[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 
     // fragment reads: MFMA k-slot e of lane half h <-> k = 16j + 8h + e, i.e. the 16-byte chunk 2j + h of row (.. + lane & 31)
     const int fsw = (lane >> 2) & 3, fh = lane >> 5;
     const int foff[2] = {((fh ^ fsw) << 3), (((2 + fh) ^ fsw) << 3)};
-    const int rowA = (wm * (BM / 2) + (lane & 31)) * BKP, rowB = (wn * (BN / 2) + (lane & 31)) * BKP;
+    const int rowA = (wm * WTM + (lane & 31)) * BKP, rowB = (wn * WTN + (lane & 31)) * BKP;
 
-    if (nsteps > 0) issue(0);
+    // vmcnt(N) immediates: N = DMA pieces of the steps that may stay in flight; gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
+    constexpr int PIECES = 3 * (RA + RB);
+#define SDT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
+    static_assert(PIECES * (NBUF - 2) < 64, "vmcnt counter range");
+#pragma unroll
+    for (int s0 = 0; s0 < NBUF - 1; ++s0)
+        if (s0 < nsteps) issue(s0);
+    int buf = 0, nbuf = NBUF - 1;  // slot of the current step / slot the next issue goes to
     for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA pieces of `step` have landed
-        __syncthreads();                      // ... everyone's have, and everyone is done reading the other buffer
-        if (step + 1 < nsteps) issue(buf ^ 1);
-        const __bf16* pa = &sA[buf][rowA];
-        const __bf16* pb = &sB[buf][rowB];
+        // my pieces of `step` have landed once at most the (NBUF - 2) younger steps issued so far are still outstanding
+        const int younger = min(NBUF - 2, nsteps - 1 - step);
+        if (NBUF == 2 || younger == 0) SDT_VMCNT(0);
+        else if (younger == 1) SDT_VMCNT(PIECES);
+        else SDT_VMCNT(2 * PIECES);
+        __builtin_amdgcn_s_barrier();  // everyone's pieces of `step` have landed, and everyone is done reading the slot reused below
+        if (step + NBUF - 1 < nsteps) issue(nbuf);
+        const __bf16* pa = smem + buf * STAGE + rowA;
+        const __bf16* pb = smem + buf * STAGE + 3 * PLANEA + rowB;
+        nbuf = buf;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bf16x8 a[TM][3], b[TN][3];
@@ -217,17 +246,15 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) b[tn][p] = *(const bf16x8*)(pb + p * PLANEB + tn * 32 * BKP + foff[j]);
             }
+            // (A piece, B piece, accumulator) of the six products, product-major over the tiles
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0}, PC[6] = {0, 1, NA - 1, 1, NA - 1, 1};
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], acc[tm][tn], 0, 0, 0);
-                    accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], accl[tm][tn], 0, 0, 0);
-                    accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], accl[tm][tn], 0, 0, 0);
-                    accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], accl[tm][tn], 0, 0, 0);
-                    accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], accl[tm][tn], 0, 0, 0);
-                    accl[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], accl[tm][tn], 0, 0, 0);
-                }
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[PC[q]][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA[q]], b[tn][PB[q]], acc[PC[q]][tm][tn], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -235,20 +262,24 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
+            for (int r = 0; r < 16; ++r) {  // corrections first (small terms), then the large term
+                float c = acc[1][i][j][r];
+                if constexpr (NA == 3) c += acc[2][i][j][r];
+                acc[0][i][j][r] += c;
+            }
 
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)   (as conv_taps_kernel, incl. its statistics modes)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+            const int n = n0 + wn * WTN + tn * 32 + (lane & 31);
             const bool nok = n < g.Cout;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int off = sOut[row];
-                if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r];
+                if (off >= 0 && nok) Y[(size_t)off + n] = acc[0][tm][tn][r];
             }
             if constexpr (EPI == 1) {  // forward statistics of the normalisation that follows
                 const int g0 = m0 / rows_per_group;
@@ -256,9 +287,9 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int row = wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (sOut[row] >= 0 && nok) {
-                        const float v = acc[tm][tn][r];
+                        const float v = acc[0][tm][tn][r];
                         if (m0 + row < mb) {
                             s0 += v;
                             q0 = fmaf(v, v, q0);
@@ -301,13 +332,13 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll 4
                 for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int row = wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int off = sOut[row];
                     if (off >= 0 && nok) {
                         const float yv = nb.y[(size_t)off + n];
                         const bool second = m0 + row >= mb;
                         const float yh = (yv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
-                        const float gg = acc[tm][tn][r] * act_grad(yh * ga + be, nb.slope);
+                        const float gg = acc[0][tm][tn][r] * act_grad(yh * ga + be, nb.slope);
                         if (!second) {
                             s0 += gg;
                             q0 = fmaf(gg, yh, q0);
@@ -335,12 +366,13 @@ __global__ __launch_bounds__(256) void conv_taps_pre_kernel(const __bf16* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// x (n floats) -> three bf16 planes (planes + p * n): standalone split, for tensors whose producer is not one of ours.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, size_t n) {
+// x (rows, C) fp32 -> planes (layout: common.h planes_index): standalone split, for tensors whose producer is not one of ours.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, size_t n, int C) {
     const size_t nv = n >> 2;
+    const int cq = C >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
         const f32x4 v = *(const f32x4*)(x + 4 * i);
-        store_planes4(v, planes + 4 * i, n);
+        store_planes4(v, planes + planes_index(i / cq, 4 * (int)(i % cq), C));
     }
 }
 
@@ -358,7 +390,6 @@ __global__ __launch_bounds__(256) void weight_planes_batched_kernel(const sdt_wp
     rem /= nci;
     const int co0 = (rem % nco) * 32, t = rem / nco;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const size_t plane = (size_t)d.cout * d.taps * d.cin;
     __bf16* wp = (__bf16*)d.wp;
     __bf16* wtp = (__bf16*)d.wtp;
 #pragma unroll
@@ -370,10 +401,10 @@ __global__ __launch_bounds__(256) void weight_planes_batched_kernel(const sdt_wp
         if (ok) {
             __bf16 p0, p1, p2;
             split3(v, p0, p1, p2);
-            const size_t o = ((size_t)co * d.taps + t) * d.cin + ci;
+            const size_t o = planes_index((size_t)co * d.taps + t, ci, d.cin);  // rows = (cout, tap), channels = cin
             wp[o] = p0;
-            wp[plane + o] = p1;
-            wp[2 * plane + o] = p2;
+            wp[o + 32] = p1;
+            wp[o + 64] = p2;
         }
     }
     __syncthreads();
@@ -383,10 +414,10 @@ __global__ __launch_bounds__(256) void weight_planes_batched_kernel(const sdt_wp
         if (ci < d.cin && co < d.cout) {
             __bf16 p0, p1, p2;
             split3(tile[tx][ty + 8 * i], p0, p1, p2);
-            const size_t o = ((size_t)ci * d.taps + t) * d.cout + co;
+            const size_t o = planes_index((size_t)ci * d.taps + t, co, d.cout);  // mirror: rows = (cin, tap), channels = cout
             wtp[o] = p0;
-            wtp[plane + o] = p1;
-            wtp[2 * plane + o] = p2;
+            wtp[o + 32] = p1;
+            wtp[o + 64] = p2;
         }
     }
 }
@@ -408,12 +439,13 @@ static int check_geom_p(const sdt_conv_geom* g) {
 
 static int g_pre_tile = 0;  // 0 = automatic; 64064 / 128064 / 128128 force a tile (developer switch through sdt_set_pre_tile)
 extern "C" int sdt_set_pre_tile(int tile) {
-    SDT_CHECK_ARG(tile == 0 || tile == 64064 || tile == 128064 || tile == 128128, "unknown tile");
+    SDT_CHECK_ARG(tile == 0 || tile == 64064 || tile == 128064 || tile == 128128 || tile == 1281288 || tile == 1282568,
+                  "unknown tile");
     g_pre_tile = tile;
     return SDT_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM = 2, int WN = 2, int NBUF = 3>
 static void launch_pre(const __bf16* xp, size_t xplane, const __bf16* wp, size_t wplane, float* y, const sdt_conv_geom* const* gs,
                        int ncls, double* stats, int rpg, const norm_bwd_args_p& nb, hipStream_t s) {
     geom_pack_p gp;
@@ -422,11 +454,11 @@ static void launch_pre(const __bf16* xp, size_t xplane, const __bf16* wp, size_t
     for (int c = 0; c < ncls; ++c) tiles = std::max(tiles, cdiv(gs[c]->B * gs[c]->Ho * gs[c]->Wo, BM) * cdiv(gs[c]->Cout, BN));
     dim3 grid(tiles, ncls, 1);
     if (stats != nullptr)
-        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, 1>), grid, dim3(256), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
+        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, WM, WN, 1, NBUF>), grid, dim3(64 * WM * WN), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
     else if (nb.sums != nullptr)
-        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, 2>), grid, dim3(256), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
+        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, WM, WN, 2, NBUF>), grid, dim3(64 * WM * WN), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
     else
-        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, 0>), grid, dim3(256), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
+        hipLaunchKernelGGL((conv_taps_pre_kernel<BM, BN, WM, WN, 0, NBUF>), grid, dim3(64 * WM * WN), 0, s, xp, xplane, wp, wplane, y, gp, stats, rpg, nb);
 }
 
 // Forward conv / input gradient from pre-split operands (see the header of this file and include/sdt_hip.h).
@@ -468,14 +500,11 @@ extern "C" int sdt_conv_taps_pre_f32(const void* x_planes, int64_t x_plane_elems
     const __bf16* xp = (const __bf16*)x_planes;
     const __bf16* wp = (const __bf16*)w_planes;
     int tile = g_pre_tile;
-    if (tile == 0) {  // enough workgroups for >= 2 waves of the chip at 128x128, else smaller tiles
-        int64_t m = 0;
-        for (int c = 0; c < ncls; ++c) m += (int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo;
-        const int64_t t128 = cdiv64(m, 128) * cdiv(gs[0]->Cout, 128);
-        tile = (gs[0]->Cout % 128 == 0 && t128 >= 1024) ? 128128 : ((cdiv64(m, 128) * cdiv(gs[0]->Cout, 64) >= 1024) ? 128064 : 64064);
-    }
+    if (tile == 0) tile = 64064;  // measured (tools/pre_bench.py, B=32): 64x64 >= 128x64 > 128x128 on every audio-encoder layer
     switch (tile) {
         case 128128: launch_pre<128, 128>(xp, (size_t)x_plane_elems, wp, (size_t)w_plane_elems, y, gs, ncls, stats, rows_per_group, nb, s); break;
+        case 1281288: launch_pre<128, 128, 2, 4>(xp, (size_t)x_plane_elems, wp, (size_t)w_plane_elems, y, gs, ncls, stats, rows_per_group, nb, s); break;
+        case 1282568: launch_pre<128, 256, 2, 4, 2>(xp, (size_t)x_plane_elems, wp, (size_t)w_plane_elems, y, gs, ncls, stats, rows_per_group, nb, s); break;
         case 128064: launch_pre<128, 64>(xp, (size_t)x_plane_elems, wp, (size_t)w_plane_elems, y, gs, ncls, stats, rows_per_group, nb, s); break;
         default: launch_pre<64, 64>(xp, (size_t)x_plane_elems, wp, (size_t)w_plane_elems, y, gs, ncls, stats, rows_per_group, nb, s); break;
     }
@@ -483,10 +512,10 @@ extern "C" int sdt_conv_taps_pre_f32(const void* x_planes, int64_t x_plane_elems
     return SDT_OK;
 }
 
-extern "C" int sdt_split_planes_f32(const float* x, void* planes, int64_t n, void* stream) {
-    SDT_CHECK_ARG(x && planes && n > 0 && n % 8 == 0, "bad argument (n must be a multiple of 8)");
+extern "C" int sdt_split_planes_f32(const float* x, void* planes, int64_t n, int C, void* stream) {
+    SDT_CHECK_ARG(x && planes && n > 0 && C > 0 && C % 32 == 0 && n % C == 0, "bad argument (C must be a multiple of 32 dividing n)");
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n / 4, 256), 4096);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, (size_t)n);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, (size_t)n, C);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

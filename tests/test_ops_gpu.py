@@ -675,7 +675,7 @@ def _planes(ops, t):
     from speechdrivestemplates_amd import _lib
     t = t.contiguous()
     p = ops.planes_like(t)
-    _lib.check(_lib.load().sdt_split_planes_f32(t.data_ptr(), p.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+    _lib.check(_lib.load().sdt_split_planes_f32(t.data_ptr(), p.data_ptr(), t.numel(), t.shape[-1], torch.cuda.current_stream().cuda_stream))
     return p
 
 
@@ -686,14 +686,15 @@ def test_presplit_planes_are_an_exact_split(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4096, generator=g) * torch.tensor([1e-20, 1e-3, 1.0, 1e6]).repeat_interleave(1024)
     x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -100 * 1.2345678, 65504.0, 1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -23)])
-    p = _planes(ops, x.to(DEV)).float().cpu()
+    x2 = x.reshape(32, 128)  # (rows, C): pieces of element (row, c) sit at row*3C + (c/32)*96 + piece*32 + c%32
+    p = _planes(ops, x2.to(DEV)).float().cpu().reshape(32, 4, 3, 32).permute(2, 0, 1, 3).reshape(3, -1)
     tot = (p[0].double() + p[1].double() + p[2].double()).float()
     bad = (tot != x).nonzero().flatten()[:8].tolist()
     assert not bad, [(i, x[i].item(), p[0][i].item(), p[1][i].item(), p[2][i].item()) for i in bad]
     assert torch.equal(p[0] + (p[1] + p[2]), x)  # the pieces do not overlap: any fp32 summation order recovers x
 
 
-@pytest.mark.parametrize("tile", [64064, 128064, 128128])
+@pytest.mark.parametrize("tile", [64064, 128064, 128128, 1281288, 1282568])
 @pytest.mark.parametrize("case", [("k3 s1", 3, 20, 53, 128, 256, 3, 3, 1, 1), ("k4 s2", 2, 21, 40, 64, 128, 4, 4, 2, 1),
                                   ("k(6,3) p0", 2, 10, 53, 256, 256, 6, 3, 1, 0)], ids=lambda c: c[0])
 def test_presplit_conv_vs_float64(ops, case, tile):

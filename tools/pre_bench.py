@@ -20,7 +20,7 @@ LAYERS = [("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1,
 def planes(t):
     t = t.contiguous()
     p = ops.planes_like(t)
-    _lib.check(_lib.load().sdt_split_planes_f32(t.data_ptr(), p.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+    _lib.check(_lib.load().sdt_split_planes_f32(t.data_ptr(), p.data_ptr(), t.numel(), t.shape[-1], torch.cuda.current_stream().cuda_stream))
     return p
 
 
@@ -62,7 +62,7 @@ def main():
         t_f = timeit(lambda: ops.conv_forward(x, w, None, s, p), a.reps)
         t_d = timeit(lambda: ops.conv_input_grad(gy, w, x.shape, s, p), a.reps)
         line = "%-3s fp32-MFMA fwd %7.1f us %6.1f TF | dX %7.1f us %6.1f TF ||" % (name, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6)
-        for tile in (64064, 128064, 128128):
+        for tile in (64064, 128064, 1281288, 1282568):
             _lib.check(lib.sdt_set_pre_tile(tile))
             f = lambda: _lib.check(lib.sdt_conv_taps_pre_f32(xp.data_ptr(), xp.shape[1], wp.data_ptr(), wp.shape[1], y.data_ptr(), geo, 1, None, 0, None, st))  # noqa: E731
             d = lambda: _lib.check(lib.sdt_conv_taps_pre_f32(gyp.data_ptr(), gyp.shape[1], wtp.data_ptr(), wtp.shape[1], dx.data_ptr(), arr, n, None, 0, None, st))  # noqa: E731
