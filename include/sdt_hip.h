@@ -142,6 +142,47 @@ int sdt_conv_taps_pre_f32(const void* x_planes, int64_t x_plane_elems, const voi
 /* developer switch: force the tile of sdt_conv_taps_pre_f32 (0 = automatic, 64064, 128064, 128128) */
 int sdt_set_pre_tile(int tile);
 
+/*
+ * The Conv1d stage of the sdt generator as one launch per layer and direction (csrc/conv1d.hip): Conv1d (k3 s1 p1 | k4 s2 p1 | k1,
+ * building_blocks.py:8-12,31-38) whose per-(b,t) normalisation over channels + LeakyReLU (building_blocks.py:46,50-51) and the
+ * linear x2 upsample + skip add in front of the U-Net decoder convs (generator.py:79-83) are applied while the A operand is
+ * staged ("normalise on load"), and whose epilogue emits the row statistics the NEXT launch needs.
+ *   Y[b,to,n] = bias[n] + add[b,to,n] + sum_{t<taps, c<Cin} A(b, to*stride + t - pad, c) * W[n,t,c]       W (Cout,taps,Cin)
+ * in_mode 0: A = X (B,Ti,Cin).   1: A = act(norm(X)), row statistics of X from xstats.
+ *         2: A = linear_upsample(act(norm(X2 (B,T2,Cin))))[ti] + act(norm(X))[ti]  (x2stats / xstats).
+ *         3: input gradient of a layer: X = dz w.r.t. the layer's ACTIVATED output (B,Ti,Cin), X2 = its raw output y, xstats =
+ *            forward statistics, x2stats = backward statistics (sum g, sum g*yhat); A = the normalisation backward on load;
+ *            W = the (Cin_layer,taps,Cout_layer) mirror; output row to gathers layer-output rows (to + pad - t) / stride.
+ * Row statistics are PARTIALS: stats[row][np][2], one (sum, sum of squares) -- or (sum g, sum g*yhat) -- per 64-column tile of the
+ * launch that produced them (np = C / 64); consumers add the np pairs.  ystats (nullable, Cout % 64 == 0): forward partials of Y,
+ * or, when bw_y != NULL, backward partials of the layer below (raw output bw_y, forward partials bw_stats, shape of Y).
+ */
+typedef struct sdt_c1d {
+    const float* X;
+    const float* X2;
+    const float* xstats;
+    const float* x2stats;
+    const float* W;
+    const float* bias;
+    const float* add;
+    float* Y;
+    float* ystats;
+    const float* bw_y;
+    const float* bw_stats;
+    int32_t B, Ti, T2, Cin, To, Cout, taps, stride, pad;
+    int32_t in_mode, np_in, np_in2, np_bw;
+    float eps, slope;
+} sdt_c1d;
+int sdt_c1d_layer_f32(const sdt_c1d* p, void* stream);
+/* z = act(norm(y)) from partial statistics, also mean / rstd per row (feeds the generic weight-gradient kernels). */
+int sdt_c1d_rownorm_partials_f32(const float* y, const float* stats, int np, float* z, float* mean, float* rstd, int64_t rows,
+                                 int C, float eps, float slope, void* stream);
+/* Adjoint of F.interpolate(prev (B,Ti,C), To, 'linear') applied to g (B,To,C) -> dprev, fused with the backward statistics of
+ * the layer that produced prev (raw output y, forward partials stats): bstats[row][np_out][2] = {sum g', sum g'*yhat, 0...}.
+ * Ti == To degenerates to a copy + statistics. */
+int sdt_c1d_upsample_bwd_stats_f32(const float* g, float* dprev, const float* y, const float* stats, int np, float* bstats,
+                                   int np_out, int B, int Ti, int To, int C, float eps, float slope, void* stream);
+
 /* out[c] += sum_rows x[row, c]  (bias gradient of the k1 head conv, generator.py:103). */
 int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream);
 

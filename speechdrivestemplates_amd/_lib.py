@@ -26,6 +26,13 @@ class NormBwd(C.Structure):
                 ("sums", C.c_void_p), ("slope", C.c_float), ("groups", C.c_int32)]
 
 
+class C1d(C.Structure):
+    """Mirror of ``sdt_c1d`` (include/sdt_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("X", "X2", "xstats", "x2stats", "W", "bias", "add", "Y", "ystats", "bw_y", "bw_stats")]
+                + [(n, C.c_int32) for n in ("B", "Ti", "T2", "Cin", "To", "Cout", "taps", "stride", "pad", "in_mode", "np_in", "np_in2", "np_bw")]
+                + [("eps", C.c_float), ("slope", C.c_float)])
+
+
 class WpDesc(C.Structure):
     """Mirror of ``sdt_wp_desc`` (include/sdt_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wtp", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32),
@@ -63,6 +70,9 @@ SIGNATURES = {
     "sdt_weight_planes_batched": [_p, _i, _i, _p],
     "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
     "sdt_set_pre_tile": [_i],
+    "sdt_c1d_layer_f32": [C.POINTER(C1d), _p],
+    "sdt_c1d_rownorm_partials_f32": [_p, _p, _i, _p, _p, _p, _i64, _i, _f, _f, _p],
+    "sdt_c1d_upsample_bwd_stats_f32": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "sdt_conv_taps_multi_f32": [_p, _p, _p, _G, _i, _i, _p, C.POINTER(NormBwd), _p],
     "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -4,7 +4,7 @@ channels-last through the gfx950 kernels."""
 import torch
 from torch import nn
 
-from .... import ops
+from .... import ops, stage1d
 from ..building_blocks import ConvNormRelu, conv_head, make_head
 
 # (cin, cout, kernel, stride, padding) of the 8-layer mel encoder, two blocks per stage (generator.py:15-30)
@@ -105,10 +105,14 @@ class SequenceGeneratorCNN(nn.Module):
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         ops.stage_mark("g1d_fwd:begin")
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
-        h = self.unet.forward_cl(h)
-        for block in list(self.decoder)[:4]:
-            h = block.forward_cl(h)
-        h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
+        if stage1d.usable(self, h):
+            # one launch per layer and direction, normalisation / activation / upsample-add applied on load (csrc/conv1d.hip)
+            h = stage1d.Gen1dStageFn.apply(h, self, *[p for p in list(self.unet.parameters()) + list(self.decoder.parameters())])
+        else:
+            h = self.unet.forward_cl(h)
+            for block in list(self.decoder)[:4]:
+                h = block.forward_cl(h)
+            h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
         ops.stage_mark("g1d_fwd:end")
         if ops.STAGES is not None and h.requires_grad:
             h.register_hook(lambda g: ops.stage_mark("g1d_bwd:begin"))

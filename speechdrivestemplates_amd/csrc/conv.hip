@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     SDT_SGPR(B); SDT_SGPR(Hi); SDT_SGPR(Wi); SDT_SGPR(Cin); SDT_SGPR(Ho); SDT_SGPR(Wo); SDT_SGPR(Hy); SDT_SGPR(Wy); SDT_SGPR(Cout);
     SDT_SGPR(sy); SDT_SGPR(sx); SDT_SGPR(osy); SDT_SGPR(osx); SDT_SGPR(ooy); SDT_SGPR(oox); SDT_SGPR(ntaps); SDT_SGPR(Tw);
 #undef SDT_SGPR
-    __shared__ __attribute__((aligned(16))) float sA[BM * LDP];
-    __shared__ __attribute__((aligned(16))) float sB[BN * LDP];
+    constexpr bool DBUF = PRIO == 20;  // experiment: two LDS buffers, ONE barrier per K step (tile k+1 is written while tile k computes)
+    __shared__ __attribute__((aligned(16))) float sA[(DBUF ? 2 : 1) * BM * LDP];
+    __shared__ __attribute__((aligned(16))) float sB[(DBUF ? 2 : 1) * BN * LDP];
     __shared__ int sOut[BM];
     __shared__ int sTap[3 * SDT_MAX_TAPS];
     __shared__ int sLive[SDT_MAX_TAPS + 1];  // flags, then the ordered list of the taps that reach at least one in-range input for this tile; [MAX] = count
@@ -327,6 +328,45 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     const float* pa = sA + (wm * (BM / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
     const float* pb = sB + (wn * (BN / 2) + (lane & 31)) * LDP + (lane >> 5) * 4;
 
+    if constexpr (DBUF) {
+        if (step0 < nsteps) {
+            load(step0);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
+            if (step0 + 1 < nsteps) load(step0 + 1);
+        }
+        __syncthreads();
+        for (int step = step0; step < nsteps; ++step) {
+            const int cur = (step - step0) & 1;
+            if (step + 1 < nsteps) {  // regs hold tile step+1: into the other buffer (nobody reads it: its last readers passed the barrier below)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(cur ^ 1) * BM * LDP + (r0 + 32 * i) * LDP + kv * 4] = ra[i];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(cur ^ 1) * BN * LDP + (r0 + 32 * i) * LDP + kv * 4] = rb[i];
+                if (step + 2 < nsteps) load(step + 2);
+            }
+            const float* qa = pa + cur * BM * LDP;
+            const float* qb = pb + cur * BN * LDP;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] = *(const f32x4*)(qa + tm * 32 * LDP + j * 8);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[tn] = *(const f32x4*)(qb + tn * 32 * LDP + j * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    } else {
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
         if (!(PRIO == 7 || PRIO == 8 || PRIO == 9) || step == step0) {
@@ -363,6 +403,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (PRIO != 4 && (PRIO != 9 || step == step0)) __syncthreads();
+    }
     }
 
     if constexpr (TWO_ACC) {
@@ -1283,6 +1324,7 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
     else if (vec4 && prio == 12) SDT_TAPS(12);  // A/B: live taps in table (dy-major) order
     else if (vec4 && prio == 14) SDT_TAPS(14);  // A/B: row-residue tap order on every launch
     else if (vec4 && prio == 16) SDT_TAPS(16);  // A/B: tap culling also on launches with <= 4 taps
+    else if (vec4 && prio == 20) SDT_TAPS(20);  // experiment: double-buffered LDS, one barrier per K step
     else
 #endif
     if (vec4)

@@ -743,3 +743,55 @@ def test_eval_time_code_sources(opt):
         mu_ref, _ = O.pose_seq_encoder({k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}, "pose_encoder",
                                        batch["poses"], O.cfg_named("voice2pose_sdt_bp"), False)
         check("code = pose-encoder mean of the ground truth", code, mu_ref, 5e-4)
+
+
+@pytest.mark.parametrize("B", [3, 32])
+def test_fused_conv1d_stage_matches_per_block_path(B):
+    """stage1d.Gen1dStageFn (one launch per Conv1d layer and direction, normalise-on-load, csrc/conv1d.hip) against the per-block
+    path (conv -> split-K reduce + row-norm -> upsample-add) on the same generator weights: prediction, the gradient that leaves
+    the stage towards the audio encoder / clip code, and every weight gradient.  Both are exact-fp32 MFMA paths; they differ in
+    summation order and in the one-pass row variance (E[y^2] - E[y]^2 from 64-column partials) -> 2e-5 forward, 2e-4 on gradients."""
+    from speechdrivestemplates_amd import stage1d
+    from speechdrivestemplates_amd.core.networks import get_model
+    cfg = O.default_cfg(**{"VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION": 32})
+    st = {}
+    O.fill_generator(st, np.random.Generator(np.random.PCG64(3)), "netG", cfg)
+    net = get_model("SequenceGeneratorCNN")(cfg)
+    net.load_state_dict({k[len("netG."):]: v.clone() for k, v in st.items()}, strict=True)
+    net.to(DEV).train()
+    g = torch.Generator().manual_seed(B)
+    feat = torch.randn(B, 5, 51, 256, generator=g).to(DEV)
+    code = torch.randn(B, 32, generator=g).to(DEV)
+    gout = torch.randn(B, 64, 242, generator=g).to(DEV)
+    params = [p for n, p in net.named_parameters() if not n.startswith("audio_encoder.")]
+    res = {}
+    for fused in (False, True):
+        stage1d.ENABLED = fused
+        try:
+            for p in params:
+                p.grad = None
+            f, c = feat.clone().requires_grad_(True), code.clone().requires_grad_(True)
+            h = ops_mod().ResizeConcatFn.apply(f, c, 64)
+            assert stage1d.usable(net, h) == fused
+            if fused:
+                out = stage1d.Gen1dStageFn.apply(h, net, *params)
+            else:
+                out = net.unet.forward_cl(h)
+                for block in list(net.decoder)[:4]:
+                    out = block.forward_cl(out)
+                from speechdrivestemplates_amd.core.networks.building_blocks import conv_head
+                out = conv_head(out, net.decoder[4])
+            out.backward(gout)
+            ops_mod().join_side_stream()
+            torch.cuda.synchronize()
+            res[fused] = [out.detach().clone(), f.grad.clone(), c.grad.clone()] + [p.grad.clone() for p in params]
+        finally:
+            stage1d.ENABLED = True
+    names = ["prediction", "d/dfeat", "d/dcode"] + [n for n, p in net.named_parameters() if not n.startswith("audio_encoder.")]
+    for n, a, b in zip(names, res[True], res[False]):
+        check("fused 1-D stage: " + n, a, b, 2e-5 if n == "prediction" else 2e-4)
+
+
+def ops_mod():
+    from speechdrivestemplates_amd import ops
+    return ops
