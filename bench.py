@@ -47,11 +47,11 @@ CONV1D_GFLOP_PER_CLIP = {"generator_fwd_bwd": 3 * 0.243, "pose_encoder_x2": 2 * 
 # timed steps that carry HIP events around every conv launch, half of them "alone", half "as run" (see below).  A sampled
 # step costs ~1.6 ms extra (the events serialise neighbouring launches, and an "alone" step gives up the side stream), so they
 # are kept to ~1 in 15
-EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "4"))
+EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "6"))
 
 
 def event_steps(steps):
-    return min(EVENT_STEPS_MAX, max(2, (steps // 30) * 2), steps)
+    return min(EVENT_STEPS_MAX, max(3, (steps // 30) * 3), steps)
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -182,6 +182,9 @@ def main(argv=None):
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
+    ap.add_argument("--fused-conv1d", action="store_true",
+                    help="run the generator's Conv1d stage as one launch per layer and direction (csrc/conv1d.hip; measured 2 %% slower "
+                         "end to end, profiles/r02_conv1d_stage.txt)")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
 
@@ -217,6 +220,9 @@ def main(argv=None):
         from speechdrivestemplates_amd import ops
         ops.OVERLAP_DW = not args.no_overlap_dw
         ops.DEFER_SMALL_DW = not args.no_defer_dw
+        if args.fused_conv1d:
+            from speechdrivestemplates_amd import stage1d
+            stage1d.ENABLED = True
         ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
         ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
         ops.OVERLAP_AUX = not args.no_overlap_aux
@@ -258,7 +264,7 @@ def main(argv=None):
         dist.barrier()
     t0 = time.perf_counter()
     overlap_dw = ops.OVERLAP_DW if ops is not None else False
-    n_alone = n_ovl = 0
+    n_alone = n_ovl = n_stage = 0
     for i in range(args.steps):
         if marks is not None:
             marks[i].record()
@@ -267,10 +273,14 @@ def main(argv=None):
         if prof is not None:  # sampled: the events serialise the host a little and cost a few % on the steps they cover
             ops.PROFILER, ops.STAGES, ops.OVERLAP_DW = None, None, overlap_dw
             if i in sampled:
-                if prof_ovl is not None and n_alone > n_ovl:
-                    ops.PROFILER, ops.STAGES, n_ovl = prof_ovl, stages, n_ovl + 1  # stage windows are taken on "as run" steps
-                else:
+                # three kinds of sampled step in rotation: per-launch events with the side stream off ("alone"), per-launch events
+                # as run, and stage windows only (a handful of events per step: per-launch events would inflate the windows)
+                if n_alone <= n_stage:
                     ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
+                elif prof_ovl is not None and n_ovl < n_alone:
+                    ops.PROFILER, n_ovl = prof_ovl, n_ovl + 1
+                else:
+                    ops.STAGES, n_stage = stages, n_stage + 1
         losses = runner(args.warmup + i)
     if marks is not None:
         marks[args.steps].record()
@@ -307,7 +317,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1)},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d)},
             "final_G_loss": final_loss,
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included
@@ -345,7 +355,7 @@ def main(argv=None):
                                        "tflops": v["flops"] / (v["us"] * 1e-6) / 1e12} for k, v in sorted(summ.items())}
             out["conv_total"] = {"ms_per_step": tot_us / prof_steps / 1e3, "tflops": tot_fl / (tot_us * 1e-6) / 1e12,
                                  "gflop_per_step": tot_fl / prof_steps / 1e9}
-            if stages is not None and n_ovl > 0 and args.config.startswith("voice2pose"):
+            if stages is not None and n_stage > 0 and args.config.startswith("voice2pose"):
                 win = {k: v[1] / v[0] for k, v in stages.windows_us().items()}  # us per step, per window
                 if all(k in win for k in ("g1d_fwd", "g1d_bwd")):
                     scale = B / 32.0
@@ -359,10 +369,10 @@ def main(argv=None):
                         "mfma_achieved_tflops": gflop * 1e9 / (stage_us * 1e-6) / 1e12,
                         "mfma_frac": gflop * 1e9 / (stage_us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
                         "algorithmic_mb_per_step": mb, "algorithmic_gflop_per_step": gflop,
-                        "stage_us_per_step": stage_us, "windows_us": win, "exposed_us_per_step": exposed_us,
+                        "stage_us_per_step": stage_us, "windows_us": win, "event_sampled_steps": n_stage, "exposed_us_per_step": exposed_us,
                         "note": "Conv1d stacks of one train step: U-Net + decoder forward and backward chains (main stream, exposed), "
                                 "their weight gradients and the two no-grad pose-encoder passes (side stream, overlapped with the "
-                                "Conv2d backward); HIP-event windows on the stream each piece runs on, as-run sampled steps; "
+                                "Conv2d backward); HIP-event windows on the stream each piece runs on, sampled steps that carry ONLY these 8 events; "
                                 "algorithmic bytes / FLOPs from SURVEY.md 8d.  In fp32 the stage is bound by the fp32 MFMA rate and "
                                 "by launch latency, not by HBM: at the MFMA roofline (%.0f us) it would still reach only %.0f %% of 8 TB/s"
                                 % (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) * 1e6,

@@ -27,7 +27,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define C1_BN 64
 #define C1_BK 64
 #define C1_PITCH 68      // floats per LDS row of a [row][64] tile (16-byte aligned rows, 4-float skew against bank conflicts)
-#define C1_NPART_MAX 16  // partial statistics per row: Cout / 64 <= 16
+#define C1_NPART_MAX 8   // partial statistics per row: Cout / 64 <= 8
 #define C1_MAXROWS 80    // input rows a tile can touch: 32 * stride + taps - 1 <= 67; 2 source resolutions in the upsample mode
 
 enum { C1_IN_PLAIN = 0, C1_IN_NORM = 1, C1_IN_UPADD = 2, C1_IN_NORMBWD = 3 };
@@ -71,200 +71,381 @@ struct c1d_args {
     int B, Ti, T2, Cin, To, Cout, taps, stride, pad;
     int in_mode, np_in, np_in2, np_bw;
     float eps, slope;
+    unsigned cin_magic;  // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, cin_magic) for the k the kernel forms
+#ifdef SDT_TUNING
+    int dbg_mode;             // 1: multipliers skip the MFMAs, 2: loaders skip the transform + LDS stores, 4: loaders skip the global loads
+    unsigned long long* dbg;  // 64 timestamps per launch (tools/debug/c1d_timeline.py): [0,32) loader wave 0, [32,64) multiplier wave 4
+#endif
+};
+#ifdef SDT_TUNING
+#define C1_STAMP(slot)                                                                                             \
+    do {                                                                                                           \
+        if (a.dbg != nullptr && blockIdx.x == 0 && (tid & 255) == 0 && (slot) < 32) a.dbg[(loader ? 0 : 32) + (slot)] = wall_clock64(); \
+    } while (0)
+static unsigned long long* g_c1d_dbg = nullptr;
+static int g_c1d_dbg_launch = 0, g_c1d_dbg_max = 0, g_c1d_dbg_mode = 0;
+extern "C" void sdt_c1d_debug_mode(int m) { g_c1d_dbg_mode = m; }
+#define C1_DBG_MODE(bit) (a.dbg_mode & (bit))
+extern "C" void sdt_c1d_debug_buffer(void* p, int max_launches) {
+    g_c1d_dbg = (unsigned long long*)p;
+    g_c1d_dbg_launch = 0;
+    g_c1d_dbg_max = max_launches;
+}
+#else
+#define C1_STAMP(slot) do { } while (0)
+#define C1_DBG_MODE(bit) 0
+#endif
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// How the kernel got its shape (measured on MI355X, 12-16 K steps per launch, one 512-thread workgroup per CU):
+//   v1  every thread loads, transforms and multiplies; one tile of prefetch ..................... 30 us / launch whatever the grid
+//   v2  3-deep register ring of raw loads: no change -- hipcc drained vmcnt to 0 at every control-flow merge around a load
+//   v3  static load counts (template on mode, out-of-range buffer loads instead of branches, loop exits instead of guards,
+//       18 steps unrolled so that no back edge is taken): counted vmcnt(N) waits ................. 19 us
+//       what was left: the two waves of a SIMD run in lockstep between the barriers, so a step cost (loader VALU) + (MFMA);
+//       sched_group_barrier hints did not make hipcc interleave them inside a wave
+//   v4  (this) wave specialisation: waves 0-3 are LOADERS (global -> registers -> transform -> LDS), waves 4-7 are MULTIPLIERS
+//       (LDS -> MFMA); one of each per SIMD, so the hardware overlaps the loader's VALU with the multiplier's MFMA pipe.
+// Loads: raw buffer loads whose offset is pushed out of range for masked elements (zeros come back, no memory access), issued
+// C1 ring-depth steps ahead, also past the end of K (masked), so the number in flight is static and the waits are counted.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c1_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4v c1_ld4(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+__device__ __forceinline__ float c1_ld1(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+}
+// sum of the np <= C1_NPART_MAX partial (a, b) pairs of one row, all loads in flight at once
+__device__ __forceinline__ void c1_sum_partials(const __amdgpu_buffer_rsrc_t rs, unsigned row, int np, bool ok, float& s, float& q) {
+    f32x2v v[C1_NPART_MAX];
+#pragma unroll
+    for (int i = 0; i < C1_NPART_MAX; ++i)
+        v[i] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(rs, (ok && i < np) ? (int)((row * np + i) * 8u) : (int)0x80000000u, 0, 0));
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < C1_NPART_MAX; ++i) {
+        s += v[i][0];
+        q += v[i][1];
+    }
+}
+__device__ __forceinline__ void c1_mean_rstd(float s, float q, int C, float eps, float& mean, float& rstd) {
+    mean = s / (float)C;
+    float var = q / (float)C - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    rstd = 1.f / sqrtf(var + eps);
+}
+// LDS-visible workgroup barrier usable inside the (wave-uniform) role branches: every wave executes the same NUMBER of them
+__device__ __forceinline__ void c1_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// raw ring slot of one loader thread: 2 A elements (rows lr, lr + 16) and 4 B elements (rows lr + 16 j) of a 64-wide K step
+template <int MODE>
+struct c1d_raw {
+    f32x4v x[2], b[4];
+    int r[2];  // source row (< 0: masked)
+};
+template <>
+struct c1d_raw<C1_IN_UPADD> {
+    f32x4v x[2], b[4], p0[2], p1[2];
+    int r[2];
+};
+template <>
+struct c1d_raw<C1_IN_NORMBWD> {
+    f32x4v x[2], b[4], p0[2];
+    int r[2];
 };
 
+template <int MODE, bool BW>
 __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
-    __shared__ __attribute__((aligned(16))) float sA[C1_BM * C1_PITCH];
-    __shared__ __attribute__((aligned(16))) float sB[C1_BN * C1_PITCH];
-    __shared__ float sStat[2][C1_MAXROWS][4];  // per source row: mean, rstd, (s1 / C, s2 / C in the backward mode)
-    __shared__ float sPart[2][C1_BM][2];       // per wn: row partials of the epilogue
+    constexpr int D = MODE == C1_IN_NORMBWD ? 3 : (MODE == C1_IN_UPADD ? 4 : 5);  // ring depth in K steps (VGPR budget: 256 per wave)
+    constexpr int U = D == 3 ? 6 : (D == 4 ? 4 : 10);                                                       // unrolled steps: a multiple of D and of 2
+    constexpr bool bwd = MODE == C1_IN_NORMBWD;
+    typedef c1d_raw<MODE> Raw;
+    __shared__ __attribute__((aligned(16))) float sA[2][C1_BM * C1_PITCH];
+    __shared__ __attribute__((aligned(16))) float sB[2][C1_BN * C1_PITCH];
+    __shared__ __attribute__((aligned(16))) float sStat[2][C1_MAXROWS][4];  // per source row: mean, rstd, (s1 / C, s2 / C: backward mode)
+    __shared__ float sBw[C1_BM][2];       // mean, rstd of the rows of bw_y this tile stores (backward-statistics epilogue)
+    __shared__ float sPart[2][C1_BM][2];  // per wn: row partials of the epilogue
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave < 4;
     const int M = a.B * a.To;
     const int nnb = (a.Cout + C1_BN - 1) / C1_BN;
     const int m0 = (blockIdx.x / nnb) * C1_BM, n0 = (blockIdx.x % nnb) * C1_BN;
     const int Ktot = a.taps * a.Cin;
     const int nit = (Ktot + C1_BK - 1) / C1_BK;
-    const bool bwd = a.in_mode == C1_IN_NORMBWD;
+    const unsigned OOB = 0x80000000u;
+    const int sshift = a.stride - 1;  // stride is 1 or 2
 
-    // ---- prologue: statistics of the source rows this tile touches.  Rows of the primary source: a contiguous window per batch
-    // item; the tile's 32 output rows may straddle two batch items, so the table is indexed by (global row - first global row).
+    // source-row windows of the statistics tables.  Rows of the primary source: a contiguous window per batch item; the tile's 32
+    // output rows may straddle two batch items, so the tables are indexed by (global row - first global row).
     const int b_first = m0 / a.To, to_first = m0 % a.To;
-    int row_lo, row_lo2 = 0;
-    if (!bwd) {
+    int row_lo = 0, row_lo2 = 0;
+    if constexpr (!bwd) {
         row_lo = b_first * a.Ti + max(0, to_first * a.stride - a.pad);
     } else {  // contributing layer-output rows for input rows [to_first, ...): (to + p - t) / s
-        row_lo = b_first * a.Ti + max(0, (to_first + a.pad - (a.taps - 1)) / a.stride);
+        row_lo = b_first * a.Ti + max(0, (to_first + a.pad - (a.taps - 1)) >> sshift);
     }
-    if (a.in_mode == C1_IN_UPADD) row_lo2 = b_first * a.T2 + max(0, (max(0, to_first * a.stride - a.pad)) / 2 - 1);
-    if (a.in_mode != C1_IN_PLAIN) {
-        const int total = a.B * a.Ti;
-        for (int j = tid; j < C1_MAXROWS; j += 512) {
-            const int r = row_lo + j;
-            if (r < total) {
-                float mu, rs;
-                c1_row_stats(a.xstats + (size_t)r * a.np_in * 2, a.np_in, a.Cin, a.eps, mu, rs);
-                sStat[0][j][0] = mu;
-                sStat[0][j][1] = rs;
-                if (bwd) {
-                    float s1 = 0.f, s2 = 0.f;
-                    for (int i = 0; i < a.np_in2; ++i) {
-                        s1 += a.x2stats[((size_t)r * a.np_in2 + i) * 2];
-                        s2 += a.x2stats[((size_t)r * a.np_in2 + i) * 2 + 1];
+    if constexpr (MODE == C1_IN_UPADD) row_lo2 = b_first * a.T2 + max(0, (max(0, to_first * a.stride - a.pad)) / 2 - 1);
+
+    if (loader) {
+        // =========================================================== LOADER WAVES ===========================================================
+        const int lr = tid >> 4, lq = tid & 15;  // lr in [0, 16)
+        bool am_ok[2];
+        int ab[2], ato[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int am = m0 + lr + 16 * u;
+            am_ok[u] = am < M;
+            ab[u] = am_ok[u] ? am / a.To : 0;
+            ato[u] = am_ok[u] ? am % a.To : 0;
+        }
+        const __amdgpu_buffer_rsrc_t rsX = c1_rsrc(a.X, (unsigned)a.B * a.Ti * a.Cin * 4u);
+        const __amdgpu_buffer_rsrc_t rsX2 =
+            c1_rsrc(MODE == C1_IN_UPADD || bwd ? a.X2 : a.X, (unsigned)a.B * (MODE == C1_IN_UPADD ? a.T2 : a.Ti) * a.Cin * 4u);
+        const __amdgpu_buffer_rsrc_t rsW = c1_rsrc(a.W, (unsigned)a.Cout * Ktot * 4u);
+        unsigned wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = n0 + lr + 16 * j < a.Cout ? (unsigned)(n0 + lr + 16 * j) * Ktot * 4u : OOB;
+        const float up_scale = (float)a.T2 / (float)a.Ti;
+
+        // F.interpolate(prev, Ti, mode='linear', align_corners=False) at output index ti (generator.py:79-83)
+        auto lerp_src = [&](int ti, int& i0, int& i1, float& w1) {
+            const float src = ((float)ti + 0.5f) * up_scale - 0.5f;
+            const float sc = src < 0.f ? 0.f : src;
+            i0 = (int)sc;
+            i0 = i0 < a.T2 - 1 ? i0 : a.T2 - 1;
+            i1 = i0 + 1 < a.T2 ? i0 + 1 : a.T2 - 1;
+            w1 = sc - (float)i0;
+        };
+        // branch-free on purpose (bitwise & on the predicates, selects on the offsets)
+        auto issue = [&](int k, Raw& q) {
+            const bool kok = k < Ktot;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q.b[j] = c1_ld4(rsW, (kok & (wb[j] != OOB)) ? wb[j] + (unsigned)k * 4u : OOB);
+            const int t = (int)__umulhi((unsigned)k, a.cin_magic), c = k - t * a.Cin;  // k / Cin, k % Cin (exactness checked on the host)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int ti;
+                bool ok = am_ok[u] & kok;
+                if constexpr (!bwd) {
+                    ti = ato[u] * a.stride + t - a.pad;
+                    ok = ok & ((unsigned)ti < (unsigned)a.Ti);
+                } else {  // the layer-output row that tap t maps output row ato to
+                    const int num = ato[u] + a.pad - t;
+                    ti = num >> sshift;
+                    ok = ok & (num >= 0) & ((num & sshift) == 0) & (ti < a.Ti);
+                }
+                const int row = ab[u] * a.Ti + ti;
+                q.r[u] = ok ? row : -1;
+                const unsigned xo = ok ? (unsigned)(row * a.Cin + c) * 4u : OOB;
+                q.x[u] = c1_ld4(rsX, xo);
+                if constexpr (bwd) q.p0[u] = c1_ld4(rsX2, xo);
+                if constexpr (MODE == C1_IN_UPADD) {
+                    int i0, i1;
+                    float w1;
+                    lerp_src(ok ? ti : 0, i0, i1, w1);
+                    q.p0[u] = c1_ld4(rsX2, ok ? (unsigned)((ab[u] * a.T2 + i0) * a.Cin + c) * 4u : OOB);
+                    q.p1[u] = c1_ld4(rsX2, ok ? (unsigned)((ab[u] * a.T2 + i1) * a.Cin + c) * 4u : OOB);
+                }
+            }
+        };
+
+        // ---- everything the loaders read from global memory starts here, in one burst
+        C1_STAMP(0);
+        Raw ring[D];
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0) issue(s0 * C1_BK + 4 * lq, ring[s0]);
+        C1_STAMP(1);
+
+        // statistics tables: threads 0..79 the primary source, threads 128..207 the half-resolution source
+        if constexpr (MODE != C1_IN_PLAIN) {
+            if (tid < C1_MAXROWS) {
+                const int r = row_lo + tid;
+                const bool ok = r < a.B * a.Ti;
+                const __amdgpu_buffer_rsrc_t rs = c1_rsrc(a.xstats, (unsigned)a.B * a.Ti * a.np_in * 8u);
+                float s, q, mu, rsd;
+                c1_sum_partials(rs, (unsigned)r, a.np_in, ok, s, q);
+                c1_mean_rstd(s, q, a.Cin, a.eps, mu, rsd);
+                sStat[0][tid][0] = mu;
+                sStat[0][tid][1] = rsd;
+                if constexpr (bwd) {
+                    const __amdgpu_buffer_rsrc_t rs2 = c1_rsrc(a.x2stats, (unsigned)a.B * a.Ti * a.np_in2 * 8u);
+                    c1_sum_partials(rs2, (unsigned)r, a.np_in2, ok, s, q);
+                    sStat[0][tid][2] = s / (float)a.Cin;
+                    sStat[0][tid][3] = q / (float)a.Cin;
+                }
+            }
+        }
+        if constexpr (MODE == C1_IN_UPADD) {
+            if (tid >= 128 && tid < 128 + C1_MAXROWS) {
+                const int j = tid - 128, r = row_lo2 + j;
+                const __amdgpu_buffer_rsrc_t rs = c1_rsrc(a.x2stats, (unsigned)a.B * a.T2 * a.np_in2 * 8u);
+                float s, q, mu, rsd;
+                c1_sum_partials(rs, (unsigned)r, a.np_in2, r < a.B * a.T2, s, q);
+                c1_mean_rstd(s, q, a.Cin, a.eps, mu, rsd);
+                sStat[1][j][0] = mu;
+                sStat[1][j][1] = rsd;
+            }
+        }
+        C1_STAMP(2);
+        c1_barrier();  // (1) tables complete
+        C1_STAMP(3);
+
+        auto act = [&](float u) { return u > 0.f ? u : u * a.slope; };
+        auto finish = [&](const Raw& q, int u) -> f32x4v {  // the A element after the input transform
+            f32x4v v = q.x[u];  // zeros when masked
+            if constexpr (MODE == C1_IN_PLAIN) {
+                return v;
+            } else {
+                const bool ok = q.r[u] >= 0;
+                const f32x4v st = *(const f32x4v*)sStat[0][ok ? q.r[u] - row_lo : 0];
+                if constexpr (bwd) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yh = (q.p0[u][e] - st[0]) * st[1];
+                        const float gg = q.x[u][e] * (yh > 0.f ? 1.f : a.slope);
+                        v[e] = ok ? st[1] * (gg - st[2] - yh * st[3]) : 0.f;
                     }
-                    sStat[0][j][2] = s1 / (float)a.Cin;
-                    sStat[0][j][3] = s2 / (float)a.Cin;
+                    return v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act((v[e] - st[0]) * st[1]);
+                    if constexpr (MODE == C1_IN_UPADD) {
+                        int i0, i1;
+                        float w1;
+                        lerp_src(ok ? q.r[u] - ab[u] * a.Ti : 0, i0, i1, w1);  // recomputed: cheaper than 3 more ring registers
+                        const int j0 = ok ? ab[u] * a.T2 + i0 - row_lo2 : 0, j1 = ok ? ab[u] * a.T2 + i1 - row_lo2 : 0;
+                        const f32x2v t0 = *(const f32x2v*)sStat[1][j0], t1 = *(const f32x2v*)sStat[1][j1];
+                        const float w0 = 1.f - w1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += w0 * act((q.p0[u][e] - t0[0]) * t0[1]) + w1 * act((q.p1[u][e] - t1[0]) * t1[1]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                    return v;
                 }
             }
+        };
+        auto to_lds = [&](const Raw& q, int buf) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *(f32x4v*)&sA[buf][(lr + 16 * u) * C1_PITCH + 4 * lq] = finish(q, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4v*)&sB[buf][(lr + 16 * j) * C1_PITCH + 4 * lq] = q.b[j];
+        };
+
+        to_lds(ring[0], 0);
+        C1_STAMP(4);
+        c1_barrier();  // (2) tile 0 in LDS
+        C1_STAMP(5);
+        // U steps unrolled back to back with exits (a guard around the body or a back edge would make hipcc drain vmcnt to 0 at the
+        // merge).  The layers of the sdt generator have 4..16 K steps, so the back edge is never taken there.
+        for (int it0 = 0;; it0 += U) {
+#pragma unroll
+            for (int s0 = 0; s0 < U; ++s0) {
+                const int it = it0 + s0;
+                if (!C1_DBG_MODE(2)) to_lds(ring[(s0 + 1) % D], (s0 & 1) ^ 1);        // tile it+1 (zeros past the end of K): issued D-1 steps ago
+                if (!C1_DBG_MODE(4)) issue((it + D) * C1_BK + 4 * lq, ring[s0 % D]);  // slot of tile `it`, moved to LDS one step ago
+                C1_STAMP(6 + it);
+                c1_barrier();                                    // (3 + it)
+                if (it + 1 >= nit) goto loaders_done;
+            }
         }
-        if (a.in_mode == C1_IN_UPADD) {
-            const int total2 = a.B * a.T2;
-            for (int j = tid; j < C1_MAXROWS; j += 512) {
-                const int r = row_lo2 + j;
-                if (r < total2) {
-                    float mu, rs;
-                    c1_row_stats(a.x2stats + (size_t)r * a.np_in2 * 2, a.np_in2, a.Cin, a.eps, mu, rs);
-                    sStat[1][j][0] = mu;
-                    sStat[1][j][1] = rs;
+    loaders_done:
+        C1_STAMP(30);
+        c1_barrier();  // (E) the multipliers' epilogue partials
+        C1_STAMP(31);
+    } else {
+        // ========================================================= MULTIPLIER WAVES =========================================================
+        const int mw = wave - 4, wm = mw >> 1, wn = mw & 1;  // 16 rows x 32 columns per wave, full K
+        C1_STAMP(0);
+        // epilogue operands of this lane's 8 outputs (C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg)
+        const __amdgpu_buffer_rsrc_t rsAdd = c1_rsrc(a.add != nullptr ? a.add : a.Y, a.add != nullptr ? (unsigned)M * a.Cout * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rsBwy = c1_rsrc(BW ? a.bw_y : a.Y, BW ? (unsigned)M * a.Cout * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rsBias = c1_rsrc(a.bias != nullptr ? a.bias : a.Y, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
+        float eadd[2][4], ebwy[2][4], ebias[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int n = n0 + wn * 32 + tl * 16 + (lane & 15);
+            ebias[tl] = c1_ld1(rsBias, n < a.Cout ? (unsigned)n * 4u : OOB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+                const unsigned o = ((m < M) & (n < a.Cout)) ? (unsigned)(m * a.Cout + n) * 4u : OOB;
+                eadd[tl][r] = c1_ld1(rsAdd, o);
+                if constexpr (BW) ebwy[tl][r] = c1_ld1(rsBwy, o);
+            }
+        }
+        if constexpr (BW) {
+            if (tid >= 256 && tid < 256 + C1_BM) {
+                const int j = tid - 256, m = m0 + j;
+                const __amdgpu_buffer_rsrc_t rs = c1_rsrc(a.bw_stats, (unsigned)M * a.np_bw * 8u);
+                float s, q, mu, rsd;
+                c1_sum_partials(rs, (unsigned)m, a.np_bw, m < M, s, q);
+                c1_mean_rstd(s, q, a.Cout, a.eps, mu, rsd);
+                sBw[j][0] = mu;
+                sBw[j][1] = rsd;
+            }
+        }
+        C1_STAMP(2);
+        c1_barrier();  // (1)
+        C1_STAMP(3);
+        c1_barrier();  // (2)
+        C1_STAMP(5);
+
+        f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // fragment addresses: lane = (row l & 15, k-slot h = l >> 4); sub-step (j, e) consumes k = 16 j + 4 h + e for A and B alike
+        const int fa = (wm * 16 + (lane & 15)) * C1_PITCH + (lane >> 4) * 4;
+        const int fb = (wn * 32 + (lane & 15)) * C1_PITCH + (lane >> 4) * 4;
+        for (int it = 0;; ++it) {
+            const float* pa = sA[it & 1] + fa;
+            const float* pb = sB[it & 1] + fb;
+            if (!C1_DBG_MODE(1))
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4v av = *(const f32x4v*)(pa + 16 * j);
+                const f32x4v b0 = *(const f32x4v*)(pb + 16 * j);
+                const f32x4v b1 = *(const f32x4v*)(pb + 16 * C1_PITCH + 16 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b0[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b1[e], acc[1], 0, 0, 0);
                 }
             }
+            C1_STAMP(6 + it);
+            c1_barrier();  // (3 + it)
+            if (it + 1 >= nit) break;
         }
-    }
 
-    // ---- loader mapping: A: 32 rows x 16 float4 = 512 threads; B: 64 rows x 16 float4 = 2 per thread
-    const int lr = tid >> 4, lq = tid & 15;
-    const int am = m0 + lr;
-    const bool am_ok = am < M;
-    const int ab = am_ok ? am / a.To : 0, ato = am_ok ? am % a.To : 0;
-    const int bn0 = n0 + lr, bn1 = n0 + lr + 32;
-    __syncthreads();
-
-    auto act = [&](float u) { return u > 0.f ? u : u * a.slope; };
-    // one float4 of the A operand: flattened k -> (tap t, channel c..c+3) of output row (ab, ato)
-    auto load_a = [&](int k) -> f32x4v {
-        f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (!am_ok || k >= Ktot) return v;
-        const int t = k / a.Cin, c = k - t * a.Cin;
-        if (!bwd) {
-            const int ti = ato * a.stride + t - a.pad;
-            if ((unsigned)ti >= (unsigned)a.Ti) return v;
-            const int r = ab * a.Ti + ti;
-            v = *(const f32x4v*)(a.X + (size_t)r * a.Cin + c);
-            if (a.in_mode == C1_IN_PLAIN) return v;
-            const float mu = sStat[0][r - row_lo][0], rs = sStat[0][r - row_lo][1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act((v[e] - mu) * rs);
-            if (a.in_mode == C1_IN_UPADD) {
-                // F.interpolate(prev, Ti, mode='linear', align_corners=False) at output index ti (generator.py:79-83)
-                const float src = ((float)ti + 0.5f) * ((float)a.T2 / (float)a.Ti) - 0.5f;
-                const float sc = src < 0.f ? 0.f : src;
-                int i0 = (int)sc;
-                i0 = i0 < a.T2 - 1 ? i0 : a.T2 - 1;
-                const int i1 = i0 + 1 < a.T2 ? i0 + 1 : a.T2 - 1;
-                const float w1 = sc - (float)i0, w0 = 1.f - w1;
-                const int r0 = ab * a.T2 + i0, r1 = ab * a.T2 + i1;
-                const f32x4v p0 = *(const f32x4v*)(a.X2 + (size_t)r0 * a.Cin + c);
-                const f32x4v p1 = *(const f32x4v*)(a.X2 + (size_t)r1 * a.Cin + c);
-                const float m0_ = sStat[1][r0 - row_lo2][0], s0_ = sStat[1][r0 - row_lo2][1];
-                const float m1_ = sStat[1][r1 - row_lo2][0], s1_ = sStat[1][r1 - row_lo2][1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += w0 * act((p0[e] - m0_) * s0_) + w1 * act((p1[e] - m1_) * s1_);
-            }
-            return v;
-        }
-        // backward: the layer-output row that tap t maps output row ato to
-        const int num = ato + a.pad - t;
-        if (num < 0 || num % a.stride != 0) return v;
-        const int ti = num / a.stride;
-        if (ti >= a.Ti) return v;
-        const int r = ab * a.Ti + ti;
-        const f32x4v dz = *(const f32x4v*)(a.X + (size_t)r * a.Cin + c);
-        const f32x4v yv = *(const f32x4v*)(a.X2 + (size_t)r * a.Cin + c);
-        const float* st = sStat[0][r - row_lo];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float yh = (yv[e] - st[0]) * st[1];
-            const float gg = dz[e] * (yh > 0.f ? 1.f : a.slope);
-            v[e] = st[1] * (gg - st[2] - yh * st[3]);
-        }
-        return v;
-    };
-    auto load_b = [&](int n, int k) -> f32x4v {
-        if (n >= a.Cout || k >= Ktot) return (f32x4v){0.f, 0.f, 0.f, 0.f};
-        return *(const f32x4v*)(a.W + (size_t)n * Ktot + k);  // W is (Cout, taps, Cin): K-contiguous
-    };
-
-    // ---- K loop: one 64-wide step per iteration, wave half wk multiplies k in [32 wk, 32 wk + 32)
-    f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4v ra = load_a(4 * lq), rb0 = load_b(bn0, 4 * lq), rb1 = load_b(bn1, 4 * lq);
-    // fragment addresses: lane = (row l & 15, k-slot h = l >> 4); sub-step (j, e) consumes k = 16 j + 4 h + e for A and B alike
-    const float* pa = sA + (wm * 16 + (lane & 15)) * C1_PITCH + wk * 32 + (lane >> 4) * 4;
-    const float* pb = sB + (wn * 32 + (lane & 15)) * C1_PITCH + wk * 32 + (lane >> 4) * 4;
-    for (int it = 0; it < nit; ++it) {
-        *(f32x4v*)&sA[lr * C1_PITCH + 4 * lq] = ra;
-        *(f32x4v*)&sB[lr * C1_PITCH + 4 * lq] = rb0;
-        *(f32x4v*)&sB[(lr + 32) * C1_PITCH + 4 * lq] = rb1;
-        __syncthreads();
-        if (it + 1 < nit) {
-            const int k = (it + 1) * C1_BK + 4 * lq;
-            ra = load_a(k);
-            rb0 = load_b(bn0, k);
-            rb1 = load_b(bn1, k);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4v av = *(const f32x4v*)(pa + 16 * j);
-            const f32x4v b0 = *(const f32x4v*)(pb + 16 * j);
-            const f32x4v b1 = *(const f32x4v*)(pb + 16 * C1_PITCH + 16 * j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b0[e], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b1[e], acc[1], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- combine the two K halves through LDS (reuse sB: 4 (wm, wn) pairs x 2 tiles x 256 floats = 8 KB)
-    float* red = sB;
-    if (wk == 1) {
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) *(f32x4v*)&red[(((wm * 2 + wn) * 2 + tl) * 64 + lane) * 4] = acc[tl];
-    }
-    __syncthreads();
-    if (wk == 0) {
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) acc[tl] += *(const f32x4v*)&red[(((wm * 2 + wn) * 2 + tl) * 64 + lane) * 4];
-
-        // ---- epilogue (waves wk == 0).  C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
+        // ---- epilogue
         float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
             const int n = n0 + wn * 32 + tl * 16 + (lane & 15);
             const bool nok = n < a.Cout;
-            const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * 16 + (lane >> 4) * 4 + r;
                 const int m = m0 + row;
                 if (m < M && nok) {
-                    float v = acc[tl][r] + bv;
-                    const size_t o = (size_t)m * a.Cout + n;
-                    if (a.add != nullptr) v += a.add[o];
-                    a.Y[o] = v;
-                    if (a.ystats != nullptr) {
-                        if (a.bw_y == nullptr) {
-                            ps[r] += v;
-                            pq[r] = fmaf(v, v, pq[r]);
-                        } else {  // partial (sum g, sum g*yhat) of the layer below: v is the total gradient w.r.t. its activated output
-                            float mu, rs;
-                            c1_row_stats(a.bw_stats + (size_t)m * a.np_bw * 2, a.np_bw, a.Cout, a.eps, mu, rs);
-                            const float yh = (a.bw_y[o] - mu) * rs;
-                            const float gg = v * (yh > 0.f ? 1.f : a.slope);
-                            ps[r] += gg;
-                            pq[r] = fmaf(gg, yh, pq[r]);
-                        }
+                    const float v = acc[tl][r] + ebias[tl] + eadd[tl][r];
+                    a.Y[(size_t)m * a.Cout + n] = v;
+                    if constexpr (!BW) {
+                        ps[r] += v;
+                        pq[r] = fmaf(v, v, pq[r]);
+                    } else {  // partial (sum g, sum g*yhat) of the layer below: v is the total gradient w.r.t. its activated output
+                        const float yh = (ebwy[tl][r] - sBw[row][0]) * sBw[row][1];
+                        const float gg = v * (yh > 0.f ? 1.f : a.slope);
+                        ps[r] += gg;
+                        pq[r] = fmaf(gg, yh, pq[r]);
                     }
                 }
             }
@@ -284,8 +465,10 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
                 }
             }
         }
+        C1_STAMP(30);
+        c1_barrier();  // (E)
+        C1_STAMP(31);
     }
-    __syncthreads();  // every wave of the workgroup reaches this barrier (uniform control flow above)
     if (a.ystats != nullptr && tid < C1_BM) {
         const int m = m0 + tid;
         if (m < M) {
@@ -388,10 +571,26 @@ extern "C" int sdt_c1d_layer_f32(const sdt_c1d* p, void* stream) {
     a.X = p->X; a.X2 = p->X2; a.xstats = p->xstats; a.x2stats = p->x2stats; a.W = p->W; a.bias = p->bias; a.add = p->add; a.Y = p->Y;
     a.ystats = p->ystats; a.bw_y = p->bw_y; a.bw_stats = p->bw_stats;
     a.B = p->B; a.Ti = p->Ti; a.T2 = p->T2; a.Cin = p->Cin; a.To = p->To; a.Cout = p->Cout; a.taps = p->taps; a.stride = p->stride; a.pad = p->pad;
+    a.cin_magic = (unsigned)((1ull << 32) / (unsigned)p->Cin + 1ull);
+    SDT_CHECK_ARG((uint64_t)(p->taps * p->Cin + 64 * C1_BK) * (uint64_t)p->Cin < (1ull << 31), "K extent too large for the reciprocal division");
+#ifdef SDT_TUNING
+    a.dbg_mode = g_c1d_dbg_mode;
+    a.dbg = (g_c1d_dbg != nullptr && g_c1d_dbg_launch < g_c1d_dbg_max) ? g_c1d_dbg + 64 * (g_c1d_dbg_launch++) : nullptr;
+#endif
     a.in_mode = p->in_mode; a.np_in = p->np_in; a.np_in2 = p->np_in2; a.np_bw = p->np_bw; a.eps = p->eps; a.slope = p->slope;
     const int M = p->B * p->To;
     const unsigned grid = (unsigned)(cdiv(M, C1_BM) * cdiv(p->Cout, C1_BN));
-    hipLaunchKernelGGL(c1d_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    const bool bw = p->bw_y != nullptr;
+#define C1_LAUNCH(MODE)                                                                                      \
+    if (bw) hipLaunchKernelGGL((c1d_kernel<MODE, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);  \
+    else hipLaunchKernelGGL((c1d_kernel<MODE, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a)
+    switch (p->in_mode) {
+        case C1_IN_PLAIN: C1_LAUNCH(C1_IN_PLAIN); break;
+        case C1_IN_NORM: C1_LAUNCH(C1_IN_NORM); break;
+        case C1_IN_UPADD: C1_LAUNCH(C1_IN_UPADD); break;
+        default: C1_LAUNCH(C1_IN_NORMBWD); break;
+    }
+#undef C1_LAUNCH
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

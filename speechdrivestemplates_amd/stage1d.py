@@ -10,12 +10,17 @@ stream, where they overlap the audio encoder's backward pass.
 Used for the InstanceNorm ('IN') generator in exact-fp32 math while gradients are enabled; every other case (BatchNorm generator,
 no-grad inference, the bf16 modes) keeps the per-block path of core.networks.building_blocks.
 """
+import os
+
 import torch
 
 from . import _lib, ops
 from ._lib import check
 
-ENABLED = True  # bench / test switch
+# Opt-in (SDT_STAGE1D=1): measured on MI355X (profiles/r02_conv1d_stage.txt) the fused stage shortens the exposed Conv1d chains
+# (0.85 -> 0.81 ms per step) but moves more work onto the weight-gradient side stream, and the whole step comes out 2 % SLOWER
+# (3950 vs 4040 clips/s), so the per-block path stays the default.
+ENABLED = os.environ.get("SDT_STAGE1D", "0") == "1"
 _p = ops._p
 
 
