@@ -182,6 +182,8 @@ def main(argv=None):
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
+    ap.add_argument("--deterministic-dw", action="store_true",
+                    help="weight gradients through row-range slabs + an ordered reduce instead of fp32 atomics (bit-reproducible)")
     ap.add_argument("--fused-conv1d", action="store_true",
                     help="run the generator's Conv1d stage as one launch per layer and direction (csrc/conv1d.hip; measured 2 %% slower "
                          "end to end, profiles/r02_conv1d_stage.txt)")
@@ -220,6 +222,7 @@ def main(argv=None):
         from speechdrivestemplates_amd import ops
         ops.OVERLAP_DW = not args.no_overlap_dw
         ops.DEFER_SMALL_DW = not args.no_defer_dw
+        ops.DETERMINISTIC_DW = bool(args.deterministic_dw)
         if args.fused_conv1d:
             from speechdrivestemplates_amd import stage1d
             stage1d.ENABLED = True
@@ -317,7 +320,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d)},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": bool(args.deterministic_dw)},
             "final_G_loss": final_loss,
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included

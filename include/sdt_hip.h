@@ -88,6 +88,13 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);
+/* The same weight gradient without atomics: every row range of the split reduction stores its partial product into its own slab of
+ * `workspace` (>= sdt_conv_dw_workspace_bytes(g) bytes, 16-byte aligned) and the slabs are added to dw in a fixed order, so the
+ * result is bit-identical from run to run (torch.use_deterministic_algorithms territory; the reference's cuDNN weight gradient
+ * is not deterministic either, core/pipelines/trainer.py never asks for it).  fp32 MFMA only. */
+int64_t sdt_conv_dw_workspace_bytes(const sdt_conv_geom* g);
+int sdt_conv_dw_det_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* workspace, int64_t workspace_bytes,
+                        void* stream);
 /* Which kernel instantiation the two entry points above pick for a geometry (16-B aligned operands assumed):
  * (BM*1000+BN)*10 + vec4, e.g. 1281281 = conv_taps_kernel<128,128,true>.  Used by bench.py to attribute timings. */
 int sdt_conv_taps_variant(const sdt_conv_geom* g);

@@ -52,6 +52,7 @@ _G = C.POINTER(ConvGeom)
 SIGNATURES = {
     "sdt_conv_taps_f32": [_p, _p, _p, _p, _G, _p],
     "sdt_conv_dw_f32": [_p, _p, _p, _G, _p],
+    "sdt_conv_dw_det_f32": [_p, _p, _p, _G, _p, _i64, _p],
     "sdt_conv_taps_splitk_hint": [_G],
     "sdt_conv_taps_splitk_f32": [_p, _p, _p, _p, _G, _i, _p, _p],
     "sdt_splitk_reduce_f32": [_p, _p, _p, _i64, _i, _i, _p],
@@ -132,6 +133,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.sdt_conv_dw_workspace_bytes.argtypes = [_G]
+    lib.sdt_conv_dw_workspace_bytes.restype = C.c_int64
     lib.sdt_last_error.restype = C.c_char_p
     lib.sdt_abi_version.restype = C.c_int
     lib.sdt_get_conv_math.restype = C.c_int

@@ -964,7 +964,10 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&out)[NS
     }
 }
 
-template <int BM, int BN, bool VEC4, int NS = 0>
+// SLAB: the deterministic variant -- every row range writes its partial product with plain stores into its own slab
+// dW + range * (Cout * Tw * Cin) and dw_slab_reduce_kernel adds the slabs to the gradient in a fixed order (no atomics, bit-identical
+// from run to run).
+template <int BM, int BN, bool VEC4, int NS = 0, bool SLAB = false>
 __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW, const sdt_conv_geom g,
                                                       const int rows_per_split) {
@@ -1191,9 +1194,34 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (cok && n < g.Cout) atomicAdd(&dW[((size_t)n * g.Tw + wt) * g.Cin + c], acc[tm][tn][r]);
+                if (cok && n < g.Cout) {
+                    const size_t o = ((size_t)n * g.Tw + wt) * g.Cin + c;
+                    if constexpr (SLAB)
+                        dW[(size_t)bx * ((size_t)g.Cout * g.Tw * g.Cin) + o] = acc[tm][tn][r];
+                    else
+                        atomicAdd(&dW[o], acc[tm][tn][r]);
+                }
             }
         }
+}
+
+// dw[i] += slab[0][i] + slab[1][i] + ... in that order (deterministic weight gradient)
+__global__ __launch_bounds__(256) void dw_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t n, int nsplit) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((n & 3) == 0) {
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            f32x4 a = *(const f32x4*)(slabs + 4 * i);
+            for (int sidx = 1; sidx < nsplit; ++sidx) a += *(const f32x4*)(slabs + (size_t)sidx * n + 4 * i);
+            *(f32x4*)(dw + 4 * i) += a;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float a = slabs[i];
+            for (int sidx = 1; sidx < nsplit; ++sidx) a += slabs[(size_t)sidx * n + i];
+            dw[i] += a;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1480,15 +1508,32 @@ extern "C" int sdt_splitk_reduce_f32(const float* partial, const float* bias, fl
 }
 
 template <int BM, int BN>
-static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, const sdt_conv_geom& g, hipStream_t s) {
+static void dw_split(bool vec4, const sdt_conv_geom& g, int& nsplit, int& rows, int& coltiles, int& ntiles) {
     const int M = g.B * g.Ho * g.Wo;
-    const int coltiles = vec4 ? g.ntaps * cdiv(g.Cin, BN) : cdiv(g.ntaps * g.Cin, BN);
-    const int ntiles = cdiv(g.Cout, BM);
-    int nsplit = cdiv(1536, coltiles * ntiles);
+    coltiles = vec4 ? g.ntaps * cdiv(g.Cin, BN) : cdiv(g.ntaps * g.Cin, BN);
+    ntiles = cdiv(g.Cout, BM);
+    nsplit = cdiv(1536, coltiles * ntiles);
     nsplit = max(1, min(nsplit, max(1, M / (4 * BK))));  // at least 4 K-steps per workgroup: bounds the atomic traffic
-    int rows = cdiv(cdiv(M, nsplit), BK) * BK;
+    rows = cdiv(cdiv(M, nsplit), BK) * BK;
     nsplit = cdiv(M, rows);
+}
+
+// slabs != nullptr: deterministic (plain stores into nsplit slabs + an ordered reduce), fp32 math only
+template <int BM, int BN>
+static void launch_dw(bool vec4, const float* x, const float* dy, float* dw, const sdt_conv_geom& g, hipStream_t s, float* slabs = nullptr) {
+    int nsplit, rows, coltiles, ntiles;
+    dw_split<BM, BN>(vec4, g, nsplit, rows, coltiles, ntiles);
     dim3 grid(nsplit * coltiles * ntiles);
+    if (slabs != nullptr) {
+        if (vec4)
+            hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true, 0, true>), grid, dim3(256), 0, s, x, dy, slabs, g, rows);
+        else
+            hipLaunchKernelGGL((conv_dw_kernel<BM, BN, false, 0, true>), grid, dim3(256), 0, s, x, dy, slabs, g, rows);
+        const size_t n = (size_t)g.Cout * g.Tw * g.Cin;
+        const unsigned rgrid = (unsigned)std::max<size_t>(1, std::min<size_t>((n / 4 + 255) / 256, 2048));
+        hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)slabs, dw, n, nsplit);
+        return;
+    }
     if (vec4 && g_conv_math == SDT_MATH_BF16)
         hipLaunchKernelGGL((conv_dw_kernel<BM, BN, true, 1>), grid, dim3(256), 0, s, x, dy, dw, g, rows);
     else if (vec4 && g_conv_math == SDT_MATH_BF16X3)
@@ -1528,6 +1573,28 @@ extern "C" int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const
 #endif
         default: launch_dw<64, 64>(vec4, x, dy, dw, *g, s); break;
     }
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+// Deterministic weight gradient (fp32 MFMA): same tiling as sdt_conv_dw_f32, but every row range stores its partial product into
+// its own slab of `workspace` and the slabs are added to dw in a fixed order.  workspace >= sdt_conv_dw_workspace_bytes(g).
+extern "C" int64_t sdt_conv_dw_workspace_bytes(const sdt_conv_geom* g) {
+    if (check_geom(g)) return -1;
+    int nsplit, rows, coltiles, ntiles;
+    dw_split<64, 64>((g->Cin % 4 == 0) && (g->Cout % 4 == 0), *g, nsplit, rows, coltiles, ntiles);
+    return (int64_t)nsplit * g->Cout * g->Tw * g->Cin * (int64_t)sizeof(float);
+}
+
+extern "C" int sdt_conv_dw_det_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    SDT_CHECK_ARG(x && dy && dw && workspace, "null pointer");
+    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace | (uintptr_t)dw) % 16) == 0, "operands must be 16-byte aligned");
+    SDT_CHECK_ARG(workspace_bytes >= sdt_conv_dw_workspace_bytes(g), "workspace too small");
+    const bool vec4 = (g->Cin % 4 == 0) && (g->Cout % 4 == 0);
+    launch_dw<64, 64>(vec4, x, dy, dw, *g, (hipStream_t)stream, (float*)workspace);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

@@ -13,6 +13,7 @@ There is no CPU or eager-PyTorch fallback: a non-CUDA tensor raises.
 """
 import functools
 import math
+import os
 
 import torch
 
@@ -603,6 +604,13 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
     if gws.data_ptr() != gw.data_ptr():
         raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
     st = _stream()
+    if DETERMINISTIC_DW:
+        if _CONV_MATH_NOW[0] != 0:
+            raise RuntimeError("DETERMINISTIC_DW needs conv math f32")
+        nbytes = lib.sdt_conv_dw_workspace_bytes(g)
+        ws = torch.empty(nbytes // 4, device=x4.device, dtype=torch.float32)  # on the launching stream: freed blocks are reused in order
+        _conv_launch("dW", w.dim() == 4, g, lambda: lib.sdt_conv_dw_det_f32(_p(x4), _p(gy4), _p(gws), g, _p(ws), nbytes, st))
+        return
     _conv_launch("dW", w.dim() == 4, g, lambda: lib.sdt_conv_dw_f32(_p(x4), _p(gy4), _p(gws), g, st))
 
 
@@ -613,6 +621,9 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
 # optimiser step.
 OVERLAP_DW = True
 OVERLAP_DW_MIN_FLOPS = 4e9
+# Bit-reproducible weight gradients: row-range slabs + an ordered reduce instead of fp32 atomics (sdt_conv_dw_det_f32).  Off by
+# default: measured cost in DESIGN.md / profiles/r02_deterministic_dw.txt.
+DETERMINISTIC_DW = os.environ.get("SDT_DETERMINISTIC_DW", "0") == "1"
 _SIDE = {}
 
 

@@ -797,3 +797,49 @@ def test_presplit_chain_matches_float64(ops, norm):
     for a, r in zip(got[1:], [p.grad for p in params]):
         check("pre-split chain parameter gradient vs float64", a, r, 6e-4)
     del opt
+
+
+@pytest.mark.parametrize("case", [CONV2D[1], CONV2D[5], CONV2D[7], ("1-D 256->256 k4s2", 4, 1, 64, 256, 256, 1, 4, 2, 1),
+                                  ("ragged 3->5 k3", 2, 9, 11, 3, 5, 3, 3, 1, 1)], ids=lambda c: c[0])
+def test_deterministic_weight_gradient(ops, case):
+    """ops.DETERMINISTIC_DW (sdt_conv_dw_det_f32): row-range slabs + an ordered reduce instead of fp32 atomics.  Repeated launches
+    are BIT-identical (the atomic path is not: it is checked to differ by rounding only), the result equals the float64 weight
+    gradient to the tolerance of the atomic path, and it accumulates into an existing gradient like the atomic path does."""
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    one_d = Hi == 1
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    if one_d:
+        x = torch.randn(B, Cin, Wi, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, Cin, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kw)) ** 0.5
+        conv = F.conv1d
+    else:
+        x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+        conv = F.conv2d
+    wr = w.clone().requires_grad_(True)
+    y = conv(x, wr, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    ref = ops.to_weight_layout(wr.grad)
+    prev = ops.DETERMINISTIC_DW
+    try:
+        ops.DETERMINISTIC_DW = True
+        runs = []
+        for _ in range(3):
+            wd.grad = None
+            ops.conv_weight_grad(xd, gyd, wd, s, p)
+            torch.cuda.synchronize()
+            runs.append(wd.grad.clone())
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "deterministic weight gradient differs between runs"
+        check(tag + " dW (deterministic)", runs[0], ref, 5e-5)
+        ops.conv_weight_grad(xd, gyd, wd, s, p)  # accumulates
+        check(tag + " dW (deterministic, accumulated)", wd.grad, 2 * ref, 5e-5)
+        ops.DETERMINISTIC_DW = False
+        wd.grad = None
+        ops.conv_weight_grad(xd, gyd, wd, s, p)
+        torch.cuda.synchronize()
+        check(tag + " dW (atomics) vs deterministic", wd.grad, runs[0].double(), 2e-5)
+    finally:
+        ops.DETERMINISTIC_DW = prev
