@@ -25,6 +25,9 @@
 #define SDT_MAX_CLASSES 4
 struct geom_pack {
     sdt_conv_geom g[SDT_MAX_CLASSES];
+    // > 0: rotate the m-tile index by mrot * (block of 32 / n-tiles m-tiles) inside each such block (launch_taps: layers whose tap
+    // culling makes the work of a tile depend strongly on its image row, i.e. the p = 0 (6,3) layer's input gradient)
+    int mrot;
 };
 // Epilogue of an input-gradient launch that also accumulates the statistics of the normalisation BACKWARD that consumes it
 // (what colstats_kernel<true> would compute in a separate pass over dz and y):
@@ -96,7 +99,20 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     const int nnb = (g.Cout + BN - 1) / BN;
     if ((int)blockIdx.x >= nmb * nnb) return;  // the grid is sized for the largest class of the launch
     const int lin = xcd_remap(blockIdx.x, nmb * nnb);
-    const int m0 = (lin / nnb) * BM;
+    int mt = lin / nnb;
+    if constexpr (VEC4) {
+        // Load balance under tap culling.  A CU's co-resident workgroups are 32 positions apart in `lin`, i.e. 32 / nnb m-tiles; when
+        // that stride is close to the number of tiles per image (8 vs 8.28 on the (6,3) p=0 layer's input gradient) every tile of a
+        // CU sits at the same image row: one CU gets 4 tiles with 15-18 live taps, another 4 tiles with 3-6, and the launch waits for
+        // the first (293 us at 66 TFLOP/s).  Rotating the tile index inside consecutive blocks of 32 / nnb tiles by mrot * block
+        // spreads a CU's tiles evenly over the image rows.
+        const int mrot = __builtin_amdgcn_readfirstlane(gp.mrot);
+        if (mrot > 0) {
+            const int S = 32 / nnb, blk = mt / S;
+            if ((blk + 1) * S <= nmb) mt = blk * S + (mt - blk * S + mrot * blk) % S;
+        }
+    }
+    const int m0 = mt * BM;
     const int n0 = (lin % nnb) * BN;
 
     if (tid < g.ntaps) {
@@ -1309,6 +1325,7 @@ static const norm_bwd_args kNoNormBwd = {nullptr, nullptr, nullptr, nullptr, nul
 static geom_pack pack_of(const sdt_conv_geom* const* gs, int n) {
     geom_pack gp;
     for (int i = 0; i < SDT_MAX_CLASSES; ++i) gp.g[i] = *gs[i < n ? i : 0];
+    gp.mrot = 0;
     return gp;
 }
 
@@ -1321,7 +1338,17 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
     int tiles = 0;
     for (int c = 0; c < ncls; ++c) tiles = std::max(tiles, cdiv(gs[c]->B * gs[c]->Ho * gs[c]->Wo, BM) * cdiv(gs[c]->Cout, BN));
     dim3 grid(tiles, ncls, splitk);
-    const geom_pack gp = pack_of(gs, ncls);
+    geom_pack gp = pack_of(gs, ncls);
+    if (vec4 && ncls == 1 && splitk == 1 && g.ntaps >= 9) {  // see the kernel: tile rotation for tall valid-correlation launches
+        int dymin = g.dy[0], dymax = g.dy[0];
+        for (int t = 1; t < g.ntaps; ++t) dymin = std::min(dymin, g.dy[t]), dymax = std::max(dymax, g.dy[t]);
+        const int nnb = cdiv(g.Cout, BN), nmb = cdiv(g.B * g.Ho * g.Wo, BM);
+        if (dymax - dymin + 1 > g.Hi && 32 % nnb == 0 && 32 / nnb >= 4) {
+            const int S = 32 / nnb;
+            const double per_image = (double)g.Ho * g.Wo / BM, per_cu = std::max(1.0, (double)nmb * nnb / 256.0);
+            gp.mrot = (int)std::max(1l, lround(per_image / per_cu)) % S;
+        }
+    }
     if (vec4 && g_conv_math != SDT_MATH_F32 && ncls == 1 && nb.sums == nullptr) {
         switch (g_conv_math) {
             case SDT_MATH_BF16: hipLaunchKernelGGL((conv_taps_bf_kernel<1, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;

@@ -232,7 +232,7 @@ def test_b32_bf16_mode_vs_oracle():
         cos = (F.cosine_similarity(got.reshape(1, -1), ref.reshape(1, -1)).item()) if ref.numel() > 1 else 1.0
         rows.append((k, rel, cos))
     lines = ["voice2pose_sdt_bp B=32 (bf16 products) vs float64 oracle: prediction rel-max-err %.3e; losses %s" % (
-        e, {k: "%.2e" % abs(float(losses[k]) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
+        e, {k: "%.2e" % abs(float(losses[k].detach()) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
     lines += ["      %-60s rel-max-err %.3e  cosine %.5f" % r for r in rows]
     _dump(lines)
     assert e <= 4e-2, e

@@ -38,8 +38,27 @@ def algorithmic_bytes(name, rows_elems):
     return None
 
 
+UNR = 4  # csrc/norm.hip
+
+
+def rows_per_block(C, G, R, stats):
+    """mirror of colnorm_rows_per_block (csrc/norm.hip): the grid identifies the layer(s) a launch group belongs to"""
+    rpp = 256 // (C >> 2)
+    target = 512 if (stats and G == 1) else 2048
+    want = -(-R // max(1, target // G))
+    unit = UNR * rpp
+    rpb = -(-want // unit) * unit
+    return min(max(rpb, unit), rpp * 64)
+
+
+# 2-D layers that own a normalisation launch (L0 is fused into l0_*): name -> (rows per clip, C)
+NORM2D = collections.OrderedDict([("L1", (40 * 213, 64)), ("L2", (40 * 213, 128)), ("L3", (20 * 106, 128)), ("L4", (20 * 106, 256)),
+                                  ("L5", (10 * 53, 256)), ("L6", (10 * 53, 256)), ("L7", (5 * 51, 256))])
+
+
 def main():
     path = sys.argv[1]
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
     groups = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -49,52 +68,55 @@ def main():
         g = groups.setdefault(key, [0, 0.0])
         g[0] += 1
         g[1] += d
-    # match a (kernel, grid) group to the activation it streams by elapsed-time rank within the kernel family: the families'
-    # launches come in the layer sizes of ACT, so sort both by size
-    rows = []
-    fam = collections.defaultdict(list)
+    if steps is None:  # one Adam launch of the generator group per step
+        steps = float(max(n for (name, gx, _, _), (n, _) in groups.items() if name.startswith("adam_kernel")))
+    # layers by the grid their normalisation launches use: several layers can share a grid, so a group's bytes are the SUM over
+    # its layers and the rate is (bytes per step) / (time per step) of the whole group
+    by_grid = collections.defaultdict(list)
+    for lname, (R, C) in NORM2D.items():
+        by_grid[(-(-R // rows_per_block(C, B, R, False)), B)].append(lname)
+    rows, small = [], collections.defaultdict(lambda: [0, 0.0])
     for (name, gx, gy, gz), (n, t) in groups.items():
-        fam[name].append(((gx, gy, gz), n, t / n / 1e3))
-    for name, lst in fam.items():
-        if name.startswith(("colnorm_apply", "colstats", "colnorm_bwd")):
-            # 2-D layers: grid.y == B (InstanceNorm groups) -> sizes L1..L7 (L0 is fused into l0_*); sort by avg time descending
-            two_d = sorted([x for x in lst if x[0][1] == B], key=lambda x: -x[2])
-            sizes = sorted((v for k, v in ACT.items() if k != "L0"), reverse=True)
-            # distinct sizes only (L5 == L6)
-            uniq = sorted(set(sizes), reverse=True)
-            for (grid, n, us), elems in zip(two_d, uniq):
-                rows.append((name, grid, n, us, algorithmic_bytes(name, elems)))
-            for x in lst:
-                if x[0][1] != B:
-                    rows.append((name, x[0], x[1], x[2], None))
+        per_step_us = t / steps / 1e3
+        calls = n / steps
+        fam2d = name.startswith(("colnorm_apply", "colstats", "colnorm_bwd"))
+        if fam2d and gy == B and (gx, gy) in by_grid:
+            layers = by_grid[(gx, gy)]
+            if abs(calls - len(layers)) > 1e-6 and abs(calls - 1) < 1e-6:
+                layers = layers[-1:]  # a group that only the last layer of the chain launches (L7: no fused statistics)
+            ok = abs(calls - len(layers)) < 1e-6
+            nb = sum(algorithmic_bytes(name, B * NORM2D[l][0] * NORM2D[l][1]) for l in layers) if ok else None
+            rows.append((name, (gx, gy, gz), calls, per_step_us, nb, "+".join(layers) if ok else "?"))
+        elif fam2d or name.startswith(("rownorm_kernel", "splitk_reduce", "upsample_add", "c1d_")):
+            s_ = small[name.split("<")[0]]
+            s_[0] += calls
+            s_[1] += per_step_us
         elif name.startswith("l0_fwd"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 4 * (ACT["L0"] + MEL)))
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 4 * (ACT["L0"] + MEL), "L0 fwd: mel in, z out"))
         elif name.startswith("l0_bwd_sums"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 4 * (ACT["L0"] + MEL)))
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 4 * (ACT["L0"] + MEL), "L0 bwd: dz + mel in"))
         elif name.startswith("l0_moments"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 4 * MEL))
-        elif name.startswith("adam_kernel"):
-            for grid, n, us in sorted(lst, key=lambda x: -x[2])[:1]:
-                rows.append((name, grid, n, us, 7 * 4 * 7075122))
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 4 * MEL, "mel moments (latency-bound)"))
+        elif name.startswith("adam_kernel") and gx >= 1024:
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 7 * 4 * 7075122, "generator group: p,g,m,v in; p,m,v out"))
         elif name.startswith("weight_transpose_batched"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 2 * 4 * (7075122 - 848626 + 848384)))
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 2 * 4 * (7075122 - 848626 + 848384), "all mirrors, one launch"))
         elif name.startswith("final_metrics_kernel"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 2 * B * 64 * 242 * 4))
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 2 * B * 64 * 242 * 4, "f64 metrics (latency-bound)"))
         elif name.startswith("mel_fb"):
-            for grid, n, us in lst:
-                rows.append((name, grid, n, us, 4 * (B * 427 * 514 + MEL)))
-    print("%-34s %-18s %7s %9s %10s %9s %8s" % ("kernel", "grid", "calls", "avg_us", "alg_MB", "TB/s", "of 8TB/s"))
-    for name, grid, n, us, nb in sorted(rows, key=lambda r: -(r[3] * r[2])):
+            rows.append((name, (gx, gy, gz), calls, per_step_us, 4 * (B * 427 * 514 + MEL), "power spectrum in, log-mel out"))
+    print("HBM-bound kernels of one train step (B=32, voice2pose_sdt_bp): algorithmic bytes per step / time per step, %d steps in the trace" % steps)
+    print("%-30s %-14s %6s %9s %9s %7s %8s  %s" % ("kernel", "grid", "calls", "us/step", "alg_MB", "TB/s", "of 8TB/s", "tensors"))
+    for name, grid, calls, us, nb, what in sorted(rows, key=lambda r: -r[3]):
         if nb is None:
-            print("%-34s %-18s %7d %9.1f %10s %9s %8s" % (name[:34], str(grid), n, us, "?", "?", "?"))
+            print("%-30s %-14s %6.1f %9.1f %9s %7s %8s  %s" % (name[:30], str(grid), calls, us, "?", "?", "?", what))
         else:
             tbs = nb / (us * 1e-6) / 1e12
-            print("%-34s %-18s %7d %9.1f %10.1f %9.2f %7.0f%%" % (name[:34], str(grid), n, us, nb / 1e6, tbs, 100 * tbs * 1e12 / HBM_PEAK))
+            print("%-30s %-14s %6.1f %9.1f %9.1f %7.2f %7.0f%%  %s" % (name[:30], str(grid), calls, us, nb / 1e6, tbs, 100 * tbs * 1e12 / HBM_PEAK, what))
+    print()
+    print("latency-bound 1-D / small launches (<= 3 MB each, a launch is ~4 us whatever it moves), per step:")
+    for name, (calls, us) in sorted(small.items(), key=lambda kv: -kv[1][1]):
+        print("  %-34s %6.1f launches %8.1f us  (%.1f us each)" % (name, calls, us, us / max(calls, 1e-9)))
 
 
 if __name__ == "__main__":
