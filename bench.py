@@ -344,6 +344,11 @@ def main(argv=None):
                                            "weight-gradient side stream switched off (the kernel alone on the GPU)",
                                "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
                                "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6}
+            # the same kernel serves the MFMA-bound Conv2d launches and the latency-bound 1-D launches (M = B*T <= 2048 rows):
+            # the average above mixes them, the split shows each (role = forward / input gradient, 2-D / 1-D stage)
+            out["roofline"]["by_role"] = {
+                r: {"launches_per_step": v[0] / prof_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
+                    "frac": v[2] / (v[1] * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS} for r, v in sorted(d["roles"].items())}
             out["roofline"].update(cited_traffic(name))
             if prof_ovl is not None and n_ovl > 0:
                 do = prof_ovl.summary()[name]
