@@ -179,6 +179,11 @@ typedef struct sdt_c1d {
     int32_t B, Ti, T2, Cin, To, Cout, taps, stride, pad;
     int32_t in_mode, np_in, np_in2, np_bw;
     float eps, slope;
+    /* split-K inside the launch (1 = none): K slices of a tile store partial tiles into slabs [splitk][B*To][Cout]; the last slice
+     * to arrive (counters [tiles], uint32, zero on entry, left zero) adds them in slice order and runs the epilogue. */
+    int32_t splitk;
+    float* slabs;
+    uint32_t* counters;
 } sdt_c1d;
 int sdt_c1d_layer_f32(const sdt_c1d* p, void* stream);
 /* z = act(norm(y)) from partial statistics, also mean / rstd per row (feeds the generic weight-gradient kernels). */

@@ -30,7 +30,7 @@ class C1d(C.Structure):
     """Mirror of ``sdt_c1d`` (include/sdt_hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("X", "X2", "xstats", "x2stats", "W", "bias", "add", "Y", "ystats", "bw_y", "bw_stats")]
                 + [(n, C.c_int32) for n in ("B", "Ti", "T2", "Cin", "To", "Cout", "taps", "stride", "pad", "in_mode", "np_in", "np_in2", "np_bw")]
-                + [("eps", C.c_float), ("slope", C.c_float)])
+                + [("eps", C.c_float), ("slope", C.c_float), ("splitk", C.c_int32), ("slabs", C.c_void_p), ("counters", C.c_void_p)])
 
 
 class WpDesc(C.Structure):

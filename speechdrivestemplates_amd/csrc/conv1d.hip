@@ -72,6 +72,9 @@ struct c1d_args {
     int in_mode, np_in, np_in2, np_bw;
     float eps, slope;
     unsigned cin_magic;  // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, cin_magic) for the k the kernel forms
+    int splitk;          // K slices per output tile (1 = none)
+    float* slabs;        // [splitk][M][Cout] partial products (splitk > 1)
+    unsigned* counters;  // [tiles] arrival counters, zero on entry, left zero (splitk > 1)
 #ifdef SDT_TUNING
     int dbg_mode;             // 1: multipliers skip the MFMAs, 2: loaders skip the transform + LDS stores, 4: loaders skip the global loads
     unsigned long long* dbg;  // 64 timestamps per launch (tools/debug/c1d_timeline.py): [0,32) loader wave 0, [32,64) multiplier wave 4
@@ -179,11 +182,19 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
     const bool loader = wave < 4;
     const int M = a.B * a.To;
     const int nnb = (a.Cout + C1_BN - 1) / C1_BN;
-    const int m0 = (blockIdx.x / nnb) * C1_BM, n0 = (blockIdx.x % nnb) * C1_BN;
+    // split-K: consecutive workgroups are the K slices of one output tile.  Every slice stores its partial tile into its slab; the
+    // LAST one to arrive (arrival counter) adds the slabs in slice order -- the result does not depend on the arrival order -- and
+    // runs the epilogue.  One launch, no reduce pass, and the tiny-T layers (8-64 tiles) spread their 12-16 K steps over the chip.
+    const int tile = (int)blockIdx.x / a.splitk, zslice = (int)blockIdx.x - tile * a.splitk;
+    const int m0 = (tile / nnb) * C1_BM, n0 = (tile % nnb) * C1_BN;
     const int Ktot = a.taps * a.Cin;
-    const int nit = (Ktot + C1_BK - 1) / C1_BK;
+    const int nit_all = (Ktot + C1_BK - 1) / C1_BK;
+    const int step0 = (zslice * nit_all) / a.splitk, step1 = ((zslice + 1) * nit_all) / a.splitk;
+    const int nit = step1 - step0;                    // K steps of this slice (>= 1: the host keeps splitk <= nit_all)
+    const int kbeg = step0 * C1_BK, kend = min(Ktot, step1 * C1_BK);
     const unsigned OOB = 0x80000000u;
     const int sshift = a.stride - 1;  // stride is 1 or 2
+    __shared__ int sLast;
 
     // source-row windows of the statistics tables.  Rows of the primary source: a contiguous window per batch item; the tile's 32
     // output rows may straddle two batch items, so the tables are indexed by (global row - first global row).
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
         };
         // branch-free on purpose (bitwise & on the predicates, selects on the offsets)
         auto issue = [&](int k, Raw& q) {
-            const bool kok = k < Ktot;
+            const bool kok = k < kend;
 #pragma unroll
             for (int j = 0; j < 4; ++j) q.b[j] = c1_ld4(rsW, (kok & (wb[j] != OOB)) ? wb[j] + (unsigned)k * 4u : OOB);
             const int t = (int)__umulhi((unsigned)k, a.cin_magic), c = k - t * a.Cin;  // k / Cin, k % Cin (exactness checked on the host)
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
         C1_STAMP(0);
         Raw ring[D];
 #pragma unroll
-        for (int s0 = 0; s0 < D; ++s0) issue(s0 * C1_BK + 4 * lq, ring[s0]);
+        for (int s0 = 0; s0 < D; ++s0) issue(kbeg + s0 * C1_BK + 4 * lq, ring[s0]);
         C1_STAMP(1);
 
         // statistics tables: threads 0..79 the primary source, threads 128..207 the half-resolution source
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
             for (int s0 = 0; s0 < U; ++s0) {
                 const int it = it0 + s0;
                 if (!C1_DBG_MODE(2)) to_lds(ring[(s0 + 1) % D], (s0 & 1) ^ 1);        // tile it+1 (zeros past the end of K): issued D-1 steps ago
-                if (!C1_DBG_MODE(4)) issue((it + D) * C1_BK + 4 * lq, ring[s0 % D]);  // slot of tile `it`, moved to LDS one step ago
+                if (!C1_DBG_MODE(4)) issue(kbeg + (it + D) * C1_BK + 4 * lq, ring[s0 % D]);  // slot of tile `it`, moved to LDS one step ago
                 C1_STAMP(6 + it);
                 c1_barrier();                                    // (3 + it)
                 if (it + 1 >= nit) goto loaders_done;
@@ -361,6 +372,11 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
         }
     loaders_done:
         C1_STAMP(30);
+        if (a.splitk > 1) {
+            c1_barrier();  // (F1) partial tile stored
+            c1_barrier();  // (F2) sLast published
+            if (!sLast) return;
+        }
         c1_barrier();  // (E) the multipliers' epilogue partials
         C1_STAMP(31);
     } else {
@@ -423,6 +439,43 @@ __global__ __launch_bounds__(512) void c1d_kernel(const c1d_args a) {
             C1_STAMP(6 + it);
             c1_barrier();  // (3 + it)
             if (it + 1 >= nit) break;
+        }
+
+        if (a.splitk > 1) {  // ---- split-K fix-up
+            const size_t slab = (size_t)M * a.Cout;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int n = n0 + wn * 32 + tl * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+                    if (m < M && n < a.Cout) a.slabs[(size_t)zslice * slab + (size_t)m * a.Cout + n] = acc[tl][r];
+                }
+            }
+            __threadfence();  // the partial tile is visible device-wide before the arrival is counted
+            c1_barrier();     // (F1)
+            if (tid == 256) {
+                const unsigned old = atomicAdd(&a.counters[tile], 1u);
+                sLast = old == (unsigned)a.splitk - 1u;
+                if (sLast) a.counters[tile] = 0u;  // every slice has arrived: leave the counter ready for the next launch
+            }
+            c1_barrier();  // (F2)
+            if (!sLast) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int n = n0 + wn * 32 + tl * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+                    float v = 0.f;
+                    if (m < M && n < a.Cout) {
+                        const float* ps_ = a.slabs + (size_t)m * a.Cout + n;
+                        for (int z = 0; z < a.splitk; ++z) v += __builtin_nontemporal_load(ps_ + (size_t)z * slab);
+                    }
+                    acc[tl][r] = v;
+                }
+            }
         }
 
         // ---- epilogue
@@ -571,6 +624,10 @@ extern "C" int sdt_c1d_layer_f32(const sdt_c1d* p, void* stream) {
     a.X = p->X; a.X2 = p->X2; a.xstats = p->xstats; a.x2stats = p->x2stats; a.W = p->W; a.bias = p->bias; a.add = p->add; a.Y = p->Y;
     a.ystats = p->ystats; a.bw_y = p->bw_y; a.bw_stats = p->bw_stats;
     a.B = p->B; a.Ti = p->Ti; a.T2 = p->T2; a.Cin = p->Cin; a.To = p->To; a.Cout = p->Cout; a.taps = p->taps; a.stride = p->stride; a.pad = p->pad;
+    const int nit_all = cdiv(p->taps * p->Cin, C1_BK);
+    SDT_CHECK_ARG(p->splitk >= 1 && p->splitk <= 16 && p->splitk <= nit_all, "splitk must be in [1, min(16, K steps)]");
+    SDT_CHECK_ARG(p->splitk == 1 || (p->slabs != nullptr && p->counters != nullptr), "split-K needs the slab workspace and the counters");
+    a.splitk = p->splitk; a.slabs = p->slabs; a.counters = p->counters;
     a.cin_magic = (unsigned)((1ull << 32) / (unsigned)p->Cin + 1ull);
     SDT_CHECK_ARG((uint64_t)(p->taps * p->Cin + 64 * C1_BK) * (uint64_t)p->Cin < (1ull << 31), "K extent too large for the reciprocal division");
 #ifdef SDT_TUNING
@@ -579,7 +636,7 @@ extern "C" int sdt_c1d_layer_f32(const sdt_c1d* p, void* stream) {
 #endif
     a.in_mode = p->in_mode; a.np_in = p->np_in; a.np_in2 = p->np_in2; a.np_bw = p->np_bw; a.eps = p->eps; a.slope = p->slope;
     const int M = p->B * p->To;
-    const unsigned grid = (unsigned)(cdiv(M, C1_BM) * cdiv(p->Cout, C1_BN));
+    const unsigned grid = (unsigned)(cdiv(M, C1_BM) * cdiv(p->Cout, C1_BN) * p->splitk);
     const bool bw = p->bw_y != nullptr;
 #define C1_LAUNCH(MODE)                                                                                      \
     if (bw) hipLaunchKernelGGL((c1d_kernel<MODE, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);  \

@@ -78,8 +78,34 @@ def usable(gen, h0):
     return h0.shape[1] >= 64 and h0.shape[1] % 32 == 0  # five stride-2 levels down to T/32 >= 2
 
 
+# K slices inside the launch for layers with few output tiles (sdt_c1d.splitk: partial tiles in slabs, the last slice to arrive
+# adds them in order).  Correct and deterministic, but MEASURED SLOWER and therefore off: the layers it targets went from 20 to
+# 36-60 us per launch and the whole step lost 8 % -- on a multi-XCD part the device-scope release / acquire around the arrival
+# counter is an L2 write-back + invalidate of the whole XCD (the slices of a tile run on different XCDs), which also hurts the
+# kernels running next to it on the side stream (profiles/r02_conv1d_stage.txt).
+SPLITK = os.environ.get("SDT_STAGE1D_SPLITK", "0") == "1"
+_WS = {}        # device index -> (slab workspace, arrival counters): launches of one stream use it one after the other
+
+
+def _split(d, M, dev):
+    """K slices for a launch: spread the 12-16 serial K steps of a layer with few output tiles over the chip."""
+    tiles = -(-M // 32) * -(-d.Cout // 64)
+    steps = -(-(d.taps * d.Cin) // 64)
+    s = 1 if (not SPLITK or tiles >= 192) else max(1, min(8, steps // 2, 256 // tiles))
+    d.splitk = s
+    if s > 1:
+        need = s * M * d.Cout
+        ws = _WS.get(dev.index)
+        if ws is None or ws[0].numel() < need:
+            cnt = ws[1] if ws is not None else torch.zeros(4096, device=dev, dtype=torch.int32)
+            ws = (torch.empty(max(need, 1 << 22), device=dev, dtype=torch.float32), cnt)
+            _WS[dev.index] = ws
+        d.slabs, d.counters = _p(ws[0]), _p(ws[1])
+
+
 def _launch(lib, role, d, st, M):
     """one c1d launch (+ a ConvProfiler record when bench.py samples this step)"""
+    _split(d, M, torch.device("cuda", torch.cuda.current_device()))
     if ops.PROFILER is None:
         check(lib.sdt_c1d_layer_f32(d, st))
         return
