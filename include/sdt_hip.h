@@ -278,6 +278,10 @@ int sdt_upsample_add_bwd_f32(const float* dout, float* dprev, int B, int Ti, int
 /* nn.L1Loss(reduction='none')(pred,gt)*lambda .mean() (voice2pose.py:141-142). partial: >=256 doubles. */
 int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n, float lambda, double* partial, float* loss, void* stream);
 int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, int64_t n, float lambda, float* dpred, void* stream);
+/* LSGAN terms (voice2pose.py:171-189, nn.MSELoss against a constant): loss = lambda * mean((scores - target)^2);
+ * dscores = gout * 2 * lambda / n * (scores - target). */
+int sdt_mse_const_fwd_f32(const float* scores, int64_t n, float target, float lambda, float* loss, void* stream);
+int sdt_mse_const_bwd_f32(const float* scores, const float* gout, int64_t n, float target, float lambda, float* dscores, void* stream);
 
 /*
  * Clip-code batch KL (voice2pose.py:147-157): code = table[idx] (B,D); mu/unbiased var over the batch;

@@ -86,6 +86,8 @@ SIGNATURES = {
     "sdt_upsample_add_bwd_f32": [_p, _p, _i, _i, _i, _i, _p],
     "sdt_l1_loss_fwd_f32": [_p, _p, _i64, _f, _p, _p, _p],
     "sdt_l1_loss_bwd_f32": [_p, _p, _p, _i64, _f, _p, _p],
+    "sdt_mse_const_fwd_f32": [_p, _i64, _f, _f, _p, _p],
+    "sdt_mse_const_bwd_f32": [_p, _p, _i64, _f, _f, _p, _p],
     "sdt_code_kl_fwd_f32": [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p],
     "sdt_code_kl_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
     "sdt_final_metrics_f64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],

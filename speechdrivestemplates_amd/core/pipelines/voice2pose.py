@@ -160,10 +160,10 @@ class Voice2PoseModel(nn.Module):
             s_real = self.netD_pose(real)
             s_fake = self.netD_pose(fake)
             s_fake_det = self.netD_pose(fake.detach())
-            g_gan = ((s_fake - 1.0) ** 2).mean() * d.LAMBDA_GAN
+            g_gan = ops.MseConstFn.apply(s_fake, 1.0, d.LAMBDA_GAN)  # nn.MSELoss against ones / zeros (voice2pose.py:189-197)
             losses['G_pose_gan_loss'] = g_gan
             losses['G_loss'] = g_loss + g_gan
-            d_loss = (((s_real - 1.0) ** 2).mean() + (s_fake_det ** 2).mean()) * d.LAMBDA_GAN
+            d_loss = ops.MseConstFn.apply(s_real, 1.0, d.LAMBDA_GAN) + ops.MseConstFn.apply(s_fake_det, 0.0, d.LAMBDA_GAN)
             losses.update(D_pose_gan_loss=d_loss, pose_score_fake=s_fake.mean(), pose_score_real=s_real.mean())
         return losses, results
 

@@ -186,6 +186,28 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+// LSGAN terms (voice2pose.py:171-189): loss = lambda * mean((s - target)^2) over the n discriminator scores (a few thousand values:
+// one workgroup, fp64 partials combined in a fixed order)
+__global__ __launch_bounds__(256) void mse_const_fwd_kernel(const float* __restrict__ sc, int64_t n, float target, double scale,
+                                                            float* __restrict__ loss) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double d = (double)sc[i] - (double)target;
+        a += d * d;
+    }
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) * scale);
+}
+__global__ __launch_bounds__(256) void mse_const_bwd_kernel(const float* __restrict__ sc, const float* __restrict__ gout, int64_t n,
+                                                            float target, float scale, float* __restrict__ ds) {
+    const float go = gout[0] * scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) ds[i] = go * (sc[i] - target);
+}
+
+// ---------------------------------------------------------------------------------------------
 // clip-code batch KL (voice2pose.py:147-157); one workgroup, one thread per code dimension
 // One workgroup; thread = (code dimension d, batch slice g): the B gathered rows are spread over 256/Dp slices so that
 // the dependent idx -> table loads of a column run in parallel; per-slice partial sums are combined in slice order
@@ -570,6 +592,20 @@ extern "C" int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n
 extern "C" int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, int64_t n, float lambda, float* dpred, void* stream) {
     SDT_CHECK_ARG(pred && gt && gout && dpred && n > 0, "bad argument");
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, pred, gt, gout, n, (float)((double)lambda / (double)n), dpred);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_mse_const_fwd_f32(const float* scores, int64_t n, float target, float lambda, float* loss, void* stream) {
+    SDT_CHECK_ARG(scores && loss && n > 0, "bad argument");
+    hipLaunchKernelGGL(mse_const_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, n, target, (double)lambda / (double)n, loss);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+extern "C" int sdt_mse_const_bwd_f32(const float* scores, const float* gout, int64_t n, float target, float lambda, float* dscores,
+                                     void* stream) {
+    SDT_CHECK_ARG(scores && gout && dscores && n > 0, "bad argument");
+    hipLaunchKernelGGL(mse_const_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, scores, gout, n, target,
+                       (float)(2.0 * (double)lambda / (double)n), dscores);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

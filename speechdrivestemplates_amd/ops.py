@@ -1093,6 +1093,28 @@ class L1LossFn(torch.autograd.Function):
         return dp, None, None
 
 
+class MseConstFn(torch.autograd.Function):
+    """lambda * mean((scores - target)^2): the LSGAN generator / discriminator terms (voice2pose.py:171-189)."""
+
+    @staticmethod
+    def forward(ctx, scores, target, lam):
+        _req_cuda(scores)
+        scores = scores.contiguous()
+        loss = torch.empty((), device=scores.device, dtype=torch.float32)
+        check(_lib.load().sdt_mse_const_fwd_f32(_p(scores), scores.numel(), float(target), float(lam), _p(loss), _stream()))
+        ctx.save_for_backward(scores)
+        ctx.target, ctx.lam = float(target), float(lam)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (scores,) = ctx.saved_tensors
+        ds = torch.empty_like(scores)
+        gout = gout.contiguous()
+        check(_lib.load().sdt_mse_const_bwd_f32(_p(scores), _p(gout), scores.numel(), ctx.target, ctx.lam, _p(ds), _stream()))
+        return ds, None, None
+
+
 class CodeGatherKLFn(torch.autograd.Function):
     """code = table[idx] and the batch-KL regulariser on it (voice2pose.py:94,147-157) in one launch.
     Returns (code, kl, valid); kl == 0 and valid == 0 when any batch variance is exactly zero (the

@@ -843,3 +843,20 @@ def test_deterministic_weight_gradient(ops, case):
         check(tag + " dW (atomics) vs deterministic", wd.grad, runs[0].double(), 2e-5)
     finally:
         ops.DETERMINISTIC_DW = prev
+
+
+def test_lsgan_mse_terms(ops):
+    """ops.MseConstFn (sdt_mse_const_*_f32) = nn.MSELoss(scores, full_like(scores, target)) * lambda, forward and gradient
+    (voice2pose.py:189-197)."""
+    g = torch.Generator().manual_seed(5)
+    for shape, target, lam in (((32, 1, 7), 1.0, 1.0), ((4, 1, 3), 0.0, 0.5), ((3, 1000), 1.0, 2.0)):
+        s = torch.randn(shape, generator=g, dtype=torch.float64)
+        sr = s.clone().requires_grad_(True)
+        ref = F.mse_loss(sr, torch.full_like(sr, target)) * lam
+        (ref * 1.5).backward()
+        sd = s.float().to(DEV).requires_grad_(True)
+        out = ops.MseConstFn.apply(sd, target, lam)
+        (out * 1.5).backward()
+        torch.cuda.synchronize()
+        check("lsgan term %s" % (shape,), out.reshape(1), ref.detach().reshape(1), 1e-6)
+        check("lsgan term gradient %s" % (shape,), sd.grad, sr.grad, 1e-6)
