@@ -1539,10 +1539,33 @@ static void dw_split(bool vec4, const sdt_conv_geom& g, int& nsplit, int& rows, 
     const int M = g.B * g.Ho * g.Wo;
     coltiles = vec4 ? g.ntaps * cdiv(g.Cin, BN) : cdiv(g.ntaps * g.Cin, BN);
     ntiles = cdiv(g.Cout, BM);
-    nsplit = cdiv(1536, coltiles * ntiles);
-    nsplit = max(1, min(nsplit, max(1, M / (4 * BK))));  // at least 4 K-steps per workgroup: bounds the atomic traffic
-    rows = cdiv(cdiv(M, nsplit), BK) * BK;
-    nsplit = cdiv(M, rows);
+    const int tiles = coltiles * ntiles;
+    // All workgroups of a launch are co-resident (8 per CU fit) and the kernel is MFMA-bound, so the launch lasts as long as the
+    // fullest CU: pick the row split whose workgroup count sits just BELOW a multiple of 256 (cdiv(1536, tiles) put 6.05-6.19
+    // workgroups on a CU for the 3x3 layers: 13-16 % of the launch spent with 7 workgroups on a few CUs and 6 on the rest).
+    const int max_split = std::max(1, M / (4 * BK));  // at least 4 K-steps per workgroup: bounds the atomic traffic
+#ifdef SDT_TUNING  // A/B: the round-1 rule
+    static const int old_rule = getenv("SDT_DW_SPLIT_OLD") ? atoi(getenv("SDT_DW_SPLIT_OLD")) : 0;
+    if (old_rule) {
+        nsplit = std::max(1, std::min(cdiv(1536, tiles), max_split));
+        rows = cdiv(cdiv(M, nsplit), BK) * BK;
+        nsplit = cdiv(M, rows);
+        return;
+    }
+#endif
+    int best = 1, best_rows = cdiv(M, BK) * BK;
+    double best_cost = 1e30;
+    for (int ns = std::max(1, 1024 / tiles); ns <= std::max(1, 2048 / tiles); ++ns) {
+        const int n0 = std::min(ns, max_split);
+        const int r = cdiv(cdiv(M, n0), BK) * BK;
+        const int n1 = cdiv(M, r);
+        const double per_cu = (double)n1 * tiles / 256.0;
+        // time ~ ceil(per_cu) * (work per workgroup ~ r); a mild preference for ~6 workgroups per CU (atomic traffic vs tail)
+        const double cost = std::ceil(per_cu) * (double)r * (1.0 + 0.01 * std::fabs(per_cu - 6.0));
+        if (cost < best_cost) best_cost = cost, best = n1, best_rows = r;
+    }
+    nsplit = best;
+    rows = best_rows;
 }
 
 // slabs != nullptr: deterministic (plain stores into nsplit slabs + an ordered reduce), fp32 math only
