@@ -364,8 +364,9 @@ def _conv_launch(kind, is2d, g, call):
     PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
-def _conv_launch_multi(kind, is2d, gs, call, pre=False):
-    """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient)"""
+def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0):
+    """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient); ``extra_bytes``:
+    what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics)"""
     if PROFILER is None:
         check(call())
         return
@@ -373,7 +374,7 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False):
     var = lib.sdt_conv_taps_variant(gs[0])
     flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for g in gs)
     g0 = gs[0]
-    nbytes = 4.0 * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin)
+    nbytes = 4.0 * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin) + extra_bytes
     e0, e1 = PROFILER.event(), PROFILER.event()
     e0.record()
     check(call())
@@ -559,7 +560,8 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
                 nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
             _conv_launch_multi("dX", True, gs,
                                lambda: lib.sdt_conv_taps_pre_f32(_p(gy_planes), gy_planes.shape[1], _p(wpl[1]), wpl[1].shape[1], _p(dx),
-                                                                 arr, n, None, 0, nb, st), pre=True)
+                                                                 arr, n, None, 0, nb, st), pre=True,
+                               extra_bytes=4.0 * dx.numel() if nb is not None else 0.0)
             return dx
     pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
     if pack is not None:
@@ -574,7 +576,8 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
             h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
             nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
         _conv_launch_multi("dX", not one_d, gs,
-                           lambda: lib.sdt_conv_taps_multi_f32(_p(gy4), _p(wt), _p(dx), arr, n, k, _p(part), nb, st))
+                           lambda: lib.sdt_conv_taps_multi_f32(_p(gy4), _p(wt), _p(dx), arr, n, k, _p(part), nb, st),
+                           extra_bytes=4.0 * dx.numel() if nb is not None else 0.0)
         if k > 1:
             check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
         return dx.squeeze(1) if one_d else dx

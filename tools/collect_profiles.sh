@@ -16,6 +16,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 python tools/trace_summary.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape.txt" 2>&1
 python tools/stream_summary.py "$OUT/trace/b_kernel_trace.csv" 35 14 > "$OUT/streams.txt" 2>&1
 python tools/hbm_kernels.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 > "$OUT/hbm_kernels.txt" 2>&1
+# (3b) the opt-in launch-per-layer Conv1d stage: launch counts / durations by shape
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_fused" -o b -- $CMD --no-overlap-dw --no-kernel-events --fused-conv1d > "$OUT/trace_fused.log" 2>&1
+python tools/trace_summary.py "$OUT/trace_fused/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape_fused.txt" 2>&1
+rm -rf "$OUT/trace_fused"
 # (4) fabric-side traffic: two PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch.log" 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_write.log" 2>&1

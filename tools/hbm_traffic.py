@@ -55,8 +55,8 @@ def main():
         head = subprocess.run(["git", "-C", REPO, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         head = None
-    if head is None and os.path.exists(os.path.join(REPO, "gpurun_out", "git_head.txt")):
-        head = open(os.path.join(REPO, "gpurun_out", "git_head.txt")).read().strip()
+    if head is None and os.path.exists(os.path.join(REPO, ".git_head")):  # the GPU box gets a snapshot without .git/
+        head = open(os.path.join(REPO, ".git_head")).read().strip()
     res = {"command": cmd,
            # bench.py cites this file only while the kernel sources still hash to this digest
            "kernel_source_digest": kernel_source_digest(), "git_head": head,
