@@ -162,12 +162,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_taps_pre_kernel(const __bf1
     int cur_tl = -1, nxt_tl = 0, nxt_kc = 0;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned swz = (unsigned)((kc4 ^ ((r0 >> 2) & 3)) * 16);  // byte offset of the chunk this lane fetches (rows r0 + 64 i share it)
-    auto issue = [&](int buf) {
-        __bf16* const sa = smem + buf * STAGE;
-        __bf16* const sb = sa + 3 * PLANEA;
+    // A step's DMA is issued in two parts: issue_prep picks the (tap, chunk) and rebuilds the row offsets when the tap changes;
+    // issue_piece(i) launches ONE 1-KiB piece.  The K loop spreads the pieces of step s + NBUF - 1 between the MFMA groups of
+    // step s: an LDS-DMA instruction sits in the issue stage for 60-190 cycles (the CU's 64 B/clk vector-memory path), and issued
+    // back to back at the top of a step the 6-12 pieces of a wave stalled it for longer than its MFMAs run.
+    __bf16* isa = smem;
+    __bf16* isb = smem;
+    int ics = 0;
+    auto issue_prep = [&](int buf) {
+        isa = smem + buf * STAGE;
+        isb = isa + 3 * PLANEA;
         const int tl = nxt_tl, kc = nxt_kc;
         if (++nxt_kc == nkc) nxt_kc = 0, ++nxt_tl;
-        const int cs = kc * 192;  // byte offset of the 32-channel chunk inside a row
+        ics = kc * 192;  // byte offset of the 32-channel chunk inside a row
         if (tl != cur_tl) {
             cur_tl = tl;
             const int t = sLive[tl];
@@ -182,18 +189,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_taps_pre_kernel(const __bf1
 #pragma unroll
             for (int i = 0; i < RB; ++i) boff[i] = bbase[i] == SDT_OOB ? SDT_OOB : bbase[i] + bshift;
         }
-        // each instruction: 1 KiB = 16 rows x 64 B of one plane, lane * 16 B apart, at rows 16 (wave + NW i) of the tile
+    };
+    // piece index = plane * (RA + RB) + (row group: A groups first).  Each instruction: 1 KiB = 16 rows x 64 B of one plane,
+    // lane * 16 B apart, at rows 16 (wave + NW i) of the tile
+    auto issue_piece = [&](int idx) {
+        const int p = idx / (RA + RB), r = idx - p * (RA + RB);
+        if (r < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(isa + p * PLANEA + (wave * 16 + 16 * NW * r) * BKP), 16, (int)aoff[r],
+                                                     ics + p * 64, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(isb + p * PLANEB + (wave * 16 + 16 * NW * (r - RA)) * BKP), 16,
+                                                     (int)boff[r - RA], ics + p * 64, 0, 0);
+    };
+    auto issue = [&](int buf) {
+        issue_prep(buf);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(sa + p * PLANEA + (wave * 16 + 16 * NW * i) * BKP), 16, (int)aoff[i],
-                                                         cs + p * 64, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(sb + p * PLANEB + (wave * 16 + 16 * NW * i) * BKP), 16, (int)boff[i],
-                                                         cs + p * 64, 0, 0);
-        }
+        for (int i = 0; i < 3 * (RA + RB); ++i) issue_piece(i);
     };
 
     // Accumulators.  The bf16 MFMA issues every 32 cycles but a DEPENDENT one (same accumulator) waits 64: five correction products
@@ -231,7 +242,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_taps_pre_kernel(const __bf1
         else if (younger == 1) SDT_VMCNT(PIECES);
         else SDT_VMCNT(2 * PIECES);
         __builtin_amdgcn_s_barrier();  // everyone's pieces of `step` have landed, and everyone is done reading the slot reused below
-        if (step + NBUF - 1 < nsteps) issue(nbuf);
+        const bool more = step + NBUF - 1 < nsteps;
+        if (more) issue_prep(nbuf);
         const __bf16* pa = smem + buf * STAGE + rowA;
         const __bf16* pb = smem + buf * STAGE + 3 * PLANEA + rowB;
         nbuf = buf;
@@ -249,12 +261,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_taps_pre_kernel(const __bf1
             // (A piece, B piece, accumulator) of the six products, product-major over the tiles
             constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0}, PC[6] = {0, 1, NA - 1, 1, NA - 1, 1};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < 6; ++q) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[PC[q]][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][PA[q]], b[tn][PB[q]], acc[PC[q]][tm][tn], 0, 0, 0);
+                // the DMA pieces of step + NBUF - 1 that belong behind MFMA group 6 j + q (12 groups per step)
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < PIECES; ++i)
+                        if ((i * 12) / PIECES == 6 * j + q) issue_piece(i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #pragma unroll

@@ -62,7 +62,7 @@ def main():
         t_f = timeit(lambda: ops.conv_forward(x, w, None, s, p), a.reps)
         t_d = timeit(lambda: ops.conv_input_grad(gy, w, x.shape, s, p), a.reps)
         line = "%-3s fp32-MFMA fwd %7.1f us %6.1f TF | dX %7.1f us %6.1f TF ||" % (name, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6)
-        for tile in (64064, 128064, 1281288, 1282568):
+        for tile in (64064, 128128, 1281288, 1282568):
             _lib.check(lib.sdt_set_pre_tile(tile))
             f = lambda: _lib.check(lib.sdt_conv_taps_pre_f32(xp.data_ptr(), xp.shape[1], wp.data_ptr(), wp.shape[1], y.data_ptr(), geo, 1, None, 0, None, st))  # noqa: E731
             d = lambda: _lib.check(lib.sdt_conv_taps_pre_f32(gyp.data_ptr(), gyp.shape[1], wtp.data_ptr(), wtp.shape[1], dx.data_ptr(), arr, n, None, 0, None, st))  # noqa: E731
