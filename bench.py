@@ -51,7 +51,11 @@ EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "6"))
 
 
 def event_steps(steps):
-    return min(EVENT_STEPS_MAX, max(3, (steps // 30) * 3), steps)
+    """sampled steps of the timed region: one "alone" + one "stages only" below 40 steps (a per-launch-event step costs ~1.5 ms, so
+    short runs carry a single one), a full rotation of three from 40 steps on, two rotations from 60 on"""
+    if steps < 2:
+        return steps  # a single timed step still carries the roofline sample
+    return 2 if steps < 40 else min(EVENT_STEPS_MAX, (steps // 30) * 3 if steps >= 60 else 3)
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -278,12 +282,14 @@ def main(argv=None):
             if i in sampled:
                 # three kinds of sampled step in rotation: per-launch events with the side stream off ("alone"), per-launch events
                 # as run, and stage windows only (a handful of events per step: per-launch events would inflate the windows)
-                if n_alone <= n_stage:
+                if n_alone <= n_ovl:
                     ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
-                elif prof_ovl is not None and n_ovl < n_alone:
+                elif n_stage < n_alone:
+                    ops.STAGES, n_stage = stages, n_stage + 1
+                elif prof_ovl is not None:
                     ops.PROFILER, n_ovl = prof_ovl, n_ovl + 1
                 else:
-                    ops.STAGES, n_stage = stages, n_stage + 1
+                    ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
         losses = runner(args.warmup + i)
     if marks is not None:
         marks[args.steps].record()
