@@ -180,6 +180,7 @@ def main(argv=None):
     ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="product arithmetic of the forward / input-gradient conv kernels (experiments; the metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the informational 20 steps in bf16x6 conv math after the timed region")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: capture the side streams too (experiment)")
@@ -394,6 +395,28 @@ def main(argv=None):
             hb = os.path.join(REPO, "profiles", "r02_hbm_kernels.txt")
             if os.path.exists(hb):
                 out["hbm_kernels_table"] = "profiles/r02_hbm_kernels.txt (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)"
+        if world == 1 and not stub and not args.no_alt_mode and args.conv_math == "f32" and not args.graph and on_gpu:
+            # informational, OUTSIDE the timed region and not part of `value`: the same step with the conv products evaluated as
+            # six bf16 MFMA products of exactly split operands (fp32-equivalent: passes the B=32 float64-calibrated parity tests,
+            # tests/test_fullsize_gpu.py::test_b32_bf16x6_mode_meets_the_fp32_bar) -- opt-in via --conv-math
+            ops.set_conv_math("bf16x6")
+            try:
+                for i in range(3):
+                    runner(args.warmup + args.steps + i)
+                sync()
+                ta = time.perf_counter()
+                n_alt = 20
+                for i in range(n_alt):
+                    losses_alt = runner(args.warmup + args.steps + 3 + i)
+                sync()
+                alt_ms = (time.perf_counter() - ta) * 1e3 / n_alt
+            finally:
+                ops.set_conv_math("f32")
+            alt_loss = float(losses_alt["G_loss" if "G_loss" in losses_alt else "loss"].detach())
+            out["alt_conv_math"] = {"mode": "bf16x6", "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt,
+                                    "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
+                                    "note": "not the headline: 20 further steps of the same run with --conv-math bf16x6 (exact 3-piece bf16 "
+                                            "split of both operands inside the conv kernels, 6 MFMA products, fp32 accumulation), no sampling events"}
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(B)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

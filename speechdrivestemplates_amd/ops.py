@@ -410,7 +410,11 @@ def conv_forward(x_cl, w, bias, stride, pad):
 
 
 CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
-PRESPLIT = True  # in 'bf16x6' mode the 2-D chain runs on PRE-SPLIT bf16 planes (sdt_conv_taps_pre_f32) where producers emit them
+# In 'bf16x6' mode the 2-D chain can run on PRE-SPLIT bf16 planes (sdt_conv_taps_pre_f32) that the producing kernels emit.  OFF by
+# default: measured end to end it is SLOWER than splitting inside the conv kernels (4060 vs 4445 clips/s on one box, f32 4000):
+# the pre kernel reaches 120 TFLOP/s in the step against 125 for the split-in-kernel variant, and every normalisation pass writes
+# 1.5x more bytes.  SDT_PRESPLIT=1 enables it (tests/test_fullsize_gpu.py covers both forms).
+PRESPLIT = os.environ.get("SDT_PRESPLIT", "0") == "1"
 
 
 def presplit_on():

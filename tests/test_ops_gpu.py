@@ -761,6 +761,8 @@ def test_presplit_chain_matches_float64(ops, norm):
             calls.append(a[6])
             return orig(*a)
     ops.set_conv_math("bf16x6")
+    prev_presplit = ops.PRESPLIT
+    ops.PRESPLIT = True  # opt-in pipeline (SDT_PRESPLIT=1)
     try:
         lib.sdt_conv_taps_pre_f32 = Spy()
         xin = x.clone().requires_grad_(True)
@@ -774,6 +776,7 @@ def test_presplit_chain_matches_float64(ops, norm):
     finally:
         lib.sdt_conv_taps_pre_f32 = orig
         ops.set_conv_math("f32")
+        ops.PRESPLIT = prev_presplit
     assert sorted(calls) == [1, 1, 1, 4], calls  # 2 forwards; dX of blk3 (stride 1) and of blk2 (4 parity classes, one launch)
     got = [xin.grad] + [p.grad for b in (blk1, blk2, blk3) for p in b.parameters()]
 
