@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_final
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python bench.py --steps 30 --warmup 5 --no-cpu-baseline"
+CMD="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-alt-mode"
 # (1) the bench line as the driver runs it
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 # (2) kernel trace + stats of the same command (default: weight gradients on the side stream)
@@ -21,9 +21,9 @@ timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_fused" -
 python tools/trace_summary.py "$OUT/trace_fused/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape_fused.txt" 2>&1
 rm -rf "$OUT/trace_fused"
 # (4) fabric-side traffic: two PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch.log" 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_write.log" 2>&1
-python tools/hbm_traffic.py "$OUT/pmc_fetch/b_counter_collection.csv" "$OUT/pmc_write/b_counter_collection.csv" "$OUT/hbm_traffic_bench.json" "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events" > "$OUT/hbm_traffic.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_fetch.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_write.log" 2>&1
+python tools/hbm_traffic.py "$OUT/pmc_fetch/b_counter_collection.csv" "$OUT/pmc_write/b_counter_collection.csv" "$OUT/hbm_traffic_bench.json" "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode" > "$OUT/hbm_traffic.log" 2>&1
 # keep the merged payload small: drop the raw traces / databases, keep the stats
 for d in trace trace_noovl; do cp "$OUT/$d/b_kernel_stats.csv" "$OUT/${d}_kernel_stats.csv" 2>/dev/null; done
 rm -rf "$OUT/trace" "$OUT/trace_noovl" "$OUT/pmc_fetch" "$OUT/pmc_write"
