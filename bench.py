@@ -413,6 +413,7 @@ def main(argv=None):
             finally:
                 ops.set_conv_math("f32")
             alt_loss = float(losses_alt["G_loss" if "G_loss" in losses_alt else "loss"].detach())
+            assert alt_loss == alt_loss and alt_loss < 10.0, "bf16x6 leg diverged: G_loss=%r" % alt_loss
             out["alt_conv_math"] = {"mode": "bf16x6", "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt,
                                     "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
                                     "note": "not the headline: 20 further steps of the same run with --conv-math bf16x6 (exact 3-piece bf16 "
