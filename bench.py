@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Benchmark of the SDT voice2pose training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (runs as typed: for N>1 without a launcher it starts its own N ranks,
+                                                            one per GPU, as the reference does with mp.spawn, main.py:60-69;
+                                                            under torch.distributed.run it takes the launcher's environment)
 
 Workload (BASELINE.json configs[1]): voice2pose_sdt_bp, 32 clips per GPU (weak scaling), 64-frame / 121-kpt clips
 (137 on-disk keypoints), fp32, synthetic seeded clips pre-staged in HBM.  One step = Voice2Pose.train_step without
@@ -197,6 +199,18 @@ def main(argv=None):
 
     stub = os.environ.get("SDT_BENCH_STUB") == "1"
     backend = os.environ.get("SDT_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for the CPU control-flow test
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as a plain command: become the launcher (the reference spawns its own ranks too, main.py:60-69) -- re-exec under
+        # torch.distributed.run with one rank per GPU on this node; rank 0 of the children prints the JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,7 +227,7 @@ def main(argv=None):
                 dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
 
@@ -253,6 +267,9 @@ def main(argv=None):
 
     for i in range(args.warmup):
         runner(i)
+    reducer = getattr(pipe, "reducer", None)
+    if world > 1 and reducer is not None and on_gpu:
+        reducer.exposed_events = []  # main-stream event windows around the gradient exchange of every timed step
     # HIP events around every conv launch on a few timed steps, recorded on the stream each kernel is launched on.  By default the
     # weight-gradient kernels run on a second stream, concurrently with the input-gradient chain, so a launch's duration
     # then includes the time it shared the GPU: sampled steps therefore ALTERNATE between "alone" (side stream off for
@@ -308,10 +325,20 @@ def main(argv=None):
     else:
         step_ms = [1e3 * (host_marks[i + 1] - host_marks[i]) for i in range(args.steps)]
     clean_ms = [t for i, t in enumerate(step_ms) if i not in sampled] or step_ms
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed, statistics.median(step_ms), sum(clean_ms) / len(clean_ms)], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, median_ms, clean_mean_ms = (float(x) for x in t.tolist())
+        exposed = reducer.exposed_us() if (reducer is not None and on_gpu) else None
+        mine = torch.tensor([elapsed, statistics.median(step_ms), sum(clean_ms) / len(clean_ms), -1.0 if exposed is None else exposed],
+                            device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = [[float(x) for x in g.tolist()] for g in gathered]
+        per_rank = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                    "elapsed_s": [r[0] for r in rows], "median_ms_per_step": [r[1] for r in rows],
+                    "exposed_allreduce_us_per_step": None if rows[0][3] < 0 else [r[3] for r in rows],
+                    "note": "exposed_allreduce_us: main-stream HIP-event window around GradReducer.all_reduce (late buckets + wait for "
+                            "the communication stream) -- the part of the gradient exchange that backward did not hide"}
+        elapsed, median_ms, clean_mean_ms = (max(r[k] for r in rows) for k in range(3))  # the slowest rank defines the job
     else:
         median_ms, clean_mean_ms = statistics.median(step_ms), sum(clean_ms) / len(clean_ms)
     final_loss = float(losses["G_loss" if "G_loss" in losses else "loss"].detach())
@@ -337,12 +364,19 @@ def main(argv=None):
         }
         if stub:
             out["stub"] = True
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if prof is not None and prof_steps > 0:
             summ = prof.summary()
             name, d = max(summ.items(), key=lambda kv: kv[1]["us"])
             avg_us = d["us"] / d["launches"]
             flops_per_launch = d["flops"] / d["launches"]
             achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
+            # accounting guard: an event window contains the launch, so algorithmic FLOPs / window can never exceed
+            # the matrix peak -- if it does, the FLOP numerator counts work that does not exist (e.g. culled structural zeros)
+            for kname, kd in summ.items():
+                assert kd["max_launch_tflops"] <= FP32_MATRIX_PEAK_TFLOPS or args.conv_math != "f32", \
+                    "%s: a launch 'achieved' %.1f TFLOP/s > fp32 matrix peak: FLOP accounting is wrong" % (kname, kd["max_launch_tflops"])
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
                                "launches_per_step": d["launches"] / prof_steps, "avg_launch_us": avg_us,
@@ -350,7 +384,8 @@ def main(argv=None):
                                "measured": "HIP events on the launching stream, sampled steps of the timed region with the "
                                            "weight-gradient side stream switched off (the kernel alone on the GPU)",
                                "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
-                               "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6}
+                               "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6,
+                               "fastest_launch_tflops": d["max_launch_tflops"]}
             # the same kernel serves the MFMA-bound Conv2d launches and the latency-bound 1-D launches (M = B*T <= 2048 rows):
             # the average above mixes them, the split shows each (role = forward / input gradient, 2-D / 1-D stage)
             out["roofline"]["by_role"] = {

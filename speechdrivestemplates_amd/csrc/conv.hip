@@ -45,6 +45,26 @@ struct norm_bwd_args {
     int groups;
 };
 
+#ifdef SDT_TUNING
+// PRIO 30 (tools/debug/taps_timeline.py): lane 0 of every workgroup stamps the 100 MHz real-time counter at five points of its
+// life and its hardware id into sdt_dbg_tl[8 * linear workgroup id ...] -- where a launch's time goes (prologue / K loop / epilogue,
+// workgroups per CU, generations).
+__device__ unsigned long long* sdt_dbg_tl = nullptr;
+extern "C" int sdt_debug_set_timeline(void* p) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sdt_dbg_tl), &p, sizeof(p));
+    return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
+}
+#define SDT_TL(slot)                                                                                                   \
+    do {                                                                                                               \
+        if constexpr (PRIO == 30) {                                                                                    \
+            if (threadIdx.x == 0 && sdt_dbg_tl != nullptr)                                                             \
+                sdt_dbg_tl[8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + (slot)] = wall_clock64(); \
+        }                                                                                                              \
+    } while (0)
+#else
+#define SDT_TL(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // stats != nullptr: the epilogue also accumulates sum(y) and sum(y^2) per (group, output channel) into ``stats`` (fp64
 // atomics; the buffer must be zero on entry), group = output row index / rows_per_group -- the statistics pass of the
@@ -98,6 +118,14 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     // (measured before this ordering: L2-miss traffic 9-16x the input bytes on the Cout=256 layers).
     const int nnb = (g.Cout + BN - 1) / BN;
     if ((int)blockIdx.x >= nmb * nnb) return;  // the grid is sized for the largest class of the launch
+    SDT_TL(0);
+#ifdef SDT_TUNING
+    if constexpr (PRIO == 30) {
+        if (threadIdx.x == 0 && sdt_dbg_tl != nullptr)
+            sdt_dbg_tl[8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 5] =
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
     const int lin = xcd_remap(blockIdx.x, nmb * nnb);
     int mt = lin / nnb;
     if constexpr (VEC4) {
@@ -383,6 +411,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
             __syncthreads();
         }
     } else {
+    SDT_TL(1);
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
         if (!(PRIO == 7 || PRIO == 8 || PRIO == 9) || step == step0) {
@@ -392,6 +421,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
             for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * LDP + kv * 4] = rb[i];
         }
         if (PRIO != 4 && (PRIO != 9 || step == step0)) __syncthreads();
+        if (step == step0) SDT_TL(2);  // the first tile is in LDS
         if constexpr (PRIO != 3 && PRIO != 6 && PRIO != 7 && PRIO != 8 && PRIO != 9) {
             if (step + 1 < nsteps) load(step + 1);
         }
@@ -430,6 +460,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     }
+    SDT_TL(3);  // K loop done
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (splitk > 1) {
         Y = partial + (size_t)blockIdx.z * ysize;
@@ -530,6 +561,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                 }
             }
         }
+    SDT_TL(4);  // every store / atomic of the epilogue issued
 }
 
 
@@ -1380,6 +1412,7 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
     else if (vec4 && prio == 14) SDT_TAPS(14);  // A/B: row-residue tap order on every launch
     else if (vec4 && prio == 16) SDT_TAPS(16);  // A/B: tap culling also on launches with <= 4 taps
     else if (vec4 && prio == 20) SDT_TAPS(20);  // experiment: double-buffered LDS, one barrier per K step
+    else if (vec4 && prio == 30) SDT_TAPS(30);  // per-workgroup timeline stamps (tools/debug/taps_timeline.py)
     else
 #endif
     if (vec4)

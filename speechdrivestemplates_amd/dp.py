@@ -56,6 +56,13 @@ def replica_state(model, optimizers):
     out += list(model.buffers())
     ext = getattr(model, 'clips_code', None)
     if torch.is_tensor(ext) and not isinstance(ext, torch.nn.Parameter):
+        # external clip codes (EXTERNAL_CODE configs, voice2pose.py:40-48) arrive as a host tensor and are moved to the GPU lazily
+        # on first use; RCCL cannot broadcast a host tensor ("No backend type associated with device type cpu"), so they move now
+        ref = out[0] if out else None
+        if ref is not None and ext.device != ref.device:
+            mover = getattr(model, '_code_table', None)
+            ext = mover(ref.device) if mover is not None else ext.to(ref.device)
+            model.clips_code = ext
         out.append(ext)
     return out
 
@@ -98,6 +105,16 @@ class GradReducer:
         if self.active and overlap and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
             self.comm_stream = torch.cuda.Stream()
         self._pending = []
+        # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
+        # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide
+        self.exposed_events = None
+
+    def exposed_us(self):
+        """mean main-stream time per all_reduce() call since ``exposed_events`` was set to a list (None: not recorded)"""
+        if not self.exposed_events:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.exposed_events) * 1e3 / len(self.exposed_events)
 
     def launch(self, opt, lo=0, hi=None):
         """Start the summing all-reduce of ``opt.flat_grad[lo:hi]`` (call as soon as that range's backward kernels have
@@ -135,6 +152,10 @@ class GradReducer:
 
     def all_reduce(self, opts=None):
         """Exchange whatever part of each group's gradients has not been launched early, then wait for all of it."""
+        timed = self.exposed_events is not None and self.active and self.optimizers[0].flat_grad.is_cuda
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for opt in (opts if opts is not None else self.optimizers):
             early = sorted(self._launched.pop(id(opt), []))
             pos, n = 0, opt.flat_grad.numel()
@@ -144,6 +165,10 @@ class GradReducer:
                 pos = max(pos, hi)
             self._launched.pop(id(opt), None)
         self.wait()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed_events.append((e0, e1))
 
 
 def reduce_scalars(tensor_dict, dst=0):

@@ -296,8 +296,10 @@ class ConvProfiler:
         torch.cuda.synchronize()
         out = {}
         for name, role, is2d, flops, nbytes, e0, e1 in self.records:
-            d = out.setdefault(name, {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0, "roles": {}})
+            d = out.setdefault(name, {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0, "roles": {}, "max_launch_tflops": 0.0})
             us = e0.elapsed_time(e1) * 1e3
+            if us > 0.0:  # the fastest single launch: bench.py asserts that no launch beats the matrix peak (FLOP accounting guard)
+                d["max_launch_tflops"] = max(d["max_launch_tflops"], flops / (us * 1e-6) / 1e12)
             d["launches"] += 1
             d["us"] += us
             d["flops"] += flops
@@ -347,14 +349,18 @@ def stage_mark(name):
         STAGES.mark(name)
 
 
-def _conv_launch(kind, is2d, g, call):
+def _conv_launch(kind, is2d, g, call, flops=None):
+    """``flops``: algorithmic FLOPs of the launch when they are not the geometry's ``2*M*Cout*ntaps*Cin`` (an input-gradient
+    class of a valid-correlation layer: the tap table spans input positions no output position reaches; SURVEY.md 8d counts
+    dX = forward)."""
     if PROFILER is None:
         check(call())
         return
     lib = _lib.load()
     var = lib.sdt_conv_dw_variant(g) if kind == "dW" else lib.sdt_conv_taps_variant(g)
     m = g.B * g.Ho * g.Wo
-    flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
+    if flops is None:
+        flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
     # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, fp32
     nbytes = 4.0 * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
     e0, e1 = PROFILER.event(), PROFILER.event()
@@ -364,15 +370,18 @@ def _conv_launch(kind, is2d, g, call):
     PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
-def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0):
+def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=None):
     """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient); ``extra_bytes``:
-    what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics)"""
+    what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics);
+    ``flops``: the algorithmic FLOPs (input gradients pass the FORWARD layer's count, SURVEY.md 8d -- the classes' tap tables
+    also cover (position, tap) pairs that fall outside the forward output, which the kernel culls and nobody should count)"""
     if PROFILER is None:
         check(call())
         return
     lib = _lib.load()
     var = lib.sdt_conv_taps_variant(gs[0])
-    flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for g in gs)
+    if flops is None:
+        flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for g in gs)
     g0 = gs[0]
     nbytes = 4.0 * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin) + extra_bytes
     e0, e1 = PROFILER.event(), PROFILER.event()
@@ -543,6 +552,8 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
     Cout = w.shape[0]
     kh, kw = _ksize(w)
     st = _stream()
+    # algorithmic work of an input gradient = the forward layer's: 2 * B*Ho*Wo * Cout * taps * Cin
+    fwd_flops = 2.0 * B * (1 if one_d else out_size(Hi, kh, stride, pad)) * out_size(Wi, kw, stride, pad) * Cout * kh * kw * Cin
     wt = WeightMirrors.lookup(w)
     if wt is None:
         ws = weight_storage(w)
@@ -565,7 +576,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
             _conv_launch_multi("dX", True, gs,
                                lambda: lib.sdt_conv_taps_pre_f32(_p(gy_planes), gy_planes.shape[1], _p(wpl[1]), wpl[1].shape[1], _p(dx),
                                                                  arr, n, None, 0, nb, st), pre=True,
-                               extra_bytes=4.0 * dx.numel() if nb is not None else 0.0)
+                               extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops)
             return dx
     pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
     if pack is not None:
@@ -581,7 +592,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
             nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
         _conv_launch_multi("dX", not one_d, gs,
                            lambda: lib.sdt_conv_taps_multi_f32(_p(gy4), _p(wt), _p(dx), arr, n, k, _p(part), nb, st),
-                           extra_bytes=4.0 * dx.numel() if nb is not None else 0.0)
+                           extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops)
         if k > 1:
             check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
         return dx.squeeze(1) if one_d else dx
@@ -594,8 +605,9 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
         if g is None:  # parity class that no tap reaches: the gradient is zero there
             dx[:, py::(1 if one_d else stride), px::stride].zero_()
             continue
+        nlive = sum(1 for gg, _ in geoms if gg is not None)
         _conv_launch("dX", not one_d, g,
-                     lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), st))
+                     lambda g=g: lib.sdt_conv_taps_splitk_f32(_p(gy4), _p(wt), None, _p(dx), g, k, _p(part), st), flops=fwd_flops / nlive)
     if k > 1:  # every dX element belongs to exactly one parity class, so each slab is fully written
         check(lib.sdt_splitk_reduce_f32(_p(part), None, _p(dx), dx.numel(), Cin, k, st))
     return dx.squeeze(1) if one_d else dx

@@ -385,3 +385,109 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
             e_hip = {k.split("Dstep:")[1]: _sample_err(sl(params[k.split("Dstep:")[1]].grad)[:64], g64[k][:64]) for k in keys}
             e_ref = {k.split("Dstep:")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
             _check_grad_distributions(title + " (discriminator step)", e_hip, e_ref, k_med=5.0, k_max=5.0, anchor=1.0)
+
+
+def _stage_err(a, ref):
+    """(max|a-ref| / max|ref|, rms(a-ref) / rms(ref)) against a float64 reference"""
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    d = a - ref
+    return (d.abs().max() / ref.abs().max()).item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def test_b32_forward_stage_error_table():
+    """Where does the forward error come from?  (the HIP prediction was 2.6x further from float64 than the fp32
+    reference's and nobody had localised it.)  Every stage of the sdt_bp generator runs ALONE on the same fp32 input -- the float64
+    chain's activations rounded to fp32 -- on the HIP path and on the fp32 oracle, and both are compared with the float64 stage on
+    that input; then the same for the cumulative chain (each implementation feeding itself).  Errors as max-norm and as RMS.
+    The bar: no isolated stage more than K_STAGE x the fp32 reference's RMS error (+ a floor of 2e-8: one stage of the
+    reference can be exact by luck), the whole chain within K_FWD."""
+    from speechdrivestemplates_amd import ops
+    from speechdrivestemplates_amd.core.networks import get_model
+    K_STAGE = 2.0
+    B, cfg_name = 32, "voice2pose_sdt_bp"
+    ocfg = O.cfg_named(cfg_name)
+    state = O.make_voice2pose_state(ocfg, N_CLIPS, seed=0, code_std=0.5)
+    batch = O.make_batch(B, N_CLIPS, step=3, seed=11)
+    st64 = {k: (v.detach().double() if v.is_floating_point() else v) for k, v in state.items()}
+    st32 = {k: v.detach() for k, v in state.items()}
+    net = get_model("SequenceGeneratorCNN")(ocfg)
+    net.load_state_dict({k[len("netG."):]: v.clone() for k, v in state.items() if k.startswith("netG.")}, strict=True)
+    net.to(DEV).train()
+    g = ocfg.VOICE2POSE.GENERATOR
+    code32 = state["clips_code"][batch["clip_index"]].detach()
+    rows = []  # (stage, hip_max, hip_rms, ref_max, ref_rms)
+
+    def cl(x):  # logical channels-first -> channels-last on the device
+        return ops.cl(x.to(DEV))
+
+    def cf(x_cl):
+        return ops.cf_view(x_cl).detach().cpu()
+
+    with torch.no_grad():
+        # ---- isolated stages on identical fp32 inputs (the float64 chain's activations, rounded)
+        mel64 = O.mel_spectrogram(batch["audio"].double(), O.mel_window(torch.float64), O.mel_filterbank(torch.float64))
+        from speechdrivestemplates_amd.mel import MelSpectrogram
+        melT = MelSpectrogram().to(DEV)
+        rows.append(("mel (unpinned oracle)",) + _stage_err(melT(batch["audio"].to(DEV)).cpu(), mel64) + _stage_err(O.mel_spectrogram(batch["audio"]), mel64))
+        x64 = mel64.unsqueeze(1)
+        for i, (_, _, _, s, p) in enumerate(O.AUDIO_ENCODER_2D):
+            pre = "netG.audio_encoder.specgram_encoder_2d.%d.%d" % (i // 2, i % 2)
+            xin = x64.float()
+            ref64 = O.conv_norm_act(xin.double(), st64, pre, s, p, g.NORM, g.LEAKY_RELU, True)
+            ref32 = O.conv_norm_act(xin, st32, pre, s, p, g.NORM, g.LEAKY_RELU, True)
+            blk = net.audio_encoder.specgram_encoder_2d[i // 2][i % 2]
+            hip = cf(blk.forward_cl(cl(xin) if i else xin.squeeze(1).unsqueeze(-1).to(DEV)))
+            rows.append(("enc2d L%d alone" % i,) + _stage_err(hip, ref64) + _stage_err(ref32, ref64))
+            x64 = ref64
+        xin = x64.float()
+        r64 = torch.cat([F.interpolate(xin.double(), (1, 64), mode="bilinear").squeeze(2), code32.double().unsqueeze(2).repeat(1, 1, 64)], 1)
+        r32 = torch.cat([F.interpolate(xin, (1, 64), mode="bilinear").squeeze(2), code32.unsqueeze(2).repeat(1, 1, 64)], 1)
+        hip = ops.ResizeConcatFn.apply(cl(xin), code32.to(DEV), 64)
+        rows.append(("resize + code concat alone",) + _stage_err(cf(hip), r64) + _stage_err(r32, r64))
+        xin = r64.float()
+        u64 = O.unet_1d(st64, "netG.unet", xin.double(), g.NORM, g.LEAKY_RELU, True)
+        u32 = O.unet_1d(st32, "netG.unet", xin, g.NORM, g.LEAKY_RELU, True)
+        rows.append(("U-Net (12 Conv1d blocks) alone",) + _stage_err(cf(net.unet.forward_cl(cl(xin))), u64) + _stage_err(u32, u64))
+        e64 = O._block1d(xin.double(), st64, "netG.unet.e0", False, g.NORM, g.LEAKY_RELU, True)
+        e32 = O._block1d(xin, st32, "netG.unet.e0", False, g.NORM, g.LEAKY_RELU, True)
+        rows.append(("  U-Net e0 (k3, Cin 288) alone",) + _stage_err(cf(net.unet.e0.forward_cl(cl(xin))), e64) + _stage_err(e32, e64))
+        xin = u64.float()
+
+        def dec(st, x):
+            for j in range(4):
+                x = O._block1d(x, st, "netG.decoder.%d" % j, False, g.NORM, g.LEAKY_RELU, True)
+            return F.conv1d(x, st["netG.decoder.4.weight"], st["netG.decoder.4.bias"])
+
+        from speechdrivestemplates_amd.core.networks.building_blocks import conv_head
+        h = cl(xin)
+        for blk in list(net.decoder)[:4]:
+            h = blk.forward_cl(h)
+        h = conv_head(h, net.decoder[4])
+        d64 = dec(st64, xin.double())
+        rows.append(("decoder (4 blocks + head) alone",) + _stage_err(cf(h), d64) + _stage_err(dec(st32, xin), d64))
+        # ---- the cumulative chain, every implementation feeding itself from the same fp32 mel (the float64 mel, rounded)
+        mel32 = mel64.float()
+        p64 = O.generator(st64, "netG", mel32.double(), 64, code32.double(), ocfg, True)
+        p32 = O.generator(st32, "netG", mel32, 64, code32, ocfg, True)
+        ph = net(mel32.to(DEV), 64, code32.to(DEV)).cpu()
+        x64c, x32c = mel32.double().unsqueeze(1), mel32.unsqueeze(1)
+        xh = mel32.unsqueeze(-1).to(DEV)
+        for i, (_, _, _, s, p) in enumerate(O.AUDIO_ENCODER_2D):
+            pre = "netG.audio_encoder.specgram_encoder_2d.%d.%d" % (i // 2, i % 2)
+            x64c = O.conv_norm_act(x64c, st64, pre, s, p, g.NORM, g.LEAKY_RELU, True)
+            x32c = O.conv_norm_act(x32c, st32, pre, s, p, g.NORM, g.LEAKY_RELU, True)
+            xh = net.audio_encoder.specgram_encoder_2d[i // 2][i % 2].forward_cl(xh)
+            rows.append(("chain after enc2d L%d" % i,) + _stage_err(cf(xh), x64c) + _stage_err(x32c, x64c))
+        rows.append(("chain: prediction",) + _stage_err(ph, p64) + _stage_err(p32, p64))
+    torch.cuda.synchronize()
+    lines = ["voice2pose_sdt_bp B=32 generator forward, per stage vs float64 (max-norm | rms), HIP and the fp32 oracle on identical inputs:"]
+    bad = []
+    for name, hm, hr, rm, rr in rows:
+        lines.append("      %-34s hip %.3e | %.3e   ref32 %.3e | %.3e   ratio max %5.2f  rms %5.2f" % (name, hm, hr, rm, rr, hm / max(rm, 1e-30), hr / max(rr, 1e-30)))
+        if "alone" in name and hr > K_STAGE * rr + 2e-8:
+            bad.append((name, hr, rr))
+        if name == "chain: prediction" and hm > K_FWD * rm + 2e-7:
+            bad.append((name, hm, rm))
+    _dump(lines)
+    assert not bad, bad
