@@ -56,7 +56,7 @@ extern "C" int sdt_debug_set_timeline(void* p) {
 }
 #define SDT_TL(slot)                                                                                                   \
     do {                                                                                                               \
-        if constexpr (PRIO == 30) {                                                                                    \
+        if constexpr (PRIO >= 30 && PRIO < 40) {                                                                       \
             if (threadIdx.x == 0 && sdt_dbg_tl != nullptr)                                                             \
                 sdt_dbg_tl[8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + (slot)] = wall_clock64(); \
         }                                                                                                              \
@@ -118,9 +118,12 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     // (measured before this ordering: L2-miss traffic 9-16x the input bytes on the Cout=256 layers).
     const int nnb = (g.Cout + BN - 1) / BN;
     if ((int)blockIdx.x >= nmb * nnb) return;  // the grid is sized for the largest class of the launch
+    // experiments 31 / 32: waves outside the K loop (prologue, epilogue) issue at raised priority -- the youngest wave of a SIMD
+    // otherwise loses every VALU / LDS / memory issue slot to the older waves' MFMAs (timeline: prologue 6 us alone, 30 us loaded)
+    if constexpr (PRIO == 31 || PRIO == 32) __builtin_amdgcn_s_setprio(3);
     SDT_TL(0);
 #ifdef SDT_TUNING
-    if constexpr (PRIO == 30) {
+    if constexpr (PRIO >= 30 && PRIO < 40) {
         if (threadIdx.x == 0 && sdt_dbg_tl != nullptr)
             sdt_dbg_tl[8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 5] =
                 (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
     SDT_TL(1);
     if (step0 < nsteps) load(step0);
     for (int step = step0; step < nsteps; ++step) {
+        if constexpr (PRIO == 32 || PRIO == 33) __builtin_amdgcn_s_setprio(2);  // feeding part of a K step above the MFMA bursts
         if (!(PRIO == 7 || PRIO == 8 || PRIO == 9) || step == step0) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * LDP + kv * 4] = ra[i];
@@ -427,6 +431,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         }
         // K order inside the 32-wide tile is permuted identically for A and B: MFMA k-slot h=lane>>5 of
         // sub-step (j,e) consumes k = 8j + 4h + e, so each lane feeds 4 MFMAs from one ds_read_b128.
+        if constexpr (PRIO == 31 || PRIO == 32 || PRIO == 33) __builtin_amdgcn_s_setprio(0);
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     }
+    if constexpr (PRIO == 31 || PRIO == 32) __builtin_amdgcn_s_setprio(3);
     SDT_TL(3);  // K loop done
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (splitk > 1) {
@@ -1413,6 +1419,9 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
     else if (vec4 && prio == 16) SDT_TAPS(16);  // A/B: tap culling also on launches with <= 4 taps
     else if (vec4 && prio == 20) SDT_TAPS(20);  // experiment: double-buffered LDS, one barrier per K step
     else if (vec4 && prio == 30) SDT_TAPS(30);  // per-workgroup timeline stamps (tools/debug/taps_timeline.py)
+    else if (vec4 && prio == 31) SDT_TAPS(31);  // experiment: prologue / epilogue at priority 3
+    else if (vec4 && prio == 32) SDT_TAPS(32);  // experiment: 31 + the feeding part of every K step at priority 2
+    else if (vec4 && prio == 33) SDT_TAPS(33);  // experiment: only the feeding part of every K step at priority 2
     else
 #endif
     if (vec4)
