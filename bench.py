@@ -194,6 +194,8 @@ def main(argv=None):
     ap.add_argument("--fused-conv1d", action="store_true",
                     help="run the generator's Conv1d stage as one launch per layer and direction (csrc/conv1d.hip; measured 2 %% slower "
                          "end to end, profiles/r02_conv1d_stage.txt)")
+    ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
+    ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
 
@@ -240,6 +242,10 @@ def main(argv=None):
         from __graft_entry__ import make_pipeline
         from speechdrivestemplates_amd import ops
         ops.OVERLAP_DW = not args.no_overlap_dw
+        ops.USE_STREAMK = not args.no_streamk
+        if args.streamk_min_steps is not None:
+            ops.STREAMK_MIN_STEPS = args.streamk_min_steps
+            ops.STREAMK_MIN_COUT = 64
         ops.DEFER_SMALL_DW = not args.no_defer_dw
         ops.DETERMINISTIC_DW = bool(args.deterministic_dw)
         if args.fused_conv1d:

@@ -85,6 +85,34 @@ typedef struct sdt_norm_bwd {
 } sdt_norm_bwd;
 int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_conv_geom* geoms, int ncls, int splitk,
                             float* partial, const sdt_norm_bwd* nb, void* stream);
+/*
+ * Persistent stream-K form of the same convolution (csrc/convsk.hip; round 3) for the MFMA-bound Conv2d launches of the audio
+ * encoder (generator.py:15-30 through building_blocks.py:15-22): forward (ncls = 1) or input gradient (ncls parity classes) with
+ * Cin % 32 == 0 and Cout % 64 == 0.  One workgroup per CU walks a contiguous range of the launch's (tile, live K step) list, so every
+ * CU gets the same number of K steps whatever the tile count; tiles that straddle two ranges are combined in a fixed order
+ * (bit-identical from run to run).  128x128x32 or 256x64x32 tiles, software-pipelined, fp32 accumulation in chunks of 256 products.
+ *   sdt_convsk_supported     1 if the geometry pack qualifies
+ *   sdt_convsk_plan_bytes    size of the PLAN of a geometry pack: per GEMM row {X byte offset, iy0 | ix0 << 16, Y element offset,
+ *                            statistics group}, per m-tile {live-tap mask, tap rotation}, prefix sums of live K steps, first tile of
+ *                            each workgroup's range.  Built on the host once per geometry (sdt_convsk_plan_build), kept by the caller
+ *                            in host AND device memory and handed to every launch
+ *   rows_per_group > 0       statistics group of output row m = m / rows_per_group (forward statistics, as sdt_conv_taps_stats_f32);
+ *   rows_per_group <= 0      group = batch item (bwd_groups == B) or 0 (bwd_groups == 1) (backward statistics, as sdt_norm_bwd)
+ *   sdt_convsk_workspace_bytes  partial-tile slabs + flags: one buffer per stream, ZERO-FILLED ONCE by the caller, then passed to every
+ *                            launch on that stream with a strictly increasing epoch (>= 1); the word after the flags is an error code
+ *                            (non-zero: a wait for a partial tile gave up -- cannot happen while the launch's workgroups are resident)
+ *   sdt_convsk_f32           the launch; stats / nb as in sdt_conv_taps_stats_f32 / sdt_conv_taps_multi_f32 (at most one of them);
+ *                            xbytes / wbytes / ybytes: sizes of the X, W and Y tensors
+ */
+int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls);
+int sdt_convsk_grid(void);
+int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for plans built afterwards (default 2) */
+int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls);
+int64_t sdt_convsk_workspace_bytes(void);
+int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes);
+int sdt_convsk_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
+                   void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nb, int64_t xbytes, int64_t wbytes, int64_t ybytes,
+                   void* stream);
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);

@@ -99,6 +99,11 @@ SIGNATURES = {
     "sdt_time_diff_bwd_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_clip_poses_prepare_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sdt_rows_gather_f32": [_p, _p, _p, _i, _i, _i64, _p],
+    "sdt_convsk_supported": [_G, _i],
+    "sdt_convsk_grid": [],
+    "sdt_convsk_set_wg_per_cu": [_i],
+    "sdt_convsk_plan_build": [_G, _i, _i, _i, _p, _i64],
+    "sdt_convsk_f32": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
 }
 
 _lib = None
@@ -137,6 +142,17 @@ def load():
         fn.restype = C.c_int
     lib.sdt_conv_dw_workspace_bytes.argtypes = [_G]
     lib.sdt_conv_dw_workspace_bytes.restype = C.c_int64
+    lib.sdt_convsk_plan_bytes.argtypes = [_G, _i]
+    lib.sdt_convsk_plan_bytes.restype = C.c_int64
+    if hasattr(lib, "sdt_convtab_f32"):  # the -DSDT_TUNING build only (experiment: the 64x64 kernel driven by a plan)
+        lib.sdt_convtab_plan_bytes.argtypes = [_G, _i]
+        lib.sdt_convtab_plan_bytes.restype = C.c_int64
+        for name, at in (("sdt_convtab_supported", [_G, _i]), ("sdt_convtab_plan_build", [_G, _i, _i, _i, _p, _i64]),
+                         ("sdt_convtab_f32", [_p, _p, _p, _p, _p, _p, _p, C.POINTER(NormBwd), _i, _i64, _i64, _i64, _p])):
+            getattr(lib, name).argtypes = at
+            getattr(lib, name).restype = C.c_int
+    lib.sdt_convsk_workspace_bytes.argtypes = []
+    lib.sdt_convsk_workspace_bytes.restype = C.c_int64
     lib.sdt_last_error.restype = C.c_char_p
     lib.sdt_abi_version.restype = C.c_int
     lib.sdt_get_conv_math.restype = C.c_int

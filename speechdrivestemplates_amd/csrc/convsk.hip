@@ -1,0 +1,926 @@
+// Persistent stream-K implicit-GEMM convolution for gfx950 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the Conv2d forward and
+// input-gradient launches of the audio encoder (building_blocks.py:15-22; generator.py:15-30), round 3.
+//
+// Why a second conv kernel.  profiles/r03_mfma_pipe_microbench.txt / r03_taps_timeline_64x64.txt: the 64x64-tile kernel of conv.hip keeps
+// 7 workgroups per CU resident, but under load a workgroup spends 30 us of its 120 us life in a prologue that takes 6 us alone (and 9 us in
+// the epilogue): only ~3.5 of the 7 waves of a SIMD are in their K loop, the matrix pipe is 73-80 % busy, and layers with 1060 tiles put
+// 5 workgroups on 36 CUs and 4 on the rest (17 % tail).  The same K loop WITHOUT prologue / epilogue / quantisation sustains 0.95 of the
+// peak -- and one wave per SIMD on a 128x128 tile with the feeding instructions interleaved between its own MFMAs sustains 0.91.
+//
+// Design.
+//   * grid = one workgroup (4 waves, 2x2) per CU slot, G = 256 * R workgroups, R = 1.  The launch's work is the list of (tile, live K step)
+//     pairs in tile order; workgroup r owns the contiguous range [r*S/G, (r+1)*S/G) of that list (stream-K): every CU gets the same
+//     number of K steps whatever the tile count, tap culling included (the host counts LIVE steps per tile).
+//   * a tile that straddles a range boundary is finished by the workgroup that owns its first step: the others store their partial
+//     accumulators write-through into a slab, drain, and raise a flag; the owner -- which reaches that tile at the END of its range, when
+//     the others (who meet it at the START of theirs) are long done -- polls the flags, adds the slabs in range order and runs the
+//     epilogue.  Fixed split points, fixed order: bit-identical from run to run.  (MI355X_MICROARCH.md, Guideline 16 recipe R1.)
+//   * tile 128x128x32 (wave tile 64x64 = 2x2 accumulators) or 256x64x32 (N = 64 layers; wave tile 128x32); two LDS buffers, ONE barrier
+//     per K step; tile s+1 goes registers -> LDS[next] and the global loads of tile s+2 are issued BETWEEN the MFMAs of tile s
+//     (sched_group_barrier), so the in-order wave overlaps its own feeding with its own MFMAs.
+//   * no index arithmetic in the kernel: the host builds a PLAN per geometry pack (sdt_convsk_plan_*): per GEMM row {byte offset of the
+//     row's (0,0) tap in X, mask of the taps that fall outside X for this row, byte offset of the output row in Y}, per m-tile {live-tap mask, first tap of the
+//     residue-rotated order}, prefix sums of live steps per tile, first tile of every range.
+//   * fp32 accumulation in CHUNKS of 8 K steps (256 products): a chunk starts from C = 0 and is added to the running total when it
+//     ends.  A K-long single accumulator made the HIP forward 2-3.8x further from float64 than the blocked sums of the CPU reference
+//     (profiles/r03_stage_errors_before.txt: the error grew with sqrt(K)); chunking brings it level.
+#include <type_traits>
+
+#include "common.h"
+
+#define SK_BK 32
+#define SK_LDP 36
+#define SK_MAXC 4
+#define SK_OOB 0x80000000u
+#define SK_CHUNK 8  // K steps per accumulation chunk (256 products)
+
+struct sk_class {
+    int Hi, Wi, Cin, Cout, ntaps, nkc;
+    int tile_begin, nmb, row_begin, mt_begin;
+    int Tw;
+    int ashift[SDT_MAX_TAPS];  // ((dy * Wi + dx) * Cin) * 4
+    int dyx[SDT_MAX_TAPS];     // (dy & 0xffff) | (dx << 16)
+    int bshift[SDT_MAX_TAPS];  // wt * Cin * 4
+};
+
+struct sk_args {
+    sk_class cls[SK_MAXC];
+    int ncls, nnb, T, G;
+    int S;                  // total live K steps of the launch
+    unsigned xbytes, wbytes, ybytes;
+    const int4* rowinfo;    // [rows padded to BM per class]
+    const int2* tileinfo;   // [m-tiles of all classes] {live-tap mask rotated by rot, rot}
+    const int* tilecum;     // [T + 1]
+    const int* range_tile;  // [G] first tile of each range
+    float* slabs;           // [G][BM * BN]
+    unsigned* flags;        // [G]
+    unsigned epoch;
+    unsigned* err;          // set to a non-zero code when a spin gives up
+};
+
+struct sk_norm_bwd {
+    const float* y;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    double* sums;
+    float slope;
+    int groups;
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+#define SK_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#ifdef SDT_TUNING
+// tools/debug/sk_timeline.py: lane 0 of every workgroup stamps the 100 MHz real-time counter at five points of each of its first 16
+// tile segments: sk_dbg_tl[(range * 16 + segment) * 8 + slot], slot 5 = K steps of the segment, 6 = kind (0 whole, 1 owner, 2 publish)
+__device__ unsigned long long* sk_dbg_tl = nullptr;
+extern "C" int sdt_debug_set_timeline_sk(void* p) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sk_dbg_tl), &p, sizeof(p));
+    return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
+}
+#define SK_TL(slot, val)                                                                              \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && sk_dbg_tl != nullptr && seg < 16) sk_dbg_tl[((size_t)r * 16 + seg) * 8 + (slot)] = (val); \
+    } while (0)
+#else
+#define SK_TL(slot, val) do { } while (0)
+#endif
+
+// Epilogue of a finished output tile held in TM x TN accumulators per wave (2x2 wave grid): branch-free buffer stores (+ bias) and,
+// for EPI 1 / 2, the per-(group, channel) statistics.  sOut / sGrp: LDS, [BM] byte offset of each tile row in Y (SK_OOB: none) and its
+// statistics group.  C/D layout of a 32x32 accumulator: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).
+template <int BM, int BN, int EPI, int TMB = 0, int TME = BM / 64>
+__device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], const int* sOut, const int* sGrp, const int n0, const int wm,
+                                            const int wn, const int lane, const float* __restrict__ bias, const __amdgpu_buffer_rsrc_t rsY,
+                                            const int Cout, double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes) {
+    constexpr int TN = BN / 64;  // accumulator rows TMB .. TME-1 of the wave (the callers interleave other work between halves)
+#pragma unroll
+    for (int tm = TMB; tm < TME; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+            const float bv = bias != nullptr ? bias[n] : 0.f;
+            // branch-free stores: the four rows (q & 3) of a register quad are consecutive tile rows -> one 16-byte LDS read
+            // gives their byte offsets; rows past the end of the tensor carry SK_OOB and the hardware drops the store
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int4 o4 = *(const int4*)&sOut[wm * (BM / 2) + tm * 32 + 8 * qq + 4 * (lane >> 5)];
+                const unsigned nb4 = (unsigned)n * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 0] + bv), rsY, (int)((unsigned)o4.x + nb4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 1] + bv), rsY, (int)((unsigned)o4.y + nb4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 2] + bv), rsY, (int)((unsigned)o4.z + nb4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 3] + bv), rsY, (int)((unsigned)o4.w + nb4), 0, 0);
+            }
+            if constexpr (EPI == 1 || EPI == 2) {
+                // statistics over the rows of this 32-row block: its rows belong to at most two groups (groups ascend with the
+                // row; host-checked: a group spans >= 32 rows).  EPI 1: sum / sum of squares of the conv output (forward
+                // normalisation statistics); EPI 2: sum gg / sum gg*yhat of the normalisation backward that consumes dX
+                const int rb0 = wm * (BM / 2) + tm * 32;
+                const int gfirst = sGrp[rb0], glast = sGrp[rb0 + 31];
+                const bool two = glast != gfirst && glast >= 0;
+                float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f;
+                __amdgpu_buffer_rsrc_t rsNY = rsY;
+                if constexpr (EPI == 2) {
+                    rsNY = __builtin_amdgcn_make_buffer_rsrc((void*)nb.y, 0, (int)ybytes, 0x00020000);
+                    if (gfirst >= 0) {
+                        mu0 = nb.mean[(size_t)gfirst * Cout + n];
+                        rs0 = nb.rstd[(size_t)gfirst * Cout + n];
+                    }
+                    if (two) {
+                        mu1 = nb.mean[(size_t)glast * Cout + n];
+                        rs1 = nb.rstd[(size_t)glast * Cout + n];
+                    }
+                    if (nb.gamma != nullptr) ga = nb.gamma[n];
+                    if (nb.beta != nullptr) be = nb.beta[n];
+                }
+                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int4 o4 = *(const int4*)&sOut[rb0 + 8 * qq + 4 * (lane >> 5)];
+                    const int4 g4 = *(const int4*)&sGrp[rb0 + 8 * qq + 4 * (lane >> 5)];
+                    const int offs[4] = {o4.x, o4.y, o4.z, o4.w}, grps[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool valid = offs[e] >= 0, second = grps[e] != gfirst;
+                        float u, v;  // accumulate (u, u*v') pairs: EPI 1 (v, v*v), EPI 2 (gg, gg*yhat)
+                        if constexpr (EPI == 1) {
+                            u = valid ? tot[tm][tn][4 * qq + e] + bv : 0.f;
+                            v = u;
+                        } else {
+                            const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + (unsigned)n * 4u), 0, 0));
+                            v = (yv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
+                            u = valid ? tot[tm][tn][4 * qq + e] * act_grad(v * ga + be, nb.slope) : 0.f;
+                        }
+                        if (!second) {
+                            s0 += u;
+                            q0 = fmaf(u, v, q0);
+                        } else {
+                            s1 += u;
+                            q1 = fmaf(u, v, q1);
+                        }
+                    }
+                }
+                s0 += __shfl_xor(s0, 32, 64);  // the two lane halves hold different rows of the same column
+                q0 += __shfl_xor(q0, 32, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                q1 += __shfl_xor(q1, 32, 64);
+                double* acc_out = EPI == 1 ? stats : nb.sums;
+                if (lane < 32 && gfirst >= 0) {
+                    double* d = acc_out + ((size_t)gfirst * Cout + n) * 2;
+                    atomicAdd(d, (double)s0);
+                    atomicAdd(d + 1, (double)q0);
+                    if (two) {
+                        double* d1 = acc_out + ((size_t)glast * Cout + n) * 2;
+                        atomicAdd(d1, (double)s1);
+                        atomicAdd(d1 + 1, (double)q1);
+                    }
+                }
+            }
+        }
+}
+
+// EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
+template <int BM, int BN, int EPI, int WPC>
+__global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     float* __restrict__ Y, const sk_args P, double* __restrict__ stats,
+                                                     const int rows_per_group, const sk_norm_bwd nb) {
+    constexpr int TM = BM / 64, TN = BN / 64, RA = BM / 32, RB = BN / 32, NM = TM * TN * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                          // [2][BM * LDP]
+    float* sB = smem + 2 * BM * SK_LDP;        // [2][BN * LDP]
+    int* sOut = (int*)(sB + 2 * BN * SK_LDP);  // [BM] byte offset of the tile's output rows in Y (SK_OOB, negative as int: none)
+    int* sGrp = sOut + BM;                     // [BM] statistics group of each row (EPI 1 / 2)
+    int* sFlagOkp = sGrp + BM;                 // [4] (no static __shared__: it would shift the 16-byte alignment of the dynamic region)
+#define sFlagOk (sFlagOkp[0])
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kv = tid & 7, r0 = tid >> 3;
+    const int G = P.G;
+    // workgroup -> range: blocks that land on one XCD (id % 8) own consecutive ranges, i.e. consecutive tiles (shared L2)
+    const int bid = blockIdx.x;
+    const int r = (bid & 7) * (G >> 3) + (bid >> 3);  // G % 8 == 0
+    const int s_begin = (int)((long)r * P.S / G), s_end = (int)((long)(r + 1) * P.S / G);
+    if (s_end <= s_begin) return;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)P.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)P.ybytes, 0x00020000);
+
+    // fragment read offsets (floats) inside an LDS tile
+    const int fa = (wm * (BM / 2) + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    const int fb = (wn * (BN / 2) + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    const int wofs = r0 * SK_LDP + kv * 4;  // loader thread's position in an LDS tile (+ 32 * i rows)
+
+    // ---- the walk over the range's tiles: (tile, class c, m-tile mt, n-tile nt), `pos` = next step of the launch's list to do
+    int tile = __builtin_amdgcn_readfirstlane(P.range_tile[r]);
+    int pos = s_begin;
+    int c = 0;
+    while (c + 1 < P.ncls && tile >= P.cls[c + 1].tile_begin) ++c;
+    int mt = (tile - P.cls[c].tile_begin) / P.nnb;
+    int nt = (tile - P.cls[c].tile_begin) - mt * P.nnb;
+
+    // ------------------------------------------------------------------ per tile: set-up, pipeline fill, K loop, end phase.
+    // (Issuing the next tile's set-up reads and first K steps under the stores of the finished tile was built and measured: it helps
+    // the 128x64 instantiations by 2-4 % but pushes the 128x128 ones past 256 registers -- two workgroups per CU -- and the spills of
+    // the end phase cost 10-15 %; with two workgroups per CU the partner covers most of a tile switch anyway.)
+    for (int seg = 0;; ++seg) {
+        // ------------------------------------------------------------------ tile set-up (all state of a tile is local to this
+        // iteration: hoisting it out of the loop made the register allocator spill inside the chunk loop, -25 %)
+        SK_TL(0, wall_clock64());
+        const sk_class& cl = P.cls[c];
+        const int nkc = __builtin_amdgcn_readfirstlane(cl.nkc), Cout = __builtin_amdgcn_readfirstlane(cl.Cout);
+        const int ntaps = __builtin_amdgcn_readfirstlane(cl.ntaps);
+        const int tbeg = __builtin_amdgcn_readfirstlane(P.tilecum[tile]), tend = __builtin_amdgcn_readfirstlane(P.tilecum[tile + 1]);
+        const int a = pos - tbeg, b = min(s_end, tend) - tbeg;  // this workgroup does live steps [a, b) of the tile
+        int2 ti = P.tileinfo[cl.mt_begin + mt];
+        const int m0 = cl.row_begin + mt * BM, n0 = nt * BN;
+        // tap tables of the class: lane t holds tap t
+        const int v_ash = lane < SDT_MAX_TAPS ? cl.ashift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
+        const int v_bsh = lane < SDT_MAX_TAPS ? cl.bshift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
+        unsigned abase[RA], bbase[RB], inval[RA];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int2 ri = ((const int2*)P.rowinfo)[2 * (m0 + r0 + 32 * i)];  // {X byte offset, invalid-tap mask}
+            abase[i] = (unsigned)ri.x + (unsigned)kv * 16u;
+            inval[i] = (unsigned)ri.y;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((n0 + r0 + 32 * i) * cl.Tw * cl.Cin) * 4u + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
+        if (tid < BM) {
+            const int2 ro = ((const int2*)P.rowinfo)[2 * (m0 + tid) + 1];  // {Y byte offset, statistics group}
+            sOut[tid] = ro.x;
+            sGrp[tid] = ro.y;
+        }
+        // live taps in residue-rotated order: bit i of the (host-rotated) mask is tap (rot + i) mod ntaps; a K step is (lowest set
+        // bit, kc).  Everything in the loader is wave-uniform and branch-free (scalar selects): the steady loop stays ONE basic block.
+        unsigned rmask = (unsigned)__builtin_amdgcn_readfirstlane(ti.x);
+        const int rot = __builtin_amdgcn_readfirstlane(ti.y);
+        for (int skip = a / nkc; skip > 0; --skip) rmask &= rmask - 1;  // start inside the tile
+        int kc = a - (a / nkc) * nkc;
+        int left = b - a;  // steps the loader still has to fetch
+        f32x4 ra[RA], rb[RB];
+        auto load = [&]() {
+            // offsets of the step at (tap, kc); past the end of the segment everything is masked (loads return zeros)
+            const bool on = left > 0 && rmask != 0u;
+            int t = (rmask != 0u ? __builtin_ctz(rmask) : 0) + rot;
+            t = t >= ntaps ? t - ntaps : t;
+            t = on ? t : 0;
+            const int ash = __builtin_amdgcn_readlane(v_ash, t), bsh = __builtin_amdgcn_readlane(v_bsh, t);
+            const int cs = kc * (SK_BK * 4);
+            // the row's invalid-tap bit moves to bit 31 of the offset: out of range, the load returns zeros.  Loader off: shift 0
+            // brings the always-set bit 31 there
+            const int sh = on ? 31 - t : 0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const unsigned o = ((abase[i] + (unsigned)ash) & 0x7fffffffu) | ((inval[i] << sh) & 0x80000000u);
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, cs, 0));
+            }
+            const unsigned bsh_eff = (unsigned)bsh + (on ? 0u : SK_OOB);  // bbase + bshift < 2^31: adding the top bit pushes it out of range
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i] + bsh_eff), cs, 0));
+            // advance (scalar selects)
+            --left;
+            const bool wrap = kc + 1 == nkc;
+            kc = wrap ? 0 : kc + 1;
+            rmask = wrap ? (rmask & (rmask - 1u)) : rmask;
+        };
+        auto stage = [&](int buf) {
+            float* wA = sA + buf * BM * SK_LDP + wofs;
+            float* wB = sB + buf * BN * SK_LDP + wofs;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *(f32x4*)&wA[32 * i * SK_LDP] = ra[i];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *(f32x4*)&wB[32 * i * SK_LDP] = rb[i];
+        };
+
+        f32x16 acc[1][TM][TN], tot[TM][TN];
+        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+#define SK_READ(A, B, PA, PB, J)                                                                                        \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = *(const f32x4*)((PA) + tm * 32 * SK_LDP + (J) * 8);       \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) B[tn] = *(const f32x4*)((PB) + tn * 32 * SK_LDP + (J) * 8)
+#define SK_MFMA(SET, A, B)                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                     \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                               \
+            acc[SET][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], B[tn][e], acc[SET][tm][tn], 0, 0, 0)
+
+        // one K step (ONE instance in the kernel: variants of this body for the first step of an accumulation chunk doubled the
+        // loop nest and made the register allocator spill around the chunk loop of the 128x128 / two-workgroups-per-CU kernels)
+        auto step = [&](const int cur) {
+            constexpr int SET = 0;
+            const float* pa = sA + cur * BM * SK_LDP + fa;
+            const float* pb = sB + cur * BN * SK_LDP + fb;
+            // k-group 0: its MFMAs + fragments of k-group 1 + registers (step+1) -> LDS[next] + the global loads of step+2 (re-filling
+            // the registers just staged: issued as early as possible, a full step before they are needed)
+            SK_READ(a1, b1, pa, pb, 1);
+            stage(cur ^ 1);
+            load();
+            SK_MFMA(SET, a0, b0);
+            // k-group 1 + fragments of k-group 2
+            SK_READ(a0, b0, pa, pb, 2);
+            SK_MFMA(SET, a1, b1);
+            // k-group 2 + fragments of k-group 3
+            SK_READ(a1, b1, pa, pb, 3);
+            SK_MFMA(SET, a0, b0);
+            // the interleave: one feeding instruction after each MFMA, in this order
+            {
+                constexpr int NF = TM + TN, NL = RA + RB;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+#pragma unroll
+                for (int q = 0; q < NL; ++q) { SK_SGB(0x8, 1); SK_SGB(0x200, 1); }
+#pragma unroll
+                for (int q = 0; q < NL; ++q) { SK_SGB(0x8, 1); SK_SGB(0x20, 1); }
+                constexpr int u1 = NF + 2 * NL;
+                if constexpr (u1 < NM) SK_SGB(0x8, NM - u1);
+                constexpr int v1 = u1 < NM ? NM : u1;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+                constexpr int u2 = v1 + NF;
+                if constexpr (u2 < 2 * NM) SK_SGB(0x8, 2 * NM - u2);
+                constexpr int v2 = u2 < 2 * NM ? 2 * NM : u2;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+                constexpr int u3 = v2 + NF;
+                if constexpr (u3 < 3 * NM) SK_SGB(0x8, 3 * NM - u3);
+            }
+            // k-group 3: everybody has read LDS[cur] and written LDS[next] once the fragment reads above have landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            SK_READ(a0, b0, sA + (cur ^ 1) * BM * SK_LDP + fa, sB + (cur ^ 1) * BN * SK_LDP + fb, 0);
+            SK_MFMA(SET, a1, b1);
+#pragma unroll
+            for (int q = 0; q < TM + TN; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+            SK_SGB(0x8, NM - (TM + TN));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the finished chunk goes into the running total and the accumulators restart from zero
+        auto flush = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        tot[i][j][q] += acc[0][i][j][q];
+                        acc[0][i][j][q] = 0.f;
+                    }
+        };
+        SK_TL(1, wall_clock64());
+        load();
+        stage(0);
+        load();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[0][i][j][q] = 0.f, tot[i][j][q] = 0.f;
+        SK_READ(a0, b0, sA + fa, sB + fb, 0);
+        // K loop.  Chunks are aligned to the tile's own step index (a + s): the summation structure of a segment does not depend on
+        // where the workgroup's range starts
+        const int nsteps = b - a;
+        SK_TL(2, wall_clock64());
+        SK_TL(5, (unsigned long long)nsteps);
+        for (int s = 0; s < nsteps; ++s) {
+            if (s > 0 && ((a + s) % SK_CHUNK) == 0) flush();  // uniform
+            step(s & 1);
+        }
+        flush();
+
+        // ------------------------------------------------------------------ end of the segment
+        const bool owner = a == 0, whole = owner && b == tend - tbeg;
+        SK_TL(3, wall_clock64());
+        SK_TL(6, whole ? 0ull : (owner ? 1ull : 2ull));
+        if (!owner) {
+            // publish the partial tile: register order, 16 B per lane (write-through), then drain + flag
+            float* slab = P.slabs + (size_t)r * (BM * BN);
+            const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
+                        const int off = ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsS, off, 0, 16);  // sc1
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store((gu32*)(P.flags + r), P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (!whole) {
+                // the ranges r+1 .. r_last hold the rest of this tile: r(x) = ((x + 1) * G - 1) / S for the tile's last step x
+                const int r_last = (int)((((long)tend) * G - 1) / P.S);
+                for (int cr = r + 1; cr <= r_last; ++cr) {
+                    if (wave == 0) {
+                        unsigned spins = 0;
+                        bool ok = true;
+                        while (__hip_atomic_load((gu32*)(P.flags + cr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) {
+                                ok = false;
+                                break;
+                            }
+                        }
+                        if (lane == 0) {
+                            sFlagOk = ok ? 1 : 0;
+                            if (!ok) __hip_atomic_store((gu32*)P.err, 1u + (unsigned)cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    if (sFlagOk) {
+                        const float* slab = P.slabs + (size_t)cr * (BM * BN);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const f32x4 v = *(const f32x4*)(slab + ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) tot[i][j][4 * q + e] += v[e];
+                                }
+                    }
+                    __syncthreads();
+                }
+            }
+            sk_epilogue<BM, BN, EPI>(tot, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
+        }
+        SK_TL(4, wall_clock64());
+        // ------------------------------------------------------------------ next tile of the range
+        pos = tbeg + b;
+        if (pos >= s_end) break;
+        ++tile;
+        if (++nt == P.nnb) {
+            nt = 0;
+            if (++mt == P.cls[c].nmb) {
+                mt = 0;
+                ++c;
+            }
+        }
+        __syncthreads();  // the epilogue's reads of sOut / sGrp are done before the next tile's set-up overwrites them
+    }
+#undef SK_READ
+#undef SK_MFMA
+}
+
+#ifdef SDT_TUNING  // measured, not faster than conv_taps_kernel (profiles/r03_streamk_ab.txt): kept as an experiment only
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (tuning build): the 64x64-tile kernel of conv.hip (7 workgroups per CU, register-staged K loop) with the PLAN doing its
+// index work.  Result: NOT faster than the original (+5 % on three launches, -5 % on five, the (6,3) input gradient -17 % without the
+// original's tile rotation): the slow prologue of the original overlaps other workgroups' MFMAs and is not what bounds it.  The timeline of
+// the original (profiles/r03_taps_timeline_64x64.txt) shows a prologue of 6 us alone / 30 us under load -- integer divisions, two serial
+// LDS loops over the taps, three barriers -- and an epilogue of 9 us (16 LDS-dependent, branch-guarded dword stores per lane), i.e. a
+// third of a workgroup's life outside its K loop.  Here the prologue is a handful of independent table loads and the epilogue the
+// branch-free buffer stores of sk_epilogue.  One workgroup per output tile; tiles of all classes in one 1-D grid, XCD-chunked.
+// CHUNK > 0: fp32 accumulation in chunks of CHUNK K steps (see the header of this file).
+template <int EPI, int CHUNK>
+__global__ __launch_bounds__(256) void conv_tab_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
+    constexpr int BM = 64, BN = 64, RA = 2, RB = 2;
+    __shared__ __attribute__((aligned(16))) float sA[BM * SK_LDP];
+    __shared__ __attribute__((aligned(16))) float sB[BN * SK_LDP];
+    __shared__ __attribute__((aligned(16))) int sOut[BM];
+    __shared__ __attribute__((aligned(16))) int sGrp[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kv = tid & 7, r0 = tid >> 3;
+    const int tile = xcd_remap(blockIdx.x, P.T);
+    int c = 0;
+    while (c + 1 < P.ncls && tile >= P.cls[c + 1].tile_begin) ++c;
+    const sk_class& cl = P.cls[c];
+    const int rel = tile - cl.tile_begin;
+    const int mt = rel / P.nnb, nt = rel - mt * P.nnb;
+    const int Hi = __builtin_amdgcn_readfirstlane(cl.Hi), Wi = __builtin_amdgcn_readfirstlane(cl.Wi);
+    const int nkc = __builtin_amdgcn_readfirstlane(cl.nkc), Cout = __builtin_amdgcn_readfirstlane(cl.Cout);
+    const int ntaps = __builtin_amdgcn_readfirstlane(cl.ntaps);
+    const int m0 = cl.row_begin + mt * BM, n0 = nt * BN;
+    // every table read of the prologue is issued before the first result is needed
+    int2 ti = P.tileinfo[cl.mt_begin + mt];
+    const int4 ri0 = P.rowinfo[m0 + r0], ri1 = P.rowinfo[m0 + r0 + 32];
+    int v_ash = 0, v_bsh = 0;
+    if (lane < ntaps) {
+        v_ash = cl.ashift[lane];
+        v_bsh = cl.bshift[lane];
+    }
+    if (tid < BM) {
+        const int4 ri = P.rowinfo[m0 + tid];
+        sOut[tid] = ri.z;
+        sGrp[tid] = ri.w;
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)P.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)P.ybytes, 0x00020000);
+    unsigned rmask = (unsigned)__builtin_amdgcn_readfirstlane(ti.x);
+    const int rot = __builtin_amdgcn_readfirstlane(ti.y);
+    const int nsteps = __builtin_popcount(rmask) * nkc;
+    unsigned abase[RA], bbase[RB], aoff[RA], boff[RB];
+    unsigned inval[RA];
+    abase[0] = (unsigned)ri0.x + (unsigned)kv * 16u, abase[1] = (unsigned)ri1.x + (unsigned)kv * 16u;
+    inval[0] = (unsigned)ri0.y, inval[1] = (unsigned)ri1.y;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((n0 + r0 + 32 * i) * cl.Tw * cl.Cin) * 4u + (unsigned)kv * 16u;
+    int kc = 0;
+    bool newtap = true;
+    f32x4 ra[RA], rb[RB];
+    auto load = [&]() {
+        if (newtap) {  // uniform: row offsets are rebuilt only when the tap changes (every Cin/32 steps)
+            int t = (rmask != 0u ? __builtin_ctz(rmask) : 0) + rot;
+            t = t >= ntaps ? t - ntaps : t;
+            const int ash = __builtin_amdgcn_readlane(v_ash, t), bsh = __builtin_amdgcn_readlane(v_bsh, t);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) aoff[i] = (inval[i] >> t) & 1u ? SK_OOB : abase[i] + (unsigned)ash;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) boff[i] = bbase[i] + (unsigned)bsh;
+        }
+        const int cs = kc * (SK_BK * 4);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)aoff[i], cs, 0));
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)boff[i], cs, 0));
+        newtap = ++kc == nkc;
+        if (newtap) {
+            kc = 0;
+            rmask &= rmask - 1u;
+        }
+    };
+    f32x16 acc[1][1], tot[1][1];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f, tot[0][0][q] = 0.f;
+    const float* pa = sA + (wm * 32 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    const float* pb = sB + (wn * 32 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    if (nsteps > 0) load();
+    for (int step = 0; step < nsteps; ++step) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * SK_LDP + kv * 4] = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * SK_LDP + kv * 4] = rb[i];
+        __syncthreads();
+        if (step + 1 < nsteps) load();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = *(const f32x4*)(pa + j * 8), b = *(const f32x4*)(pb + j * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[0][0], 0, 0, 0);
+        }
+        if constexpr (CHUNK > 0) {
+            if ((step + 1) % CHUNK == 0) {  // uniform
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    tot[0][0][q] += acc[0][0][q];
+                    acc[0][0][q] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (CHUNK > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot[0][0][q] += acc[0][0][q];
+        sk_epilogue<BM, BN, EPI, 0, 1>(tot, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
+    } else {
+        sk_epilogue<BM, BN, EPI, 0, 1>(acc, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
+    }
+}
+
+#endif  // SDT_TUNING
+
+// ---------------------------------------------------------------------------------------------
+// Host side: the plan.  Layout of the blob (all int32, offsets in ints from the start of the blob):
+//   [0] magic  [1] BM  [2] BN  [3] G  [4] ncls  [5] nnb  [6] T  [7] S  [8] rows (total, padded)  [9] n m-tiles (total)
+//   [10] off rowinfo  [11] off tileinfo  [12] off tilecum  [13] off range_tile  [14] off classes  [15] total ints
+#define SK_MAGIC 0x534b3033
+#define SK_HDR 16
+#define SK_CLS_INTS (11 + 3 * SDT_MAX_TAPS)
+
+static bool sk_supported(const sdt_conv_geom* const* gs, int ncls, int bm, int bn) {
+    for (int c = 0; c < ncls; ++c) {
+        const sdt_conv_geom& g = *gs[c];
+        if (g.Cin % SK_BK != 0 || g.Cout % bn != 0 || g.Hi >= 32768 || g.Wi >= 32768 || g.ntaps > SDT_MAX_TAPS) return false;
+        if (g.Cin != gs[0]->Cin || g.Cout != gs[0]->Cout || g.Tw != gs[0]->Tw || g.B != gs[0]->B || g.Hi != gs[0]->Hi || g.Wi != gs[0]->Wi ||
+            g.Hy != gs[0]->Hy || g.Wy != gs[0]->Wy)
+            return false;
+    }
+    return true;
+}
+
+// workgroups per CU (experiment switch, sdt_convsk_set_wg_per_cu): 1 = one wave per SIMD, every bubble of a tile switch is exposed
+// but the pipelined loop runs at 0.91 of the peak; 2 = two waves per SIMD cover each other's tile switches (0.88 in the loop)
+static int g_sk_wpc = 2;
+extern "C" int sdt_convsk_set_wg_per_cu(int n) {
+    SDT_CHECK_ARG(n == 1 || n == 2, "1 or 2 workgroups per CU");
+    g_sk_wpc = n;
+    return SDT_OK;
+}
+
+static void sk_tile_choice(const sdt_conv_geom& g, int& bm, int& bn) {
+    if (g.Cout % 128 == 0) bm = 128, bn = 128;
+    else if (g_sk_wpc == 1) bm = 256, bn = 64;
+    else bm = 128, bn = 64;  // two workgroups per CU: 2 x 55 KB of LDS
+}
+
+static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, int bn, int G) {
+    int64_t rows = 0, mts = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int64_t M = (int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo;
+        const int64_t nmb = cdiv64(M, bm);
+        rows += nmb * bm;
+        mts += nmb;
+    }
+    const int nnb = gs[0]->Cout / bn;
+    const int64_t T = mts * nnb;
+    return SK_HDR + rows * 4 + mts * 2 + (T + 1) + G + (int64_t)ncls * SK_CLS_INTS;
+}
+
+// kind: 0 = stream-K plan (tile and grid from the workgroups-per-CU setting), 1 = plan of the 64x64 table-driven kernel
+static void plan_shape(const sdt_conv_geom& g, int kind, int& bm, int& bn, int& G) {
+    if (kind == 1) {
+        bm = 64, bn = 64, G = 8;
+    } else {
+        sk_tile_choice(g, bm, bn);
+        G = 256 * g_sk_wpc;
+    }
+}
+
+static int plan_supported(const sdt_conv_geom* geoms, int ncls, int kind) {
+    if (!geoms || ncls < 1 || ncls > SK_MAXC) return 0;
+    const sdt_conv_geom* gs[SK_MAXC];
+    for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
+    int bm, bn, G;
+    plan_shape(*gs[0], kind, bm, bn, G);
+    return sk_supported(gs, ncls, bm, bn) ? 1 : 0;
+}
+extern "C" int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 0); }
+extern "C" int sdt_convtab_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 1); }
+
+// grid of a plan (number of persistent workgroups): one per CU
+extern "C" int sdt_convsk_grid(void) { return 256 * g_sk_wpc; }
+
+static int64_t plan_bytes(const sdt_conv_geom* geoms, int ncls, int kind) {
+    if (!plan_supported(geoms, ncls, kind)) return -1;
+    const sdt_conv_geom* gs[SK_MAXC];
+    for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
+    int bm, bn, G;
+    plan_shape(*gs[0], kind, bm, bn, G);
+    return sk_plan_ints(gs, ncls, bm, bn, G) * 4;
+}
+extern "C" int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 0); }
+extern "C" int64_t sdt_convtab_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 1); }
+
+// workspace of a launch: slabs + flags + error word (bytes); the caller zero-fills it ONCE after allocation and hands the same
+// buffer to every launch of one stream with a strictly increasing epoch (>= 1)
+extern "C" int64_t sdt_convsk_workspace_bytes(void) { return (int64_t)512 * (128 * 128) * 4 + (int64_t)512 * 4 + 64; }
+
+// Builds the plan into host memory `out` (sdt_convsk_plan_bytes bytes); the caller copies it to the device once per geometry.
+// rows_per_group > 0: statistics group of row m of class c = m / rows_per_group (forward statistics) -- for an input gradient with
+// normalisation-backward statistics pass -1: the group is the batch item (groups == B) or 0 (groups == 1), chosen by `bwd_groups`.
+static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes, int kind) {
+    SDT_CHECK_ARG(plan_supported(geoms, ncls, kind), "geometry not supported by this kernel");
+    SDT_CHECK_ARG(out != nullptr && out_bytes >= plan_bytes(geoms, ncls, kind), "plan buffer too small");
+    const sdt_conv_geom* gs[SK_MAXC];
+    for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
+    int bm, bn, G;
+    plan_shape(*gs[0], kind, bm, bn, G);
+    int* P = (int*)out;
+    const int nnb = gs[0]->Cout / bn;
+    int64_t rows = 0, mts = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int64_t nmb = cdiv64((int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo, bm);
+        rows += nmb * bm;
+        mts += nmb;
+    }
+    const int64_t T = mts * nnb;
+    const int64_t o_row = SK_HDR, o_ti = o_row + rows * 4, o_cum = o_ti + mts * 2, o_rt = o_cum + T + 1, o_cls = o_rt + G;
+    int* rowinfo = P + o_row;
+    int* tileinfo = P + o_ti;
+    int* tilecum = P + o_cum;
+    int* range_tile = P + o_rt;
+    int* clsp = P + o_cls;
+    int64_t row_begin = 0, mt_begin = 0, tile_begin = 0, S = 0;
+    tilecum[0] = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const sdt_conv_geom& g = *gs[c];
+        const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+        const int nmb = (int)cdiv64(M, bm);
+        const int nkc = g.Cin / SK_BK;
+        int dymin = g.dy[0], dymax = g.dy[0];
+        for (int t = 1; t < g.ntaps; ++t) dymin = std::min(dymin, g.dy[t]), dymax = std::max(dymax, g.dy[t]);
+        const int nd = dymax - dymin + 1;
+        // tap order: by the residue of the input row a tap reads on layers whose weights fit an L2 (see conv.hip), table order otherwise
+        const bool rotate = (unsigned)g.Cout * (unsigned)g.Tw * (unsigned)g.Cin <= (3u << 17);
+        // taps must be sorted by dy for the rotation to be a cyclic shift of the table: true for every geometry ops.py builds
+        bool sorted = true;
+        for (int t = 1; t < g.ntaps; ++t) sorted = sorted && g.dy[t] >= g.dy[t - 1];
+        for (int mt = 0; mt < nmb; ++mt) {
+            unsigned mask = 0;
+            for (int rr = 0; rr < bm; ++rr) {
+                const int64_t m = (int64_t)mt * bm + rr;
+                int* ri = rowinfo + (row_begin + m) * 4;
+                if (m >= M) {
+                    ri[0] = 0;
+                    ri[1] = -1;  // every tap invalid
+                    ri[2] = (int)SK_OOB;
+                    ri[3] = -1;
+                    continue;
+                }
+                const int ox = (int)(m % g.Wo), tq = (int)(m / g.Wo);
+                const int oy = tq % g.Ho, b = tq / g.Ho;
+                const int iy0 = oy * g.sy, ix0 = ox * g.sx;
+                ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * 4));
+                unsigned inval = 0x80000000u;  // bit t: tap t reads outside X for this row; bit 31: always set (the "loader off" position)
+                ri[2] = (int)((((int64_t)b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout * 4);  // byte offset of the output row in Y
+                ri[3] = rows_per_group > 0 ? (int)(m / rows_per_group) : (bwd_groups == 1 ? 0 : b);
+                for (int t = 0; t < g.ntaps; ++t) {
+                    if ((unsigned)(iy0 + g.dy[t]) < (unsigned)g.Hi && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.Wi) mask |= 1u << t;
+                    else inval |= 1u << t;
+                }
+                ri[1] = (int)inval;
+            }
+            if (g.Hi == 1 || g.ntaps <= 4) mask = (1u << g.ntaps) - 1u;  // as conv.hip: no culling on short tap lists (a dead tap costs zeros, not wrong results)
+            int rot = 0;
+            if (rotate && sorted) {
+                const int oy0 = (int)((((int64_t)mt * bm) / g.Wo) % g.Ho);
+                const int b0 = (oy0 * g.sy) % nd;
+                // first key in rotated order is 0: taps with (b0 + dy - dymin) mod nd == 0 ... i.e. dy - dymin == (nd - b0) mod nd
+                const int want = (nd - b0) % nd;
+                rot = g.ntaps;  // none >= want: start from the table's beginning
+                for (int t = 0; t < g.ntaps; ++t)
+                    if (g.dy[t] - dymin >= want) {
+                        rot = t;
+                        break;
+                    }
+                if (rot == g.ntaps) rot = 0;
+            }
+            // the kernel walks the live taps in the order rot, rot+1, .., ntaps-1, 0, .., rot-1: store the mask rotated accordingly
+            unsigned rmask = 0;
+            for (int i = 0; i < g.ntaps; ++i)
+                if (mask >> ((rot + i) % g.ntaps) & 1u) rmask |= 1u << i;
+            tileinfo[(mt_begin + mt) * 2] = (int)rmask;
+            tileinfo[(mt_begin + mt) * 2 + 1] = rot;
+            const int live = __builtin_popcount(mask) * nkc;
+            for (int nt = 0; nt < nnb; ++nt) {
+                const int64_t tile = tile_begin + (int64_t)mt * nnb + nt;
+                S += live;
+                tilecum[tile + 1] = (int)S;
+            }
+        }
+        int* cp = clsp + c * SK_CLS_INTS;
+        cp[0] = g.Hi, cp[1] = g.Wi, cp[2] = g.Cin, cp[3] = g.Cout, cp[4] = g.ntaps, cp[5] = nkc;
+        cp[6] = (int)tile_begin, cp[7] = nmb, cp[8] = (int)row_begin, cp[9] = (int)mt_begin, cp[10] = g.Tw;
+        for (int t = 0; t < SDT_MAX_TAPS; ++t) {
+            const bool on = t < g.ntaps;
+            cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * 4 : 0;
+            cp[11 + SDT_MAX_TAPS + t] = on ? ((g.dy[t] & 0xffff) | (g.dx[t] << 16)) : 0;
+            cp[11 + 2 * SDT_MAX_TAPS + t] = on ? g.wt[t] * g.Cin * 4 : 0;
+        }
+        row_begin += (int64_t)nmb * bm;
+        mt_begin += nmb;
+        tile_begin += (int64_t)nmb * nnb;
+    }
+    SDT_CHECK_ARG(S >= 4 * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
+    SDT_CHECK_ARG(T < (1ll << 30), "too many tiles");
+    // first tile of every range: the tile that contains step floor(r * S / G)
+    int64_t tile = 0;
+    for (int r = 0; r < G; ++r) {
+        const int64_t s0 = (int64_t)r * S / G;
+        while (tile + 1 < T && tilecum[tile + 1] <= s0) ++tile;
+        range_tile[r] = (int)tile;
+    }
+    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G, P[4] = ncls, P[5] = nnb, P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
+    P[10] = (int)o_row, P[11] = (int)o_ti, P[12] = (int)o_cum, P[13] = (int)o_rt, P[14] = (int)o_cls, P[15] = (int)(o_cls + (int64_t)ncls * SK_CLS_INTS);
+    return SDT_OK;
+}
+extern "C" int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes) {
+    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, 0);
+}
+extern "C" int sdt_convtab_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes) {
+    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, 1);
+}
+
+template <int BM, int BN, int EPI, int WPC>
+static void sk_launch(const float* x, const float* w, const float* bias, float* y, const sk_args& A, double* stats, int rpg, const sk_norm_bwd& nb,
+                      hipStream_t s) {
+    const size_t lds = (size_t)(2 * (BM + BN) * SK_LDP) * 4 + (size_t)BM * 8 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)convsk_kernel<BM, BN, EPI, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((convsk_kernel<BM, BN, EPI, WPC>), dim3(A.G), dim3(256), lds, s, x, w, bias, y, A, stats, rpg, nb);
+}
+
+// kernel arguments from a plan blob (host copy: header + class tables; device copy: row / tile tables)
+static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, const void* plan_dev, void* workspace, unsigned epoch,
+                        const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes, int64_t ybytes) {
+    const int* P = (const int*)plan_host;
+    SDT_CHECK_ARG(P[0] == SK_MAGIC, "not a conv plan");
+    SDT_CHECK_ARG(xbytes > 0 && wbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && wbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536,
+                  "tensor sizes out of range");
+    A.G = P[3], A.ncls = P[4], A.nnb = P[5], A.T = P[6], A.S = P[7];
+    const int* D = (const int*)plan_dev;
+    A.rowinfo = (const int4*)(D + P[10]);
+    A.tileinfo = (const int2*)(D + P[11]);
+    A.tilecum = D + P[12];
+    A.range_tile = D + P[13];
+    SDT_CHECK_ARG(P[10] % 4 == 0 && P[11] % 2 == 0, "plan tables misaligned");
+    for (int c = 0; c < A.ncls; ++c) {
+        const int* cp = P + P[14] + c * SK_CLS_INTS;
+        sk_class& k = A.cls[c];
+        k.Hi = cp[0], k.Wi = cp[1], k.Cin = cp[2], k.Cout = cp[3], k.ntaps = cp[4], k.nkc = cp[5];
+        k.tile_begin = cp[6], k.nmb = cp[7], k.row_begin = cp[8], k.mt_begin = cp[9], k.Tw = cp[10];
+        for (int t = 0; t < SDT_MAX_TAPS; ++t) k.ashift[t] = cp[11 + t], k.dyx[t] = cp[11 + SDT_MAX_TAPS + t], k.bshift[t] = cp[11 + 2 * SDT_MAX_TAPS + t];
+    }
+    for (int c = A.ncls; c < SK_MAXC; ++c) A.cls[c] = A.cls[0];
+    A.xbytes = (unsigned)xbytes, A.wbytes = (unsigned)wbytes, A.ybytes = (unsigned)ybytes;
+    char* ws = (char*)workspace;
+    A.slabs = (float*)ws;
+    A.flags = ws ? (unsigned*)(ws + (size_t)512 * (128 * 128) * 4) : nullptr;
+    A.err = ws ? A.flags + 512 : nullptr;
+    A.epoch = epoch;
+    nb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    if (nbw) {
+        SDT_CHECK_ARG(nbw->y && nbw->mean && nbw->rstd && nbw->sums, "null pointer in sdt_norm_bwd");
+        nb = {nbw->y, nbw->mean, nbw->rstd, nbw->gamma, nbw->beta, nbw->sums, nbw->slope, nbw->groups};
+    }
+    return SDT_OK;
+}
+
+// One launch of the persistent stream-K conv.
+//   plan_host : the blob sdt_convsk_plan_build wrote (host copy: the header and the class tables travel as kernel arguments)
+//   plan_dev  : the same blob in device memory (row / tile tables are read from there)
+//   workspace : sdt_convsk_workspace_bytes() bytes, zero-filled once; epoch strictly increasing per workspace, >= 1
+//   stats != NULL: forward statistics as sdt_conv_taps_stats_f32 (plan built with rows_per_group > 0)
+//   nbw   != NULL: normalisation-backward statistics as sdt_conv_taps_multi_f32 (plan built with rows_per_group = -1, bwd_groups)
+extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
+                              void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
+                              int64_t ybytes, void* stream) {
+    SDT_CHECK_ARG(x && w && y && plan_host && plan_dev && workspace, "null pointer");
+    SDT_CHECK_ARG(epoch >= 1, "epoch must be >= 1");
+    SDT_CHECK_ARG(!(stats && nbw), "forward and backward statistics are exclusive");
+    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)workspace | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
+    sk_args A;
+    sk_norm_bwd nb;
+    int rc = sk_fill_args(A, nb, plan_host, plan_dev, workspace, epoch, nbw, xbytes, wbytes, ybytes);
+    if (rc) return rc;
+    const int* P = (const int*)plan_host;
+    const int bm = P[1], bn = P[2];
+    hipStream_t s = (hipStream_t)stream;
+    const int epi = stats ? 1 : (nbw ? 2 : 0);
+    const int wpc = A.G / 256;
+    SDT_CHECK_ARG(A.G == 256 || A.G == 512, "plan built for an unknown grid");
+#define SK_GO(BM_, BN_, WPC_)                                                              \
+    do {                                                                                    \
+        if (epi == 0) sk_launch<BM_, BN_, 0, WPC_>(x, w, bias, y, A, stats, 0, nb, s);      \
+        else if (epi == 1) sk_launch<BM_, BN_, 1, WPC_>(x, w, bias, y, A, stats, 0, nb, s); \
+        else sk_launch<BM_, BN_, 2, WPC_>(x, w, bias, y, A, stats, 0, nb, s);               \
+    } while (0)
+    if (bm == 128 && bn == 128 && wpc == 1) SK_GO(128, 128, 1);
+    else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(128, 128, 2);
+    else if (bm == 256 && bn == 64 && wpc == 1) SK_GO(256, 64, 1);
+    else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(128, 64, 2);
+    else SDT_CHECK_ARG(false, "plan with an unknown tile shape");
+#undef SK_GO
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+#ifdef SDT_TUNING
+// The 64x64 kernel driven by a plan (sdt_convtab_plan_build): one workgroup per output tile, no workspace.  chunk: 0 = one accumulator over
+// the whole K loop (the summation order of sdt_conv_taps_f32), 8 = accumulation in chunks of 8 K steps (256 products).
+extern "C" int sdt_convtab_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
+                               double* stats, const sdt_norm_bwd* nbw, int chunk, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream) {
+    SDT_CHECK_ARG(x && w && y && plan_host && plan_dev, "null pointer");
+    SDT_CHECK_ARG(!(stats && nbw), "forward and backward statistics are exclusive");
+    SDT_CHECK_ARG(chunk == 0 || chunk == 8, "chunk must be 0 or 8");
+    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
+    sk_args A;
+    sk_norm_bwd nb;
+    int rc = sk_fill_args(A, nb, plan_host, plan_dev, nullptr, 1, nbw, xbytes, wbytes, ybytes);
+    if (rc) return rc;
+    const int* P = (const int*)plan_host;
+    SDT_CHECK_ARG(P[1] == 64 && P[2] == 64, "not a 64x64 plan");
+    hipStream_t s = (hipStream_t)stream;
+    const int epi = stats ? 1 : (nbw ? 2 : 0);
+    const dim3 grid(A.T), blk(256);
+#define TAB_GO(EPI_)                                                                                                     \
+    do {                                                                                                                  \
+        if (chunk == 0) hipLaunchKernelGGL((conv_tab_kernel<EPI_, 0>), grid, blk, 0, s, x, w, bias, y, A, stats, nb);     \
+        else hipLaunchKernelGGL((conv_tab_kernel<EPI_, 8>), grid, blk, 0, s, x, w, bias, y, A, stats, nb);                \
+    } while (0)
+    if (epi == 0) TAB_GO(0);
+    else if (epi == 1) TAB_GO(1);
+    else TAB_GO(2);
+#undef TAB_GO
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+#endif  // SDT_TUNING

@@ -349,7 +349,7 @@ def stage_mark(name):
         STAGES.mark(name)
 
 
-def _conv_launch(kind, is2d, g, call, flops=None):
+def _conv_launch(kind, is2d, g, call, flops=None, name=None):
     """``flops``: algorithmic FLOPs of the launch when they are not the geometry's ``2*M*Cout*ntaps*Cin`` (an input-gradient
     class of a valid-correlation layer: the tap table spans input positions no output position reaches; SURVEY.md 8d counts
     dX = forward)."""
@@ -367,10 +367,10 @@ def _conv_launch(kind, is2d, g, call, flops=None):
     e0.record()
     check(call())
     e1.record()
-    PROFILER.records.append((ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
+    PROFILER.records.append((name or ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
-def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=None):
+def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=None, name=None):
     """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient); ``extra_bytes``:
     what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics);
     ``flops``: the algorithmic FLOPs (input gradients pass the FORWARD layer's count, SURVEY.md 8d -- the classes' tap tables
@@ -388,9 +388,104 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=N
     e0.record()
     check(call())
     e1.record()
-    name = "conv_taps_pre_kernel (bf16x6 products, pre-split operands)" if pre else ConvProfiler.kernel_name(kind, var)
+    name = name or ("conv_taps_pre_kernel (bf16x6 products, pre-split operands)" if pre else ConvProfiler.kernel_name(kind, var))
     PROFILER.records.append((name, kind, is2d, flops, nbytes, e0, e1))
 
+
+
+# --------------------------------------------------------------------------------------------
+# persistent stream-K conv (csrc/convsk.hip): plans and workspaces
+# --------------------------------------------------------------------------------------------
+USE_STREAMK = True   # the Conv2d forward / input-gradient launches of the audio encoder go through sdt_convsk_f32 (exact fp32 math)
+_SK_PLANS = {}       # (id of the cached geometry object(s), rows_per_group, bwd_groups, device index) -> _SKPlan | None
+_SK_WS = {}          # (device index, raw stream) -> [workspace tensor, epoch]
+
+
+class _SKPlan:
+    """Host + device copy of a stream-K plan (built once per geometry pack; geometries are cached objects, see fwd_geom / dx_pack)."""
+    __slots__ = ("host", "dev", "keep", "kind")
+
+    def __init__(self, garr, n, rpg, bwd_groups, dev, kind="sk"):
+        import ctypes as C
+        lib = _lib.load()
+        nbytes = (lib.sdt_convsk_plan_bytes if kind == "sk" else lib.sdt_convtab_plan_bytes)(garr, n)
+        self.host = (C.c_int32 * (nbytes // 4))()
+        self.kind = kind
+        check((lib.sdt_convsk_plan_build if kind == "sk" else lib.sdt_convtab_plan_build)(garr, n, int(rpg), int(bwd_groups), C.addressof(self.host), nbytes))
+        self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
+        self.keep = garr  # the key holds id(garr): keep it alive
+
+
+# Which launches take the stream-K kernel (measured per layer on one MI355X, profiles/r03_streamk_ab.txt): it wins where a tile's K loop
+# is long enough to amortise the tile switch of a 1-2-workgroup-per-CU kernel (set-up + pipeline fill + epilogue, ~10 us per 128x128
+# tile) and loses on the 64-wide outputs and on the 2x2-tap parity classes of strided input gradients, which stay with the 64x64 kernel.
+STREAMK_MIN_STEPS = 48   # K steps (of 32) per output tile, nominal: taps * Cin / 32
+STREAMK_MIN_COUT = 128
+
+
+def _sk_wanted(g0):
+    return g0.Cout % STREAMK_MIN_COUT == 0 and g0.ntaps * (g0.Cin // 32) >= STREAMK_MIN_STEPS
+
+
+USE_TAB = False      # experiment (tuning library only): 2-D launches that do not take the stream-K kernel run the 64x64 kernel with a plan
+TAB_CHUNK = 8        # K steps per accumulation chunk of that kernel (0: one accumulator over the whole K loop)
+
+
+def _sk_plan(garr, n, rpg, bwd_groups, dev):
+    """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the plan (stream-K where that kernel is wanted, else the
+    64x64 table-driven kernel's) or None when the pack qualifies for neither."""
+    key = (id(garr), int(rpg), int(bwd_groups), dev.index)
+    plan = _SK_PLANS.get(key, False)
+    if plan is False:
+        lib = _lib.load()
+        plan = None
+        g0 = garr if isinstance(garr, ConvGeom) else garr[0]
+        kind = "sk" if (USE_STREAMK and lib.sdt_convsk_supported(garr, n) and _sk_wanted(g0)) else (
+            "tab" if (USE_TAB and g0.Hi > 1 and lib.sdt_convtab_supported(garr, n)) else None)
+        if kind is not None:
+            try:
+                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, kind)
+            except RuntimeError:  # e.g. too few K steps for a 256-way split (the 1-D stage): the 64x64 kernel takes it
+                plan = None
+        _SK_PLANS[key] = plan
+        if plan is None:
+            _SK_PLANS[("keep", id(garr))] = garr
+    return plan
+
+
+def _sk_workspace(dev, st):
+    key = (dev.index, int(st))
+    ws = _SK_WS.get(key)
+    if ws is None:
+        nbytes = _lib.load().sdt_convsk_workspace_bytes()
+        # zero-filled ONCE (flags carry the epoch of the launch that set them); allocated on the launching stream
+        ws = _SK_WS[key] = [torch.zeros(nbytes // 4, device=dev, dtype=torch.int32), 0]
+    ws[1] += 1
+    return ws[0], ws[1]
+
+
+def streamk_error_codes():
+    """Non-zero entries: a stream-K launch gave up waiting for a partial tile (tests / bench check this after synchronising)."""
+    out = {}
+    for key, (ws, _epoch) in _SK_WS.items():
+        code = int(ws[512 * 128 * 128 + 512].item())
+        if code:
+            out[key] = code
+    return out
+
+
+def _sk_launch(plan, x4, ws_w, bias, y, stats, nb, st):
+    lib = _lib.load()
+    if plan.kind == "tab":
+        return lib.sdt_convtab_f32(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(stats), nb, TAB_CHUNK,
+                                   x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
+    wsb, epoch = _sk_workspace(y.device, st)
+    return lib.sdt_convsk_f32(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(wsb), epoch, _p(stats), nb,
+                              x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
+
+
+def _sk_name(plan):
+    return ("convsk_kernel<%d, %d>" if plan.kind == "sk" else "conv_tab_kernel<%d, %d>") % (plan.host[1], plan.host[2])
 
 def _splitk_hint(lib, g):
     k = getattr(g, "_splitk", None)  # geometries are cached objects: ask the library once per geometry
@@ -408,6 +503,11 @@ def conv_forward(x_cl, w, bias, stride, pad):
     ws = weight_storage(w)
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
     st = _stream()
+    if (USE_STREAMK or USE_TAB) and w.dim() == 4 and _CONV_MATH_NOW[0] == 0:
+        plan = _sk_plan(g, 1, 0, 1, x_cl.device)
+        if plan is not None:
+            _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x4, ws, bias, y, None, None, st), name=_sk_name(plan))
+            return y
     k = _splitk_hint(lib, g)
     if k > 1:  # too few output tiles for 256 CUs (1-D stage): slice the K loop, then a fixed-order reduce (+bias)
         part = torch.empty((k,) + tuple(y.shape), device=x_cl.device, dtype=torch.float32)
@@ -579,6 +679,20 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
                                extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops)
             return dx
     pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
+    if pack is not None and (USE_STREAMK or USE_TAB) and not one_d:
+        arr, n, gs = pack
+        h = norm_holder
+        fuse = (h is not None and FUSE_BWD_STATS and h.y is not None and tuple(h.y.shape) == tuple(dx.shape)
+                and all((g.B * g.Ho * g.Wo if h.groups == 1 else g.Ho * g.Wo) >= 32 for g in gs))
+        plan = _sk_plan(arr, n, -1, h.groups if fuse else 1, w.device)
+        if plan is not None:
+            nb = None
+            if fuse:
+                h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
+                nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+            _conv_launch_multi("dX", True, gs, lambda: _sk_launch(plan, gy4, wt, None, dx, None, nb, st),
+                               extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops, name=_sk_name(plan))
+            return dx
     if pack is not None:
         arr, n, gs = pack
         k = max(_splitk_hint(lib, g) for g in gs)
@@ -812,7 +926,11 @@ class ConvStatsFn(torch.autograd.Function):
                                                                  rpg, None, st), pre=True)
             in_holder.zp = None  # x has exactly one consumer in this chain: the planes can go back to the allocator
         else:
-            _conv_launch("fwd", True, g, lambda: lib.sdt_conv_taps_stats_f32(_p(x_cl), _p(ws), None, _p(y), g, _p(sums), rpg, st))
+            plan = _sk_plan(g, 1, rpg, 1, x_cl.device) if ((USE_STREAMK or USE_TAB) and _CONV_MATH_NOW[0] == 0 and rpg >= 32) else None
+            if plan is not None:
+                _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x_cl, ws, None, y, sums, None, st), name=_sk_name(plan))
+            else:
+                _conv_launch("fwd", True, g, lambda: lib.sdt_conv_taps_stats_f32(_p(x_cl), _p(ws), None, _p(y), g, _p(sums), rpg, st))
         ctx.save_for_backward(x_cl, w)
         ctx.stride, ctx.pad = stride, pad
         ctx.mark_non_differentiable(sums)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Stream-K conv (csrc/convsk.hip) against the 64x64 kernel and a float64 F.conv2d, every Conv2d layer of the audio encoder at B=32:
+forward, forward + statistics epilogue, input gradient (+ backward-statistics epilogue); run-to-run bit identity; error word."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from speechdrivestemplates_amd import ops  # noqa: E402
+from conv_bench import LAYERS  # noqa: E402
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+MODE = 'sk'
+
+
+def main():
+    global MODE
+    MODE = sys.argv[2] if len(sys.argv) > 2 else 'sk'
+    if MODE == 'sk':
+        ops.STREAMK_MIN_STEPS, ops.STREAMK_MIN_COUT = 1, 64  # every layer through the stream-K kernel
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    torch.manual_seed(0)
+    bad = 0
+    for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
+        if Hi == 1 or Cin == 1:
+            continue
+        x = torch.randn((B, Hi, Wi, Cin), device="cuda")
+        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kh, kw), device="cuda") * 0.05))
+        ops.USE_STREAMK = False
+        ops.USE_TAB = False
+        y_old = ops.conv_forward(x, w, None, s, p)
+        gy = torch.randn_like(y_old)
+        dx_old = ops.conv_input_grad(gy, w, x.shape, s, p)
+        ops.USE_STREAMK = MODE == 'sk'
+        ops.USE_TAB = MODE == 'tab'
+        y1 = ops.conv_forward(x, w, None, s, p)
+        y2 = ops.conv_forward(x, w, None, s, p)
+        dx1 = ops.conv_input_grad(gy, w, x.shape, s, p)
+        dx2 = ops.conv_input_grad(gy, w, x.shape, s, p)
+        torch.cuda.synchronize()
+        # float64 reference on batch items 0 and B-1
+        idx = [0, B - 1]
+        xr = x[idx].permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+        wr = w.detach().double().cpu()
+        yr = F.conv2d(xr, wr, None, s, p)
+        yr.backward(gy[idx].permute(0, 3, 1, 2).double().cpu())
+        yref, dxref = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+        e = dict(fwd_vs_old=rel(y1, y_old), fwd_sk_f64=rel(y1[idx].cpu(), yref), fwd_old_f64=rel(y_old[idx].cpu(), yref),
+                 dx_vs_old=rel(dx1, dx_old), dx_sk_f64=rel(dx1[idx].cpu(), dxref), dx_old_f64=rel(dx_old[idx].cpu(), dxref))
+        same = bool((y1 == y2).all()) and bool((dx1 == dx2).all())
+        # statistics epilogue
+        groups = B
+        y3, sums = ops.ConvStatsFn.apply(x, w, s, p, groups)
+        rpg = y3.shape[1] * y3.shape[2]
+        ref_s = y3.double().reshape(B, rpg, Cout).sum(1)
+        ref_q = (y3.double() ** 2).reshape(B, rpg, Cout).sum(1)
+        got = sums.reshape(B, Cout, 2)
+        e["stats_sum"] = ((got[..., 0] - ref_s).abs().max() / ref_s.abs().max()).item()
+        e["stats_sq"] = ((got[..., 1] - ref_q).abs().max() / ref_q.abs().max()).item()
+        e["stats_y_same"] = float((y3 == y1).all())
+        ok = (e["fwd_vs_old"] < 2e-5 and e["dx_vs_old"] < 2e-5 and e["fwd_sk_f64"] < 3e-6 and e["dx_sk_f64"] < 3e-6 and same
+              and e["stats_sum"] < 1e-5 and e["stats_sq"] < 1e-5 and e["stats_y_same"] == 1.0)
+        bad += 0 if ok else 1
+        print("%-3s %s  bit-identical reruns: %s   %s" % (name, "ok  " if ok else "FAIL", same, "  ".join("%s %.2e" % kv for kv in e.items())), flush=True)
+    print("error words:", ops.streamk_error_codes())
+    print("FAILED" if bad or ops.streamk_error_codes() else "ALL OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Per-segment timeline of the persistent stream-K conv (tuning build): where a workgroup's time goes between tiles.
+   python __graft_entry__.py --tuning && python tools/debug/sk_timeline.py [--only L2,L5] [--roles fwd,dX] [--wpc 2]"""
+import argparse
+import ctypes
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+os.environ["SDT_HIP_LIB"] = os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from speechdrivestemplates_amd import _lib, ops  # noqa: E402
+
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from conv_bench import LAYERS  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="L1,L2,L4,L5")
+    ap.add_argument("--roles", default="fwd,dX")
+    ap.add_argument("--wpc", type=int, default=2)
+    a = ap.parse_args()
+    lib = _lib.load()
+    lib.sdt_debug_set_timeline_sk.argtypes = [ctypes.c_void_p]
+    _lib.check(lib.sdt_convsk_set_wg_per_cu(a.wpc))
+    B = 32
+    for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
+        if name not in a.only.split(",") or Hi == 1:
+            continue
+        x = torch.randn((B, Hi, Wi, Cin), device="cuda")
+        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kh, kw), device="cuda") * 0.05))
+        y = ops.conv_forward(x, w, None, s, p)
+        gy = torch.randn_like(y)
+        fns = {"fwd": lambda: ops.conv_forward(x, w, None, s, p), "dX": lambda: ops.conv_input_grad(gy, w, x.shape, s, p)}
+        for role in a.roles.split(","):
+            for _ in range(3):
+                fns[role]()
+            buf = torch.zeros((512 * 16, 8), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            assert lib.sdt_debug_set_timeline_sk(ctypes.c_void_p(buf.data_ptr())) == 0
+            fns[role]()
+            torch.cuda.synchronize()
+            lib.sdt_debug_set_timeline_sk(ctypes.c_void_p(0))
+            tl = buf.cpu().numpy().astype(np.int64).reshape(512, 16, 8)
+            np.save(os.path.join(REPO, "gpurun_out", "sk_tl_%s_%s.npy" % (name, role)), tl)
+            used = tl[:, :, 0] != 0
+            t = tl[..., :5].astype(np.float64) * 0.01
+            t0 = t[..., 0][used].min()
+            span = t[..., 4][used].max() - t0
+            steps = tl[..., 5][used]
+            kind = tl[..., 6][used]
+            ph = {"set-up": (t[..., 1] - t[..., 0])[used], "fill": (t[..., 2] - t[..., 1])[used], "K loop": (t[..., 3] - t[..., 2])[used],
+                  "end (publish / combine / epilogue)": (t[..., 4] - t[..., 3])[used]}
+            nseg = used.sum(1)
+            print("%s %s: span %.1f us; segments per workgroup %.1f (max %d, 16 recorded at most); K steps per segment median %d; kinds whole/owner/publish %d/%d/%d"
+                  % (name, role, span, nseg[nseg > 0].mean(), nseg.max(), np.median(steps), (kind == 0).sum(), (kind == 1).sum(), (kind == 2).sum()))
+            for k, v in ph.items():
+                print("    %-36s median %6.2f us  p90 %6.2f  max %6.2f   sum per workgroup %.1f us" % (k, np.median(v), np.percentile(v, 90), v.max(), v.sum() / (nseg > 0).sum()))
+            per_step = ph["K loop"] / np.maximum(steps, 1)
+            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (4096 MFMA cycles)" % (np.median(per_step), np.median(per_step) * 2380))
+            for kk, nm in ((0, "whole"), (1, "owner"), (2, "publish")):
+                sel = kind == kk
+                if sel.any():
+                    print("    end phase of %-8s segments: median %.2f us  p90 %.2f" % (nm, np.median(ph["end (publish / combine / epilogue)"][sel]), np.percentile(ph["end (publish / combine / epilogue)"][sel], 90)))
+            last = np.array([t[i, :, 4][used[i]].max() for i in range(512) if used[i].any()]) - t0
+            print("    workgroup finish times: min %.1f median %.1f max %.1f us" % (last.min(), np.median(last), last.max()))
+
+
+if __name__ == "__main__":
+    main()
