@@ -189,12 +189,13 @@ def main(argv=None):
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
-    ap.add_argument("--deterministic-dw", action="store_true",
-                    help="weight gradients through row-range slabs + an ordered reduce instead of fp32 atomics (bit-reproducible)")
+    ap.add_argument("--atomic-dw", action="store_true",
+                    help="weight gradients with fp32 atomics (the round-2 default) instead of the ordered, bit-reproducible reductions")
     ap.add_argument("--fused-conv1d", action="store_true",
-                    help="run the generator's Conv1d stage as one launch per layer and direction (csrc/conv1d.hip; measured 2 %% slower "
-                         "end to end, profiles/r02_conv1d_stage.txt)")
+                    help="experiment (tuning library only): the generator's Conv1d stage as one launch per layer and direction "
+                         "(csrc/conv1d.hip; measured 2 %% slower end to end, profiles/r02_conv1d_stage.txt)")
     ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
+    ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
@@ -243,14 +244,17 @@ def main(argv=None):
         from speechdrivestemplates_amd import ops
         ops.OVERLAP_DW = not args.no_overlap_dw
         ops.USE_STREAMK = not args.no_streamk
+        ops.USE_STREAMK_DW = not args.no_streamk and not args.no_streamk_dw
         if args.streamk_min_steps is not None:
             ops.STREAMK_MIN_STEPS = args.streamk_min_steps
             ops.STREAMK_MIN_COUT = 64
         ops.DEFER_SMALL_DW = not args.no_defer_dw
-        ops.DETERMINISTIC_DW = bool(args.deterministic_dw)
+        ops.DETERMINISTIC_DW = not args.atomic_dw
+        if args.atomic_dw:
+            ops.USE_STREAMK_DW = False
         if args.fused_conv1d:
-            from speechdrivestemplates_amd import stage1d
-            stage1d.ENABLED = True
+            from speechdrivestemplates_amd.experimental import stage1d  # needs SDT_HIP_LIB=.../libsdt_hip_tuning.so
+            stage1d.enable(True)
         ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
         ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
         ops.OVERLAP_AUX = not args.no_overlap_aux
@@ -267,7 +271,7 @@ def main(argv=None):
 
     runner = step
     if args.graph and world == 1 and not stub:
-        from speechdrivestemplates_amd.graph import GraphedStep
+        from speechdrivestemplates_amd.experimental.graph import GraphedStep
         gs = GraphedStep(pipe, warmup=min(3, max(1, args.warmup - 1)))
         runner = lambda i: gs.run(batches[i % len(batches)])  # noqa: E731
 
@@ -360,7 +364,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": bool(args.deterministic_dw)},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw},
             "final_G_loss": final_loss,
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included

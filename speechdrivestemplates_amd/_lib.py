@@ -67,13 +67,6 @@ SIGNATURES = {
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p, _p],
-    "sdt_split_planes_f32": [_p, _p, _i64, _i, _p],
-    "sdt_weight_planes_batched": [_p, _i, _i, _p],
-    "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
-    "sdt_set_pre_tile": [_i],
-    "sdt_c1d_layer_f32": [C.POINTER(C1d), _p],
-    "sdt_c1d_rownorm_partials_f32": [_p, _p, _i, _p, _p, _p, _i64, _i, _f, _f, _p],
-    "sdt_c1d_upsample_bwd_stats_f32": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "sdt_conv_taps_multi_f32": [_p, _p, _p, _G, _i, _i, _p, C.POINTER(NormBwd), _p],
     "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
@@ -103,7 +96,21 @@ SIGNATURES = {
     "sdt_convsk_grid": [],
     "sdt_convsk_set_wg_per_cu": [_i],
     "sdt_convsk_plan_build": [_G, _i, _i, _i, _p, _i64],
+    "sdt_convsk_dw_supported": [_G],
+    "sdt_convsk_dw_plan_build": [_G, _p, _i64],
+    "sdt_convsk_dw_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "sdt_convsk_f32": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
+}
+
+# entry points of the experiments (csrc/presplit.hip, csrc/conv1d.hip): present in the -DSDT_TUNING library only
+EXPERIMENTAL_SIGNATURES = {
+    "sdt_split_planes_f32": [_p, _p, _i64, _i, _p],
+    "sdt_weight_planes_batched": [_p, _i, _i, _p],
+    "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
+    "sdt_set_pre_tile": [_i],
+    "sdt_c1d_layer_f32": [C.POINTER(C1d), _p],
+    "sdt_c1d_rownorm_partials_f32": [_p, _p, _i, _p, _p, _p, _i64, _i, _f, _f, _p],
+    "sdt_c1d_upsample_bwd_stats_f32": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p],
 }
 
 _lib = None
@@ -144,6 +151,11 @@ def load():
     lib.sdt_conv_dw_workspace_bytes.restype = C.c_int64
     lib.sdt_convsk_plan_bytes.argtypes = [_G, _i]
     lib.sdt_convsk_plan_bytes.restype = C.c_int64
+    if hasattr(lib, "sdt_c1d_layer_f32"):
+        for name, argtypes in EXPERIMENTAL_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
     if hasattr(lib, "sdt_convtab_f32"):  # the -DSDT_TUNING build only (experiment: the 64x64 kernel driven by a plan)
         lib.sdt_convtab_plan_bytes.argtypes = [_G, _i]
         lib.sdt_convtab_plan_bytes.restype = C.c_int64
@@ -151,6 +163,10 @@ def load():
                          ("sdt_convtab_f32", [_p, _p, _p, _p, _p, _p, _p, C.POINTER(NormBwd), _i, _i64, _i64, _i64, _p])):
             getattr(lib, name).argtypes = at
             getattr(lib, name).restype = C.c_int
+    lib.sdt_convsk_dw_plan_bytes.argtypes = [_G]
+    lib.sdt_convsk_dw_plan_bytes.restype = C.c_int64
+    lib.sdt_convsk_dw_workspace_bytes.argtypes = []
+    lib.sdt_convsk_dw_workspace_bytes.restype = C.c_int64
     lib.sdt_convsk_workspace_bytes.argtypes = []
     lib.sdt_convsk_workspace_bytes.restype = C.c_int64
     lib.sdt_last_error.restype = C.c_char_p
@@ -160,6 +176,11 @@ def load():
         raise ImportError("libsdt_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def has_experimental():
+    """True when the loaded library is the -DSDT_TUNING build (carries the experiments' kernels)."""
+    return hasattr(load(), "sdt_c1d_layer_f32")
 
 
 def check(status):

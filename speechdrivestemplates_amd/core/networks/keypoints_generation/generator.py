@@ -4,7 +4,7 @@ channels-last through the gfx950 kernels."""
 import torch
 from torch import nn
 
-from .... import ops, stage1d
+from .... import ops
 from ..building_blocks import ConvNormRelu, conv_head, make_head
 
 # (cin, cout, kernel, stride, padding) of the 8-layer mel encoder, two blocks per stage (generator.py:15-30)
@@ -105,7 +105,8 @@ class SequenceGeneratorCNN(nn.Module):
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         ops.stage_mark("g1d_fwd:begin")
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
-        if stage1d.usable(self, h):
+        stage1d = ops.STAGE1D  # None unless the experiment was switched on (experimental.stage1d.enable(), tuning library)
+        if stage1d is not None and stage1d.usable(self, h):
             # one launch per layer and direction, normalisation / activation / upsample-add applied on load (csrc/conv1d.hip)
             h = stage1d.Gen1dStageFn.apply(h, self, *[p for p in list(self.unet.parameters()) + list(self.decoder.parameters())])
         else:

@@ -1323,15 +1323,26 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt
     }
 }
 
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                      int64_t rows, int C, int rows_per_block) {
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
-        atomicAdd(&out[c], s);
+// out[c] += sum over rows of x[r][c], in a FIXED order (bias gradients; no atomics: bit-identical from run to run).  One workgroup per
+// 64 columns; thread (column, q = 0..3) sums the rows r = q (mod 4) with eight independent partial sums (rows 4 i + q, i mod 8), which are
+// then combined in a fixed tree -- 32 row classes in flight per column instead of one dependent chain.
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (c < C) {
+        int64_t r = q;
+        for (; r + 28 < rows; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += x[(r + 4 * u) * C + c];
+        }
+        for (int u = 0; r < rows; r += 4, ++u) acc[u] += x[r * C + c];
     }
+    part[q][threadIdx.x & 63] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (q == 0 && c < C) out[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1685,6 +1696,10 @@ extern "C" int sdt_conv_dw_det_f32(const float* x, const float* dy, float* dw, c
     SDT_CHECK_ARG(x && dy && dw && workspace, "null pointer");
     SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace | (uintptr_t)dw) % 16) == 0, "operands must be 16-byte aligned");
     SDT_CHECK_ARG(workspace_bytes >= sdt_conv_dw_workspace_bytes(g), "workspace too small");
+    // every element of every slab has to be written by some workgroup: each weight tap appears exactly once in the tap table
+    SDT_CHECK_ARG(g->ntaps == g->Tw, "deterministic weight gradient needs a tap table that covers every weight tap once");
+    for (int t = 0; t < g->ntaps; ++t)
+        for (int u = 0; u < t; ++u) SDT_CHECK_ARG(g->wt[t] != g->wt[u], "deterministic weight gradient needs distinct weight taps");
     const bool vec4 = (g->Cin % 4 == 0) && (g->Cout % 4 == 0);
     launch_dw<64, 64>(vec4, x, dy, dw, *g, (hipStream_t)stream, (float*)workspace);
     SDT_LAUNCH_CHECK();
@@ -1708,8 +1723,7 @@ extern "C" int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_
 
 extern "C" int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* stream) {
     SDT_CHECK_ARG(x && out && rows > 0 && c > 0, "bad argument");
-    const int rpb = rows >= 2048 ? 8 : 64;  // short dependent-load chains: ~256 workgroups on the head conv's (2048, 242) gradient
-    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)cdiv64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, rows, c, rpb);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, x, out, rows, c);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

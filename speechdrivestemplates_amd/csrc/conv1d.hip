@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "../../include/sdt_hip_experimental.h"
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 

@@ -595,6 +595,204 @@ __global__ __launch_bounds__(256) void conv_tab_kernel(const float* __restrict__
 #endif  // SDT_TUNING
 
 // ---------------------------------------------------------------------------------------------
+// Weight gradient on the same machinery:  dW[n, (t, c)] = sum_m dY[m, n] * X[row(m) + tap t, c]  -- a GEMM whose reduction runs over
+// the output positions m (K = M / 32 steps per 128x128 tile of dW, thousands of steps), cut into G / T chunks per tile: one (tile,
+// chunk) unit per persistent workgroup.  Every workgroup stores its partial tile into a slab (plain stores: the consumer is the NEXT
+// kernel) and dw_sk_reduce_kernel adds the slabs of a tile in chunk order to dW: no atomics, bit-identical from run to run -- the deterministic
+// weight gradient is the default, not an option.  Both operands are m-major in HBM (a 16-byte load is 4 consecutive n resp. c of one
+// m), so the LDS tiles are [k = m][128] and an MFMA operand is one conflict-free ds_read_b32 (row k + lane / 32, column lane % 32).
+// The per-row tables of the FORWARD geometry's plan give, per m, the dY row offset, the X row offset and the mask of taps that fall
+// outside X; they are read two K steps ahead of the data they address.
+template <int WPC>
+__global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY, const sk_args P,
+                                                             const int K, const int ncol, const int nchunk, float* __restrict__ slabs) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, RP = 4, NM = TM * TN * 4;  // RP: 16-byte loads per thread, operand and K step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS tiles [k / 4][row][k % 4]: a thread loads 4 CONSECUTIVE m (= k) of its 4-column chunk, transposes the 4x4 block in registers
+    // (register renaming + moves) and stores, per column, the 4 k values as one 16-byte vector -- so an MFMA operand fragment is one
+    // ds_read_b128 of 4 k values of a row, exactly as in the forward kernel (a [k][row] tile costs one ds_read_b32 per MFMA operand:
+    // 8x the LDS instructions, measured 5-9 % slower than the atomics kernel it was meant to replace)
+    float* sA = smem;                // [2][8][BM][4]   dY tile
+    float* sB = smem + 2 * 32 * BM;  // [2][8][BN][4]   gathered X tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cq = tid & 31, kg = tid >> 5;  // loader: 16-byte chunk cq of the k rows 4 kg .. 4 kg + 3
+    // Work unit = (tile, chunk of the K loop): workgroup u does chunk u / T of tile u % T, so the workgroups that run side by side
+    // (consecutive u on one XCD) walk the SAME rows m at the same time, each for its own tile: dY and X rows come out of the L2 for
+    // all but one of them.  (A stream-K split with the tile as the outer index made every workgroup stream private rows: 1.5 GB of
+    // L2 misses per launch on the 3x3 layers.)
+    const int G = P.G, T = P.T;
+    const int bid = blockIdx.x;
+    const int u = (bid & 7) * (G >> 3) + (bid >> 3);
+    if (u >= T * nchunk) return;
+    const int chunk = u / T, tile = u - chunk * T;
+    const sk_class& cl = P.cls[0];
+    const int Cin = __builtin_amdgcn_readfirstlane(cl.Cin);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)P.ybytes, 0x00020000);
+    // fragment read offsets (floats): lane half h reads the k group 2 j + h of its row
+    const int fa = ((lane >> 5) * BM + wm * 64 + (lane & 31)) * 4, fb = ((lane >> 5) * BN + wn * 64 + (lane & 31)) * 4;
+    {
+        const int a = (int)((long)chunk * K / nchunk), b = (int)((long)(chunk + 1) * K / nchunk);
+        const int nt = tile / ncol, ct = tile - nt * ncol;
+        const int n0 = nt * BM, j0 = ct * BN;
+        // this thread's B column: 4 consecutive channels of ONE tap
+        const int j = j0 + cq * 4;
+        const int t = j / Cin, c = j - t * Cin;
+        const unsigned acol = (unsigned)(n0 + cq * 4) * 4u;
+        const unsigned bcol = (unsigned)cl.ashift[t] + (unsigned)c * 4u;
+        const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
+        int4 ri[RP];
+        f32x4 ra[RP], rb[RP];
+        int mrow = (a * 32) + 4 * kg;  // first row of the next table read
+        auto load_rows = [&]() {
+#pragma unroll
+            for (int i = 0; i < RP; ++i) ri[i] = P.rowinfo[mrow + i];
+            mrow += 32;
+        };
+        int left = b - a;
+        auto load = [&]() {  // data of the step whose table rows are in ri; past the end of the segment: masked
+            const unsigned off_mask = left > 0 ? 0u : SK_OOB;
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const unsigned oa = ((unsigned)ri[i].z + acol) | off_mask;  // rows past M carry SK_OOB in z already
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
+                const unsigned ob = (((unsigned)ri[i].x + bcol) & 0x7fffffffu) | (((unsigned)ri[i].y << sh) & 0x80000000u) | off_mask;
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
+            }
+            --left;
+        };
+        auto stage = [&](int buf) {  // 4x4 register transpose: column e of the block = the 4 k values of row (chunk * 4 + e)
+            float* wA = sA + buf * 32 * BM + (kg * BM + cq * 4) * 4;
+            float* wB = sB + buf * 32 * BN + (kg * BN + cq * 4) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 va = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+                const f32x4 vb = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
+                *(f32x4*)&wA[e * 4] = va;
+                *(f32x4*)&wB[e * 4] = vb;
+            }
+        };
+        f32x16 acc[1][TM][TN], tot[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[0][i][jj][q] = 0.f, tot[i][jj][q] = 0.f;
+        // fill: tables of step a -> data of step a -> LDS[0]; tables / data of step a+1 -> registers; tables of step a+2
+        load_rows();
+        load();
+        load_rows();
+        stage(0);
+        load();
+        load_rows();
+        __syncthreads();
+        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+#define DW_READ(A, B, PA, PB, J)                                                                                            \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = *(const f32x4*)((PA) + tm * 32 * 4 + (J) * 2 * BM * 4);        \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) B[tn] = *(const f32x4*)((PB) + tn * 32 * 4 + (J) * 2 * BN * 4)
+#define DW_MFMA(A, B)                                                                                                       \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                         \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                                   \
+            acc[0][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], B[tn][e], acc[0][tm][tn], 0, 0, 0)
+        DW_READ(a0, b0, sA + fa, sB + fb, 0);
+        auto step = [&](const int cur) {
+            const float* pa = sA + cur * 32 * BM + fa;
+            const float* pb = sB + cur * 32 * BN + fb;
+            // as the forward kernel's step: k-group 0 + fragments of k-group 1 + registers (step+1) -> LDS[next] + the global loads of
+            // step+2 + the table rows of step+3
+            DW_READ(a1, b1, pa, pb, 1);
+            stage(cur ^ 1);
+            load();
+            load_rows();
+            DW_MFMA(a0, b0);
+            DW_READ(a0, b0, pa, pb, 2);
+            DW_MFMA(a1, b1);
+            DW_READ(a1, b1, pa, pb, 3);
+            DW_MFMA(a0, b0);
+            {
+                constexpr int NF = TM + TN, NW = 2 * RP, NL = 3 * RP;  // fragment reads / LDS stores / global loads (data + tables)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+#pragma unroll
+                for (int q = 0; q < NW; ++q) { SK_SGB(0x8, 1); SK_SGB(0x200, 1); }
+#pragma unroll
+                for (int q = 0; q < NL; ++q) { SK_SGB(0x8, 1); SK_SGB(0x20, 1); }
+                constexpr int u1 = NF + NW + NL;  // 24 > 16: runs into k-group 1
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+                constexpr int u2 = u1 + NF;
+                if constexpr (u2 < 2 * NM) SK_SGB(0x8, 2 * NM - u2);
+#pragma unroll
+                for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+                SK_SGB(0x8, NM - NF);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my writes of LDS[next] are done
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            DW_READ(a0, b0, sA + (cur ^ 1) * 32 * BM + fa, sB + (cur ^ 1) * 32 * BN + fb, 0);
+            DW_MFMA(a1, b1);
+#pragma unroll
+            for (int q = 0; q < TM + TN; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+            SK_SGB(0x8, NM - (TM + TN));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto flush = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        tot[i][jj][q] += acc[0][i][jj][q];
+                        acc[0][i][jj][q] = 0.f;
+                    }
+        };
+        const int nsteps = b - a;
+        for (int s = 0; s < nsteps; ++s) {
+            if (s > 0 && ((a + s) % SK_CHUNK) == 0) flush();  // chunks aligned to the tile's own step index
+            step(s & 1);
+        }
+        flush();
+#undef DW_READ
+#undef DW_MFMA
+        // partial tile -> slab of this unit (natural [n][j] layout: the reduce kernel reads it coalesced)
+        float* slab = slabs + (size_t)u * (BM * BN);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int nl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                    const int jl = wn * 64 + tn * 32 + (lane & 31);
+                    slab[nl * BN + jl] = tot[tm][tn][q];
+                }
+    }
+}
+
+// dw[n, wt(t), c] += the slabs of tile (nt, ct), chunk 0 first.  One thread per 4 consecutive columns of a tile row.
+__global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, const sk_args P, const int ncol,
+                                                           const int nchunk, const int Cout, const int Tw) {
+    constexpr int BM = 128, BN = 128;
+    const int tile = blockIdx.x >> 4;                      // 16 workgroups per tile
+    const int e = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile
+    const int nl = e >> 5, jl = (e & 31) * 4;
+    const int nt = tile / ncol, ct = tile - nt * ncol;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunk; ++ch) sum += *(const f32x4*)(slabs + ((size_t)ch * P.T + tile) * (BM * BN) + nl * BN + jl);
+    const sk_class& cl = P.cls[0];
+    const int j = ct * BN + jl, t = j / cl.Cin, c = j - t * cl.Cin;
+    const int n = nt * BM + nl;
+    if (n < Cout) {
+        float* d = dw + ((size_t)n * Tw + cl.dyx[t]) * cl.Cin + c;  // dyx[] of a weight-gradient plan holds wt[t]
+        *(f32x4*)d += sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side: the plan.  Layout of the blob (all int32, offsets in ints from the start of the blob):
 //   [0] magic  [1] BM  [2] BN  [3] G  [4] ncls  [5] nnb  [6] T  [7] S  [8] rows (total, padded)  [9] n m-tiles (total)
 //   [10] off rowinfo  [11] off tileinfo  [12] off tilecum  [13] off range_tile  [14] off classes  [15] total ints
@@ -924,3 +1122,108 @@ extern "C" int sdt_convtab_f32(const float* x, const float* w, const float* bias
     return SDT_OK;
 }
 #endif  // SDT_TUNING
+
+// ---- weight gradient through the stream-K machinery
+extern "C" int sdt_convsk_dw_supported(const sdt_conv_geom* g) {
+    if (!g) return 0;
+    const sdt_conv_geom* gs[1] = {g};
+    if (!sk_supported(gs, 1, 128, 64)) return 0;  // Cin % 32, sizes
+    if (g->Cout % 128 != 0 || (g->ntaps * g->Cin) % 128 != 0 || g->ntaps != g->Tw) return 0;
+    if (g->osy != 1 || g->osx != 1 || g->ooy != 0 || g->oox != 0 || g->Hy != g->Ho || g->Wy != g->Wo) return 0;  // dense dY
+    for (int t = 0; t < g->ntaps; ++t)
+        for (int u = 0; u < t; ++u)
+            if (g->wt[t] == g->wt[u]) return 0;
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    const int64_t K = cdiv64(M, 32), T = (int64_t)(g->Cout / 128) * ((int64_t)g->ntaps * g->Cin / 128);
+    const int G = 256 * g_sk_wpc;
+    return T <= G && K >= 8 * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 steps each
+}
+// plan of a weight gradient: header + per-row table of the forward geometry (rows padded to a multiple of 32 + two extra steps)
+extern "C" int64_t sdt_convsk_dw_plan_bytes(const sdt_conv_geom* g) {
+    if (!sdt_convsk_dw_supported(g)) return -1;
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    const int64_t rows = (cdiv64(M, 32) + 3) * 32;
+    return (SK_HDR + rows * 4 + SK_CLS_INTS) * 4;
+}
+extern "C" int64_t sdt_convsk_dw_workspace_bytes(void) { return (int64_t)512 * 128 * 128 * 4; }
+extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes) {
+    SDT_CHECK_ARG(sdt_convsk_dw_supported(gp), "geometry not supported by the stream-K weight-gradient kernel");
+    SDT_CHECK_ARG(out != nullptr && out_bytes >= sdt_convsk_dw_plan_bytes(gp), "plan buffer too small");
+    const sdt_conv_geom& g = *gp;
+    int* P = (int*)out;
+    const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+    const int64_t K = cdiv64(M, 32), rows = (K + 3) * 32;
+    const int ncol = g.ntaps * g.Cin / 128;
+    const int64_t T = (int64_t)(g.Cout / 128) * ncol;
+    const int G = 256 * g_sk_wpc;
+    int* rowinfo = P + SK_HDR;
+    for (int64_t m = 0; m < rows; ++m) {
+        int* ri = rowinfo + m * 4;
+        if (m >= M) {
+            ri[0] = 0, ri[1] = -1, ri[2] = (int)SK_OOB, ri[3] = -1;
+            continue;
+        }
+        const int ox = (int)(m % g.Wo), tq = (int)(m / g.Wo);
+        const int oy = tq % g.Ho, b = tq / g.Ho;
+        const int iy0 = oy * g.sy, ix0 = ox * g.sx;
+        unsigned inval = 0x80000000u;
+        for (int t = 0; t < g.ntaps; ++t)
+            if (!((unsigned)(iy0 + g.dy[t]) < (unsigned)g.Hi && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.Wi)) inval |= 1u << t;
+        ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * 4));
+        ri[1] = (int)inval;
+        ri[2] = (int)(m * g.Cout * 4);
+        ri[3] = 0;
+    }
+    int* cp = P + SK_HDR + rows * 4;
+    cp[0] = g.Hi, cp[1] = g.Wi, cp[2] = g.Cin, cp[3] = g.Cout, cp[4] = g.ntaps, cp[5] = g.Cin / SK_BK;
+    cp[6] = 0, cp[7] = 0, cp[8] = 0, cp[9] = 0, cp[10] = g.Tw;
+    for (int t = 0; t < SDT_MAX_TAPS; ++t) {
+        const bool on = t < g.ntaps;
+        cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * 4 : 0;
+        cp[11 + SDT_MAX_TAPS + t] = on ? g.wt[t] : 0;  // the weight-gradient kernels read wt[t] here
+        cp[11 + 2 * SDT_MAX_TAPS + t] = 0;
+    }
+    P[0] = SK_MAGIC + 1, P[1] = 128, P[2] = 128, P[3] = G, P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
+    P[10] = SK_HDR, P[11] = 0, P[12] = 0, P[13] = 0, P[14] = (int)(SK_HDR + rows * 4), P[15] = (int)(SK_HDR + rows * 4 + SK_CLS_INTS);
+    return SDT_OK;
+}
+
+// dw (Cout, Tw, Cin) += the weight gradient of the geometry the plan was built for; workspace: sdt_convsk_dw_workspace_bytes() bytes,
+// contents irrelevant (every slab that is read has been written by this launch).  Deterministic: fixed split, fixed summation order.
+extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, const void* plan_host, const void* plan_dev, void* workspace,
+                                 int64_t xbytes, int64_t ybytes, void* stream) {
+    SDT_CHECK_ARG(x && dy && dw && plan_host && plan_dev && workspace, "null pointer");
+    const int* P = (const int*)plan_host;
+    SDT_CHECK_ARG(P[0] == SK_MAGIC + 1, "not a weight-gradient plan");
+    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
+    SDT_CHECK_ARG(xbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536, "tensor sizes out of range");
+    sk_args A;
+    A.G = P[3], A.ncls = 1, A.nnb = P[5], A.T = P[6], A.S = P[7];
+    const int K = P[9], ncol = P[5];
+    const int* D = (const int*)plan_dev;
+    A.rowinfo = (const int4*)(D + P[10]);
+    A.tileinfo = nullptr, A.tilecum = nullptr, A.range_tile = nullptr, A.slabs = nullptr, A.flags = nullptr, A.err = nullptr, A.epoch = 0;
+    const int* cp = P + P[14];
+    sk_class& k = A.cls[0];
+    k.Hi = cp[0], k.Wi = cp[1], k.Cin = cp[2], k.Cout = cp[3], k.ntaps = cp[4], k.nkc = cp[5];
+    k.tile_begin = 0, k.nmb = 0, k.row_begin = 0, k.mt_begin = 0, k.Tw = cp[10];
+    for (int t = 0; t < SDT_MAX_TAPS; ++t) k.ashift[t] = cp[11 + t], k.dyx[t] = cp[11 + SDT_MAX_TAPS + t], k.bshift[t] = 0;
+    for (int c = 1; c < SK_MAXC; ++c) A.cls[c] = A.cls[0];
+    A.xbytes = (unsigned)xbytes, A.wbytes = 0, A.ybytes = (unsigned)ybytes;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * 32 * (128 + 128) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)convsk_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)convsk_dw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nchunk = A.G / A.T;  // T * nchunk <= G workgroups have work (>= 98 % of them on this network's layers)
+    if (A.G == 256)
+        hipLaunchKernelGGL((convsk_dw_kernel<1>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace);
+    else
+        hipLaunchKernelGGL((convsk_dw_kernel<2>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace);
+    hipLaunchKernelGGL(dw_sk_reduce_kernel, dim3(A.T * 16), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}

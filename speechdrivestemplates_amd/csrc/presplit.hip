@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "../../include/sdt_hip_experimental.h"
 
 #define BKP 32  // K chunk (channels) per step
 #define SDT_OOB 0x80000000u

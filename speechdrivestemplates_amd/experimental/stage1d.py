@@ -14,13 +14,14 @@ import os
 
 import torch
 
-from . import _lib, ops
-from ._lib import check
+from .. import _lib, ops
+from .._lib import check
+from . import require
 
 # Opt-in (SDT_STAGE1D=1): measured on MI355X (profiles/r02_conv1d_stage.txt) the fused stage shortens the exposed Conv1d chains
 # (0.85 -> 0.81 ms per step) but moves more work onto the weight-gradient side stream, and the whole step comes out 2 % SLOWER
 # (3950 vs 4040 clips/s), so the per-block path stays the default.
-ENABLED = os.environ.get("SDT_STAGE1D", "0") == "1"
+ENABLED = False  # switched by enable() (bench.py --fused-conv1d, the tests); no environment variable
 _p = ops._p
 
 
@@ -83,7 +84,17 @@ def usable(gen, h0):
 # 36-60 us per launch and the whole step lost 8 % -- on a multi-XCD part the device-scope release / acquire around the arrival
 # counter is an L2 write-back + invalidate of the whole XCD (the slices of a tile run on different XCDs), which also hurts the
 # kernels running next to it on the side stream (profiles/r02_conv1d_stage.txt).
-SPLITK = os.environ.get("SDT_STAGE1D_SPLITK", "0") == "1"
+SPLITK = False
+
+
+def enable(on=True):
+    """Route the generator's Conv1d stage through c1d_kernel (needs the tuning library)."""
+    global ENABLED
+    import sys
+    if on:
+        require("the fused Conv1d stage")
+    ENABLED = bool(on)
+    ops.STAGE1D = sys.modules[__name__] if on else None
 _WS = {}        # device index -> (slab workspace, arrival counters): launches of one stream use it one after the other
 
 

@@ -396,6 +396,7 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=N
 # --------------------------------------------------------------------------------------------
 # persistent stream-K conv (csrc/convsk.hip): plans and workspaces
 # --------------------------------------------------------------------------------------------
+STAGE1D = None        # experiment hook: experimental.stage1d.enable() puts its module here (generator.py asks it)
 USE_STREAMK = True   # the Conv2d forward / input-gradient launches of the audio encoder go through sdt_convsk_f32 (exact fp32 math)
 _SK_PLANS = {}       # (id of the cached geometry object(s), rows_per_group, bwd_groups, device index) -> _SKPlan | None
 _SK_WS = {}          # (device index, raw stream) -> [workspace tensor, epoch]
@@ -419,11 +420,16 @@ class _SKPlan:
 # Which launches take the stream-K kernel (measured per layer on one MI355X, profiles/r03_streamk_ab.txt): it wins where a tile's K loop
 # is long enough to amortise the tile switch of a 1-2-workgroup-per-CU kernel (set-up + pipeline fill + epilogue, ~10 us per 128x128
 # tile) and loses on the 64-wide outputs and on the 2x2-tap parity classes of strided input gradients, which stay with the 64x64 kernel.
-STREAMK_MIN_STEPS = 48   # K steps (of 32) per output tile, nominal: taps * Cin / 32
+# FORWARD launches all take it (where it loses, L4: -3 %, L1 / L2: par): its chunked accumulation is what puts the forward error of
+# every Conv2d layer level with the reference's blocked sums (tests/test_fullsize_gpu.py::test_b32_forward_stage_error_table).
+STREAMK_MIN_STEPS = 48   # input gradients: K steps (of 32) per output tile, nominal: taps * Cin / 32
 STREAMK_MIN_COUT = 128
+STREAMK_ALL_FORWARD = True
 
 
-def _sk_wanted(g0):
+def _sk_wanted(g0, forward=False):
+    if forward and STREAMK_ALL_FORWARD:
+        return True
     return g0.Cout % STREAMK_MIN_COUT == 0 and g0.ntaps * (g0.Cin // 32) >= STREAMK_MIN_STEPS
 
 
@@ -431,16 +437,16 @@ USE_TAB = False      # experiment (tuning library only): 2-D launches that do no
 TAB_CHUNK = 8        # K steps per accumulation chunk of that kernel (0: one accumulator over the whole K loop)
 
 
-def _sk_plan(garr, n, rpg, bwd_groups, dev):
+def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the plan (stream-K where that kernel is wanted, else the
     64x64 table-driven kernel's) or None when the pack qualifies for neither."""
-    key = (id(garr), int(rpg), int(bwd_groups), dev.index)
+    key = (id(garr), int(rpg), int(bwd_groups), dev.index, bool(forward))
     plan = _SK_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
         plan = None
         g0 = garr if isinstance(garr, ConvGeom) else garr[0]
-        kind = "sk" if (USE_STREAMK and lib.sdt_convsk_supported(garr, n) and _sk_wanted(g0)) else (
+        kind = "sk" if (USE_STREAMK and lib.sdt_convsk_supported(garr, n) and _sk_wanted(g0, forward)) else (
             "tab" if (USE_TAB and g0.Hi > 1 and lib.sdt_convtab_supported(garr, n)) else None)
         if kind is not None:
             try:
@@ -484,6 +490,43 @@ def _sk_launch(plan, x4, ws_w, bias, y, stats, nb, st):
                               x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
 
 
+_SK_DW_PLANS = {}
+_SK_DW_WS = {}
+USE_STREAMK_DW = True  # weight gradients of the 2-D layers with Cout % 128 == 0 through sdt_convsk_dw_f32 (deterministic)
+
+
+class _SKDwPlan:
+    __slots__ = ("host", "dev", "keep")
+
+    def __init__(self, g, dev):
+        import ctypes as C
+        lib = _lib.load()
+        nbytes = lib.sdt_convsk_dw_plan_bytes(g)
+        self.host = (C.c_int32 * (nbytes // 4))()
+        check(lib.sdt_convsk_dw_plan_build(g, C.addressof(self.host), nbytes))
+        self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
+        self.keep = g
+
+
+def _sk_dw_plan(g, dev):
+    key = (id(g), dev.index)
+    plan = _SK_DW_PLANS.get(key, False)
+    if plan is False:
+        plan = _SKDwPlan(g, dev) if _lib.load().sdt_convsk_dw_supported(g) else None
+        _SK_DW_PLANS[key] = plan
+        if plan is None:
+            _SK_DW_PLANS[("keep", id(g))] = g
+    return plan
+
+
+def _sk_dw_workspace(dev, st):
+    key = (dev.index, int(st))
+    ws = _SK_DW_WS.get(key)
+    if ws is None:
+        ws = _SK_DW_WS[key] = torch.empty(_lib.load().sdt_convsk_dw_workspace_bytes() // 4, device=dev, dtype=torch.float32)
+    return ws
+
+
 def _sk_name(plan):
     return ("convsk_kernel<%d, %d>" if plan.kind == "sk" else "conv_tab_kernel<%d, %d>") % (plan.host[1], plan.host[2])
 
@@ -504,7 +547,7 @@ def conv_forward(x_cl, w, bias, stride, pad):
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
     st = _stream()
     if (USE_STREAMK or USE_TAB) and w.dim() == 4 and _CONV_MATH_NOW[0] == 0:
-        plan = _sk_plan(g, 1, 0, 1, x_cl.device)
+        plan = _sk_plan(g, 1, 0, 1, x_cl.device, forward=True)
         if plan is not None:
             _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x4, ws, bias, y, None, None, st), name=_sk_name(plan))
             return y
@@ -522,12 +565,12 @@ CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
 # In 'bf16x6' mode the 2-D chain can run on PRE-SPLIT bf16 planes (sdt_conv_taps_pre_f32) that the producing kernels emit.  OFF by
 # default: measured end to end it is SLOWER than splitting inside the conv kernels (4060 vs 4445 clips/s on one box, f32 4000):
 # the pre kernel reaches 120 TFLOP/s in the step against 125 for the split-in-kernel variant, and every normalisation pass writes
-# 1.5x more bytes.  SDT_PRESPLIT=1 enables it (tests/test_fullsize_gpu.py covers both forms).
-PRESPLIT = os.environ.get("SDT_PRESPLIT", "0") == "1"
+# 1.5x more bytes.  ops.PRESPLIT = True with the tuning library enables it (tests/test_fullsize_gpu.py covers both forms).
+PRESPLIT = False  # experiment (speechdrivestemplates_amd/experimental): needs the -DSDT_TUNING library; no environment switch
 
 
 def presplit_on():
-    return PRESPLIT and _CONV_MATH_NOW[0] == 6
+    return PRESPLIT and _CONV_MATH_NOW[0] == 6 and _lib.has_experimental()
 _CONV_MATH_NOW = [0]  # mirror of the library's process-wide setting (only set_conv_math changes it)
 
 
@@ -566,7 +609,7 @@ class WeightMirrors:
             wt = torch.empty((cin, taps, cout), device=p.device, dtype=torch.float32)
             descs.append(_lib.WtDesc(ws.data_ptr(), wt.data_ptr(), cout, taps, cin, tiles))
             planes = None
-            if p.dim() == 4 and cin % 32 == 0 and cout % 32 == 0:  # 2-D layers the pre-split conv kernel can take
+            if PRESPLIT and p.dim() == 4 and cin % 32 == 0 and cout % 32 == 0:  # experiment only: 2-D layers the pre-split conv kernel can take
                 planes = (torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16),
                           torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16))
                 pdescs.append(_lib.WpDesc(ws.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), cout, taps, cin, ptiles))
@@ -737,9 +780,14 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
     if gws.data_ptr() != gw.data_ptr():
         raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
     st = _stream()
-    if DETERMINISTIC_DW:
-        if _CONV_MATH_NOW[0] != 0:
-            raise RuntimeError("DETERMINISTIC_DW needs conv math f32")
+    if USE_STREAMK_DW and w.dim() == 4 and _CONV_MATH_NOW[0] == 0:
+        plan = _sk_dw_plan(g, x4.device)
+        if plan is not None:
+            ws = _sk_dw_workspace(x4.device, st)
+            _conv_launch("dW", True, g, lambda: lib.sdt_convsk_dw_f32(_p(x4), _p(gy4), _p(gws), plan.host, _p(plan.dev), _p(ws),
+                                                                      x4.numel() * 4, gy4.numel() * 4, st), name="convsk_dw_kernel")
+            return
+    if DETERMINISTIC_DW and _CONV_MATH_NOW[0] == 0 and g.ntaps == g.Tw:  # (the bf16 modes have no ordered variant: atomics)
         nbytes = lib.sdt_conv_dw_workspace_bytes(g)
         ws = torch.empty(nbytes // 4, device=x4.device, dtype=torch.float32)  # on the launching stream: freed blocks are reused in order
         _conv_launch("dW", w.dim() == 4, g, lambda: lib.sdt_conv_dw_det_f32(_p(x4), _p(gy4), _p(gws), g, _p(ws), nbytes, st))
@@ -754,9 +802,11 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
 # optimiser step.
 OVERLAP_DW = True
 OVERLAP_DW_MIN_FLOPS = 4e9
-# Bit-reproducible weight gradients: row-range slabs + an ordered reduce instead of fp32 atomics (sdt_conv_dw_det_f32).  Off by
-# default: measured cost in DESIGN.md / profiles/r02_deterministic_dw.txt.
-DETERMINISTIC_DW = os.environ.get("SDT_DETERMINISTIC_DW", "0") == "1"
+# Bit-reproducible weight gradients (the reference sets cudnn.deterministic = True, main.py:37-38): the 2-D layers with Cout % 128 == 0
+# go through the stream-K weight gradient (sdt_convsk_dw_f32, ordered slab reduce, as fast as the atomics kernel), every other layer
+# through row-range slabs + an ordered reduce (sdt_conv_dw_det_f32, -0.9 % on the step when it carried all layers,
+# profiles/r02_deterministic_dw.txt).  False: fp32 atomics (the round-1/2 default).
+DETERMINISTIC_DW = True
 _SIDE = {}
 
 
@@ -926,7 +976,7 @@ class ConvStatsFn(torch.autograd.Function):
                                                                  rpg, None, st), pre=True)
             in_holder.zp = None  # x has exactly one consumer in this chain: the planes can go back to the allocator
         else:
-            plan = _sk_plan(g, 1, rpg, 1, x_cl.device) if ((USE_STREAMK or USE_TAB) and _CONV_MATH_NOW[0] == 0 and rpg >= 32) else None
+            plan = _sk_plan(g, 1, rpg, 1, x_cl.device, forward=True) if ((USE_STREAMK or USE_TAB) and _CONV_MATH_NOW[0] == 0 and rpg >= 32) else None
             if plan is not None:
                 _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x_cl, ws, None, y, sums, None, st), name=_sk_name(plan))
             else:

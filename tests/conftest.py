@@ -11,11 +11,19 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+    config.addinivalue_line("markers", "experimental: covers an experiment that lives in the -DSDT_TUNING library only "
+                                       "(run with SDT_HIP_LIB=speechdrivestemplates_amd/lib/libsdt_hip_tuning.so)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
+        from speechdrivestemplates_amd import experimental
+        if not experimental.available():
+            skip_exp = pytest.mark.skip(reason="experiment: needs the -DSDT_TUNING library (SDT_HIP_LIB=.../libsdt_hip_tuning.so)")
+            for item in items:
+                if "experimental" in item.keywords:
+                    item.add_marker(skip_exp)
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
@@ -33,3 +41,38 @@ def golden_modules():
 def golden_traj():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "trajectories_B4.npz")))
+
+
+# ---------------------------------------------------------------------------------------------
+# Calibrated tolerances ("tolerances 30-100x looser than what is measured: a regression of 10x would pass everything").
+# Every `check(name, got, ref, tol)` of the GPU tests keeps its STATED tolerance `tol` (the claim) and is additionally held to 10x the
+# error this very check measured when tests/golden/margins.json was recorded (the kernels are deterministic: the same seeded inputs give
+# the same error on every box, up to the order noise of the few fp32-atomic opt-out paths), with a floor of 2e-7 (fp32 resolution).
+# Re-record after an intended numerical change:  SDT_RECORD_MARGINS=tests/golden/margins.json python -m pytest tests -m gpu
+MARGIN_FACTOR, MARGIN_FLOOR = 10.0, 2e-7
+_MARGINS, _SEEN = None, {}
+
+
+def _margins():
+    global _MARGINS
+    if _MARGINS is None:
+        import json
+        path = os.path.join(GOLDEN, "margins.json")
+        _MARGINS = json.load(open(path)) if os.path.exists(path) else {}
+    return _MARGINS
+
+
+def calibrated_bound(name, err, tol):
+    """The bound `err` has to stay under: min(stated tol, 10 x recorded error); records `err` when SDT_RECORD_MARGINS is set."""
+    import json
+    node = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" (")[0]
+    n = _SEEN[(node, name)] = _SEEN.get((node, name), 0) + 1
+    key = "%s :: %s #%d" % (node, name, n)
+    rec = os.environ.get("SDT_RECORD_MARGINS")
+    if rec:
+        data = json.load(open(rec)) if os.path.exists(rec) else {}
+        data[key] = max(float(err), data.get(key, 0.0)) if os.environ.get("SDT_RECORD_MARGINS_MAX") else float(err)
+        json.dump(data, open(rec, "w"), indent=0, sort_keys=True)
+        return tol
+    m = _margins().get(key)
+    return tol if m is None else min(tol, max(MARGIN_FACTOR * m, MARGIN_FLOOR))

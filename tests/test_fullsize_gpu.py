@@ -28,10 +28,13 @@ the whole "100x worse" gradient gap (the head-bias gradient is off by exactly 2/
      so the comparison is between the two error DISTRIBUTIONS over the gradient tensors of a step, anchored on the reference's
      worst tensor E_ref = max_k e_ref[k] (its only statistic that is stable from batch to batch):
         max_k e_hip[k]    <= K_MAX * E_ref
-        median_k e_hip[k] <= max(K_MED * median_k e_ref[k], E_ref / 4)
-        ||g_hip - g_f64||_2 / ||g_f64||_2 <= max(K_L2 * (same for ref32), E_ref / 4)      (all tensors concatenated)
-     with e[k] = max|g[k] - g_f64[k]| / max|g_f64[k]|: the typical HIP gradient tensor is closer to float64 than a quarter of the
-     reference's own worst one, and no HIP tensor is further than 3x that worst one;
+        median_k e_hip[k] <= max(K_MED * median_k e_ref[k], E_ref / 20)
+        ||g_hip - g_f64||_2 / ||g_f64||_2 <= max(K_L2 * (same for ref32), E_ref / 20)      (all tensors concatenated)
+     with e[k] = max|g[k] - g_f64[k]| / max|g_f64[k]|: the typical HIP gradient tensor is closer to float64 than a twentieth of the
+     reference's own worst one (round 2: a quarter), and no HIP tensor is further than 3x that worst one.  Round 3, with the
+     chunked accumulation of the stream-K kernels: sdt_bp B=32 median 7.5e-4 vs 4.5e-4 (1.7x; was 1.3e-3), whole-gradient L2 1.4x
+     (was 3.2x) -- both now inside the plain 2x bar; sdt_vae B=32 still shows "HIP has events, the reference has none on this
+     batch" (median 2.0e-4 vs 5.9e-7) while its whole-gradient L2 error is BELOW the reference's (2.95e-4 vs 3.87e-4);
   3. on the B=4 fixtures (no oracle in the loop, float64 gradients stored at the float64 run's own signs) L1 sign decisions
      that differ from the float64 run are COUNTED from the stored full predictions and each one is allowed its measured
      worst-case effect (FLIP_ALLOW of a tensor's max-norm); with zero differing decisions the bar is the one of item 2.
@@ -51,7 +54,7 @@ from test_model_gpu import _make_pipeline, sl
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-K_FWD = 3.0   # per forward quantity: HIP at most this many times further from float64 than the fp32 reference
+K_FWD = 2.0   # per forward quantity: HIP at most this many times further from float64 than the fp32 reference (round 2: 3.0)
 K_MED, K_MAX, K_L2 = 2.0, 3.0, 2.0  # gradient error distributions over the tensors of a step (see module docstring)
 FLIP_ALLOW = 0.1  # B=4 fixtures: measured worst effect of ONE differing L1 sign on a gradient tensor (8.8e-2 of max, head weight)
 N_CLIPS = 64
@@ -110,7 +113,7 @@ def _check_forward(title, rows):
     assert not bad, (title, bad)
 
 
-def _check_grad_distributions(title, e_hip, e_ref, l2_hip=None, l2_ref=None, allow=0.0, k_med=K_MED, k_max=K_MAX, anchor=0.25):
+def _check_grad_distributions(title, e_hip, e_ref, l2_hip=None, l2_ref=None, allow=0.0, k_med=K_MED, k_max=K_MAX, anchor=0.05):
     """e_hip / e_ref: {tensor name: max|g - g_f64| / max|g_f64|}.  ``allow``: extra absolute allowance on every statistic (B=4
     fixtures: FLIP_ALLOW per counted differing L1 sign decision)."""
     K_MED, K_MAX = k_med, k_max  # noqa: N806 (shadow the module defaults for this call)
@@ -118,11 +121,11 @@ def _check_grad_distributions(title, e_hip, e_ref, l2_hip=None, l2_ref=None, all
     eh, er = np.array([e_hip[k] for k in names]), np.array([e_ref[k] for k in names])
     med_h, med_r, max_h, max_r = np.median(eh), np.median(er), eh.max(), er.max()
     lines = ["%s -- gradient error distributions over %d tensors (allowance %.1e):" % (title, len(names), allow),
-             "      median  hip %.3e  ref32 %.3e  (bar max(%.0fx, E_ref/4))      max  hip %.3e  E_ref = ref32 %.3e  (bar %.0fx)"
-             % (med_h, med_r, K_MED, max_h, max_r, K_MAX)]
+             "      median  hip %.3e  ref32 %.3e  (bar max(%.0fx, E_ref/%.0f))      max  hip %.3e  E_ref = ref32 %.3e  (bar %.0fx)"
+             % (med_h, med_r, K_MED, 1.0 / anchor, max_h, max_r, K_MAX)]
     ok = med_h <= max(K_MED * med_r, max_r * anchor) + allow and max_h <= K_MAX * max_r + allow
     if l2_hip is not None:
-        lines.append("      whole-gradient relative L2 error  hip %.3e  ref32 %.3e  (bar max(%.0fx, E_ref/4))" % (l2_hip, l2_ref, K_L2))
+        lines.append("      whole-gradient relative L2 error  hip %.3e  ref32 %.3e  (bar max(%.0fx, E_ref/%.0f))" % (l2_hip, l2_ref, K_L2, 1.0 / anchor))
         ok = ok and l2_hip <= max(K_L2 * l2_ref, max_r * anchor) + allow
     for k, a, b in zip(names, eh, er):
         lines.append("      %-60s hip %.3e  ref32 %.3e  ratio %8.2f" % (k, a, b, a / max(b, 1e-30)))
@@ -244,12 +247,12 @@ def test_b32_bf16_mode_vs_oracle():
     assert worst_rel <= 0.25 and worst_cos >= 0.97, [r for r in rows if r[1] > 0.25 or r[2] < 0.97]
 
 
-@pytest.mark.parametrize("presplit", [False, True], ids=["split-in-kernel", "pre-split-planes"])
+@pytest.mark.parametrize("presplit", [False, pytest.param(True, marks=pytest.mark.experimental)], ids=["split-in-kernel", "pre-split-planes"])
 def test_b32_bf16x6_mode_meets_the_fp32_bar(presplit):
     """'bf16x6' (operands split exactly into three bf16 pieces, six MFMA products, fp32 accumulation) claims fp32-equivalent
     products: at B=32 it has to pass the SAME float64-calibrated checks as the exact-fp32 MFMA path -- in both of its forms, the
     split inside the conv kernels (the faster one end to end, what `--conv-math bf16x6` runs) and the pre-split operand pipeline
-    (ops.PRESPLIT / SDT_PRESPLIT=1)."""
+    (ops.PRESPLIT, an experiment carried by the -DSDT_TUNING library only)."""
     from speechdrivestemplates_amd import ops
     prev = ops.PRESPLIT
     ops.PRESPLIT = presplit
@@ -400,8 +403,10 @@ def test_b32_forward_stage_error_table():
     reference's and nobody had localised it.)  Every stage of the sdt_bp generator runs ALONE on the same fp32 input -- the float64
     chain's activations rounded to fp32 -- on the HIP path and on the fp32 oracle, and both are compared with the float64 stage on
     that input; then the same for the cumulative chain (each implementation feeding itself).  Errors as max-norm and as RMS.
-    The bar: no isolated stage more than K_STAGE x the fp32 reference's RMS error (+ a floor of 2e-8: one stage of the
-    reference can be exact by luck), the whole chain within K_FWD."""
+    The bar: no isolated stage more than K_STAGE = 2 x the fp32 reference's RMS error (+ a floor of 2e-8: one stage of the
+    reference can be exact by luck; the DFT-as-GEMM mel against the reference's FFT: 3 x), the whole chain within K_FWD.
+    History (profiles/r03_stage_errors_before.txt): with one K-long accumulator per output the Conv2d layers sat at 1.9-3.8 x, growing
+    with sqrt(K); the stream-K kernel accumulates in chunks of 256 products and is level with the reference (1.0-1.3 x)."""
     from speechdrivestemplates_amd import ops
     from speechdrivestemplates_amd.core.networks import get_model
     K_STAGE = 2.0
@@ -485,7 +490,7 @@ def test_b32_forward_stage_error_table():
     bad = []
     for name, hm, hr, rm, rr in rows:
         lines.append("      %-34s hip %.3e | %.3e   ref32 %.3e | %.3e   ratio max %5.2f  rms %5.2f" % (name, hm, hr, rm, rr, hm / max(rm, 1e-30), hr / max(rr, 1e-30)))
-        if "alone" in name and hr > K_STAGE * rr + 2e-8:
+        if "alone" in name and hr > (3.0 if name.startswith("mel") else K_STAGE) * rr + 2e-8:  # mel: a 512-long sum against an FFT
             bad.append((name, hr, rr))
         if name == "chain: prediction" and hm > K_FWD * rm + 2e-7:
             bad.append((name, hm, rm))

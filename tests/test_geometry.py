@@ -149,9 +149,25 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
-    assert declared - {"sdt_last_error", "sdt_abi_version", "sdt_get_conv_math"} == set(_lib.SIGNATURES), \
-        "ctypes signatures out of sync with the header: %s" % (declared ^ set(_lib.SIGNATURES))
+    extra = {"sdt_last_error", "sdt_abi_version", "sdt_get_conv_math", "sdt_conv_dw_workspace_bytes", "sdt_convsk_plan_bytes",
+             "sdt_convsk_workspace_bytes", "sdt_convsk_dw_plan_bytes", "sdt_convsk_dw_workspace_bytes"}
+    declared |= set(re.findall(r"^\s*int64_t\s+(sdt_\w+)\s*\(", hdr, flags=re.M))
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
+    assert declared - extra == set(_lib.SIGNATURES), "ctypes signatures out of sync with the header: %s" % ((declared - extra) ^ set(_lib.SIGNATURES))
     assert _lib.load().sdt_abi_version() == 1
+    # the experiments' header is matched by the tuning library (when it has been built) and by nothing in the product library
+    ehdr = open(os.path.join(REPO, "include", "sdt_hip_experimental.h")).read()
+    edecl = set(re.findall(r"^\s*int\s+(sdt_\w+)\s*\(", ehdr, flags=re.M))
+    assert edecl == set(_lib.EXPERIMENTAL_SIGNATURES), edecl ^ set(_lib.EXPERIMENTAL_SIGNATURES)
+    product = ctypes.CDLL(os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip.so"))
+    for name in sorted(edecl):
+        assert not hasattr(product, name), "the product library exports the experiment %s" % name
+    tuning = os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
+    if os.path.exists(tuning):
+        tl = ctypes.CDLL(tuning)
+        for name in sorted(edecl | declared):
+            assert hasattr(tl, name), "libsdt_hip_tuning.so does not export %s" % name
 
 
 def test_ops_refuse_cpu_tensors():

@@ -30,9 +30,13 @@ def relmax(got, ref):
 
 
 def check(name, got, ref, tol):
+    """`tol`: the stated fp32 tolerance of this quantity; the check is ALSO held to 10x the error recorded in tests/golden/margins.json
+    (conftest.calibrated_bound), so that a 10x numerical regression fails even where the stated tolerance is generous."""
+    from conftest import calibrated_bound
     e = relmax(got, ref)
-    print("  %-46s rel-max-err %.3e (tol %.1e)" % (name, e, tol))
-    assert e < tol, "%s: %.3e >= %.1e" % (name, e, tol)
+    bound = calibrated_bound(name, e, tol)
+    print("  %-46s rel-max-err %.3e (tol %.1e, held to %.1e)" % (name, e, tol, bound))
+    assert e < bound, "%s: %.3e >= %.1e (stated tolerance %.1e)" % (name, e, bound, tol)
 
 
 @pytest.fixture(scope="module")
@@ -325,10 +329,10 @@ def test_deferred_weight_gradients_cover_every_layer():
     on the side stream from the hook at the audio encoder's output.  Nothing may be left behind when forward_backward
     returns, the hook must be what flushes them, and the gradients must equal the inline launches (fp32 atomics: order
     noise only)."""
-    from speechdrivestemplates_amd import ops, stage1d
+    from speechdrivestemplates_amd import ops
     grads, seen = [], []
-    prev, orig_flush, stage_default = ops.DEFER_SMALL_DW, ops.flush_deferred_dw, stage1d.ENABLED
-    stage1d.ENABLED = False  # the per-block Conv1d path (BatchNorm generator, bf16 modes); the fused stage has its own side-stream batch
+    prev, orig_flush = ops.DEFER_SMALL_DW, ops.flush_deferred_dw
+    assert ops.STAGE1D is None  # the per-block Conv1d path is the product path (the fused stage is an experiment with its own batch)
 
     def spy():
         seen.append(len(ops._DEFERRED))
@@ -352,8 +356,6 @@ def test_deferred_weight_gradients_cover_every_layer():
             grads.append(pipe.optimizers["optimizerG"].flat_grad.clone())
         finally:
             ops.DEFER_SMALL_DW, ops.flush_deferred_dw = prev, orig_flush
-            if flag:
-                stage1d.ENABLED = stage_default
     check("deferred vs inline weight gradients", grads[1], grads[0], 2e-5)
 
 
@@ -477,9 +479,10 @@ def test_full_size_step_properties_b32():
     assert err <= 2e-3, err  # early-layer weight gradients carry ~1e-3 relative fp32 summation noise
 
 
+@pytest.mark.experimental
 def test_hipgraph_replay_matches_eager():
-    """graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
-    from speechdrivestemplates_amd.graph import GraphedStep
+    """experimental.graph.GraphedStep captures forward+backward+Adam into one hipGraph; replayed steps must follow the eager run."""
+    from speechdrivestemplates_amd.experimental.graph import GraphedStep
     runs = []
     for use_graph in (False, True):
         pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
@@ -748,6 +751,7 @@ def test_eval_time_code_sources(opt):
         check("code = pose-encoder mean of the ground truth", code, mu_ref, 5e-4)
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("B,slope", [(3, 1.0), (3, 0.2), (32, 1.0), (32, 0.2)])
 def test_fused_conv1d_stage_matches_per_block_path(B, slope):
     """stage1d.Gen1dStageFn (one launch per Conv1d layer and direction, normalise-on-load, csrc/conv1d.hip) against the per-block
@@ -759,7 +763,7 @@ def test_fused_conv1d_stage_matches_per_block_path(B, slope):
     statistics as tests/test_fullsize_gpu.py documents against float64; a flipped unit perturbs every upstream gradient of its clip):
     there every tensor has to agree to 1e-2 in relative L2 norm and 5e-2 of its max-norm; with slope 1.0 (no kink, the same kernels
     and code paths) everything agrees to 2e-4, and the float64-calibrated B = 32 tests of test_fullsize_gpu.py run on this path."""
-    from speechdrivestemplates_amd import stage1d
+    from speechdrivestemplates_amd.experimental import stage1d
     from speechdrivestemplates_amd.core.networks import get_model
     cfg = O.default_cfg(**{"VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION": 32})
     st = {}
@@ -776,9 +780,8 @@ def test_fused_conv1d_stage_matches_per_block_path(B, slope):
     gout = torch.randn(B, 64, 242, generator=g).to(DEV)
     params = [p for n, p in net.named_parameters() if not n.startswith("audio_encoder.")]
     res = {}
-    default = stage1d.ENABLED
     for fused in (False, True):
-        stage1d.ENABLED = fused
+        stage1d.enable(fused)
         try:
             for p in params:
                 p.grad = None
@@ -798,7 +801,7 @@ def test_fused_conv1d_stage_matches_per_block_path(B, slope):
             torch.cuda.synchronize()
             res[fused] = [out.detach().clone(), f.grad.clone(), c.grad.clone()] + [p.grad.clone() for p in params]
         finally:
-            stage1d.ENABLED = default
+            stage1d.enable(False)
     names = ["prediction", "d/dfeat", "d/dcode"] + [n for n, p in net.named_parameters() if not n.startswith("audio_encoder.")]
     errs = [(n, relmax(a, b)) for n, a, b in zip(names, res[True], res[False])]
     for n, e in errs:
@@ -819,29 +822,31 @@ def ops_mod():
     return ops
 
 
-def test_train_steps_repeat_with_deterministic_weight_gradients():
-    """ops.DETERMINISTIC_DW: two runs of three sdt_bp train steps from the same state and batches.  With the weight gradients summed
-    in a fixed order what is left of order-dependent arithmetic are the float64 atomics of the normalisation statistics and the
-    fp32 atomics of the head's bias gradient (col_sum): measured 7e-8 between two runs after three steps, against 1e-4 with the
-    fp32-atomic weight gradients -- three orders of magnitude closer, not bit-identical (the kernel itself is:
-    tests/test_ops_gpu.py::test_deterministic_weight_gradient)."""
+def test_train_steps_repeat_bit_identically():
+    """The default mode is run-to-run reproducible (the reference asks cuDNN for the same, main.py:37-38): two runs of three sdt_bp
+    train steps from the same state and batches end with BIT-IDENTICAL generator weights and clip codes.  Weight gradients, the
+    head's bias gradient and every partial tile of the stream-K kernels are summed in a fixed order; what is left of unordered
+    arithmetic are float64 atomics over fp32-valued partial sums in the normalisation statistics (order-dependent below 2^-53
+    relative, which the fp32 mean / rstd derived from them do not see)."""
     from speechdrivestemplates_amd import ops
 
     def run(det):
-        prev = ops.DETERMINISTIC_DW
-        ops.DETERMINISTIC_DW = det
+        prev = ops.DETERMINISTIC_DW, ops.USE_STREAMK_DW
+        ops.DETERMINISTIC_DW, ops.USE_STREAMK_DW = det, det
         try:
             pipe, _ = _make_pipeline("voice2pose_sdt_bp", 16, 0.5)
             for step in range(3):
                 losses, _ = pipe.forward_backward(O.make_batch(4, 16, step=step, seed=1))
                 pipe.optimizer_updates(losses)
             torch.cuda.synchronize()
-            return pipe.optimizers["optimizerG"].flat_param.detach().clone()
+            return torch.cat([o.flat_param.detach().reshape(-1).clone() for o in pipe.optimizers.values()])
         finally:
-            ops.DETERMINISTIC_DW = prev
-    a, b = run(True), run(True)
-    diff = (a - b).abs().max().item()
-    print("  deterministic dW, two runs of 3 steps: bitwise equal %s, max |diff| %.3e" % (torch.equal(a, b), diff))
-    assert diff <= 2e-6 * a.abs().max().item()
+            ops.DETERMINISTIC_DW, ops.USE_STREAMK_DW = prev
+    assert ops.DETERMINISTIC_DW, "the ordered reductions are the default"
+    runs = [run(True) for _ in range(3)]
+    for k in (1, 2):
+        diff = (runs[0] - runs[k]).abs().max().item()
+        print("  default mode, run 0 vs run %d of 3 steps: bitwise equal %s, max |diff| %.3e" % (k, torch.equal(runs[0], runs[k]), diff))
+        assert torch.equal(runs[0], runs[k])
     c, d = run(False), run(False)
-    print("  atomic dW, two runs of 3 steps: max |diff| %.3e" % (c - d).abs().max().item())
+    print("  fp32-atomic weight gradients (opt-out), two runs of 3 steps: max |diff| %.3e" % (c - d).abs().max().item())

@@ -23,9 +23,13 @@ def rel_err(got, ref):
 
 
 def check(name, got, ref, tol):
+    """`tol`: the stated fp32 tolerance of this quantity; the check is ALSO held to 10x the error recorded in tests/golden/margins.json
+    (conftest.calibrated_bound), so that a 10x numerical regression fails even where the stated tolerance is generous."""
+    from conftest import calibrated_bound
     e = rel_err(got, ref)
-    print("  %-40s rel-max-err %.3e (tol %.1e)" % (name, e, tol))
-    assert e < tol, "%s: %.3e >= %.1e" % (name, e, tol)
+    bound = calibrated_bound(name, e, tol)
+    print("  %-40s rel-max-err %.3e (tol %.1e, held to %.1e)" % (name, e, tol, bound))
+    assert e < bound, "%s: %.3e >= %.1e (stated tolerance %.1e)" % (name, e, bound, tol)
 
 
 @pytest.fixture(scope="module")
@@ -611,10 +615,22 @@ err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
 print("ERR", err)
 assert err < 3e-6, err
 ''' % REPO
-    for var in ("SDT_CONV_PRIO", "SDT_CONV_TILE"):
-        env = dict(os.environ, **{var: "3" if var == "SDT_CONV_PRIO" else "128128"})
+    env_lib = {k: v for k, v in os.environ.items() if k != "SDT_HIP_LIB"}  # the product library, whatever this session loaded
+    for var in ("SDT_CONV_PRIO", "SDT_CONV_TILE", "SDT_STAGE1D", "SDT_PRESPLIT"):
+        env = dict(env_lib, **{var: "3" if var == "SDT_CONV_PRIO" else ("128128" if var == "SDT_CONV_TILE" else "1")})
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (var, out.stdout[-2000:], out.stderr[-2000:])
+    # no experiment switch is compiled into the product library or read by the package (VERDICT r2, item 8)
+    blob = open(os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip.so"), "rb").read()
+    for needle in (b"SDT_CONV_PRIO", b"SDT_CONV_TILE", b"SDT_STAGE1D", b"SDT_PRESPLIT", b"c1d_kernel", b"conv_taps_pre_kernel", b"conv_tab_kernel"):
+        assert needle not in blob, needle
+    pkg = os.path.join(REPO, "speechdrivestemplates_amd")
+    for root, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                for needle in ("SDT_STAGE1D", "SDT_PRESPLIT", "SDT_CONV_PRIO", "SDT_DETERMINISTIC_DW"):
+                    assert ('environ.get("%s"' % needle) not in src and ("environ['%s']" % needle) not in src, (f, needle)
 
 
 @pytest.mark.parametrize("norm,stride", [("IN", 2), ("IN", 1), ("BN", 2)])
@@ -679,6 +695,7 @@ def _planes(ops, t):
     return p
 
 
+@pytest.mark.experimental
 def test_presplit_planes_are_an_exact_split(ops):
     """x = x1 + x2 + x3 exactly (three bf16 pieces by truncation) for every NORMAL fp32 value whose third piece stays normal
     (|x| >= 2^-110); below that the residuals underflow -- the kernels run with the hardware's flush of fp32 subnormal results --
@@ -694,6 +711,7 @@ def test_presplit_planes_are_an_exact_split(ops):
     assert torch.equal(p[0] + (p[1] + p[2]), x)  # the pieces do not overlap: any fp32 summation order recovers x
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("tile", [64064, 128064, 128128, 1281288, 1282568])
 @pytest.mark.parametrize("case", [("k3 s1", 3, 20, 53, 128, 256, 3, 3, 1, 1), ("k4 s2", 2, 21, 40, 64, 128, 4, 4, 2, 1),
                                   ("k(6,3) p0", 2, 10, 53, 256, 256, 6, 3, 1, 0)], ids=lambda c: c[0])
@@ -737,6 +755,7 @@ def test_presplit_conv_vs_float64(ops, case, tile):
         _lib.check(lib.sdt_set_pre_tile(0))
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("norm", ["IN", "BN"])
 def test_presplit_chain_matches_float64(ops, norm):
     """Two ConvNormRelu blocks in 'bf16x6' math with the pre-split hand-over (planes of z from the normalisation forward, planes of
@@ -762,7 +781,7 @@ def test_presplit_chain_matches_float64(ops, norm):
             return orig(*a)
     ops.set_conv_math("bf16x6")
     prev_presplit = ops.PRESPLIT
-    ops.PRESPLIT = True  # opt-in pipeline (SDT_PRESPLIT=1)
+    ops.PRESPLIT = True  # experiment (tuning library)
     try:
         lib.sdt_conv_taps_pre_f32 = Spy()
         xin = x.clone().requires_grad_(True)

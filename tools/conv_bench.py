@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--streamk", type=int, default=2, help="0: the 64x64 kernel of conv.hip; 1 / 2: the persistent stream-K kernel with 1 / 2 workgroups per CU")
     a = ap.parse_args()
     ops.USE_STREAMK = a.streamk > 0
+    ops.USE_STREAMK_DW = a.streamk > 0
     ops.USE_TAB = a.tab >= 0
     if os.environ.get("SDT_SK_ALL") == "1":  # every 2-D layer through the stream-K kernel (tool-only switch)
         ops.STREAMK_MIN_STEPS, ops.STREAMK_MIN_COUT = 1, 64

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in "--no-streamk" "" "--streamk-min-steps 16" "--no-streamk" ""; do
+for v in "--no-streamk" "" "--no-streamk-dw" "--no-streamk" ""; do
 echo "== bench $v" >> gpurun_out/bench_ab.txt
 timeout 900 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-alt-mode $v 2>&1 | python -c "
 import sys, json
