@@ -110,7 +110,7 @@ int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for 
 int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls);
 int64_t sdt_convsk_workspace_bytes(void);
 int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes);
-/* Weight gradient of a forward geometry on the same persistent stream-K machinery (dense dY, Cout % 128 == 0, taps * Cin % 128 == 0):
+/* Weight gradient of a forward geometry on the same persistent machinery (dense dY, Cout % 64 == 0, Cin % 64 == 0; 128- or 64-wide tiles):
  * the reduction over the output positions is split over the workgroups, partial 128x128 tiles go to slabs of `workspace`
  * (sdt_convsk_dw_workspace_bytes() bytes, contents irrelevant) and a second kernel adds them to dw (Cout, Tw, Cin) in a fixed order:
  * no atomics, bit-identical from run to run (what the reference asks of cuDNN with cudnn.deterministic = True, main.py:37-38).

@@ -603,20 +603,24 @@ __global__ __launch_bounds__(256) void conv_tab_kernel(const float* __restrict__
 // m), so the LDS tiles are [k = m][128] and an MFMA operand is one conflict-free ds_read_b32 (row k + lane / 32, column lane % 32).
 // The per-row tables of the FORWARD geometry's plan give, per m, the dY row offset, the X row offset and the mask of taps that fall
 // outside X; they are read two K steps ahead of the data they address.
-template <int WPC>
+template <int BM, int BN, int WPC>
 __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY, const sk_args P,
                                                              const int K, const int ncol, const int nchunk, float* __restrict__ slabs) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, RP = 4, NM = TM * TN * 4;  // RP: 16-byte loads per thread, operand and K step
+    // BM x BN tile of dW (n x (t, c)), each 128 or 64 wide.  Per operand of width Wd: Wd / 4 16-byte chunks per k row, KPT = Wd / 32
+    // consecutive k rows per thread (4 or 2)
+    constexpr int TM = BM / 64 > 0 ? BM / 64 : 1, TN = BN / 64 > 0 ? BN / 64 : 1, NM = TM * TN * 4;
+    constexpr int KA = BM / 32, KB = BN / 32;  // k rows (= 16-byte loads) per thread and K step, dY / X
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // LDS tiles [k / 4][row][k % 4]: a thread loads 4 CONSECUTIVE m (= k) of its 4-column chunk, transposes the 4x4 block in registers
-    // (register renaming + moves) and stores, per column, the 4 k values as one 16-byte vector -- so an MFMA operand fragment is one
+    // LDS tiles [k / 4][row][k % 4]: a thread loads KPT CONSECUTIVE m (= k) of its 4-column chunk, transposes the block in registers
+    // (register renaming + moves) and stores, per column, its k values as one 16- or 8-byte vector -- so an MFMA operand fragment is one
     // ds_read_b128 of 4 k values of a row, exactly as in the forward kernel (a [k][row] tile costs one ds_read_b32 per MFMA operand:
     // 8x the LDS instructions, measured 5-9 % slower than the atomics kernel it was meant to replace)
     float* sA = smem;                // [2][8][BM][4]   dY tile
     float* sB = smem + 2 * 32 * BM;  // [2][8][BN][4]   gathered X tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int cq = tid & 31, kg = tid >> 5;  // loader: 16-byte chunk cq of the k rows 4 kg .. 4 kg + 3
+    const int cqa = tid % (BM / 4), ksa = tid / (BM / 4);  // loader: chunk cq of the k rows KPT * ks .. + KPT - 1
+    const int cqb = tid % (BN / 4), ksb = tid / (BN / 4);
     // Work unit = (tile, chunk of the K loop): workgroup u does chunk u / T of tile u % T, so the workgroups that run side by side
     // (consecutive u on one XCD) walk the SAME rows m at the same time, each for its own tile: dY and X rows come out of the L2 for
     // all but one of them.  (A stream-K split with the tile as the outer index made every workgroup stream private rows: 1.5 GB of
@@ -631,46 +635,62 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)P.ybytes, 0x00020000);
     // fragment read offsets (floats): lane half h reads the k group 2 j + h of its row
-    const int fa = ((lane >> 5) * BM + wm * 64 + (lane & 31)) * 4, fb = ((lane >> 5) * BN + wn * 64 + (lane & 31)) * 4;
+    const int fa = ((lane >> 5) * BM + wm * (BM / 2) + (lane & 31)) * 4, fb = ((lane >> 5) * BN + wn * (BN / 2) + (lane & 31)) * 4;
     {
         const int a = (int)((long)chunk * K / nchunk), b = (int)((long)(chunk + 1) * K / nchunk);
         const int nt = tile / ncol, ct = tile - nt * ncol;
         const int n0 = nt * BM, j0 = ct * BN;
         // this thread's B column: 4 consecutive channels of ONE tap
-        const int j = j0 + cq * 4;
+        const int j = j0 + cqb * 4;
         const int t = j / Cin, c = j - t * Cin;
-        const unsigned acol = (unsigned)(n0 + cq * 4) * 4u;
+        const unsigned acol = (unsigned)(n0 + cqa * 4) * 4u;
         const unsigned bcol = (unsigned)cl.ashift[t] + (unsigned)c * 4u;
         const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
-        int4 ri[RP];
-        f32x4 ra[RP], rb[RP];
-        int mrow = (a * 32) + 4 * kg;  // first row of the next table read
+        int ya[KA];             // dY row offsets of this thread's k rows
+        int2 xb[KB];            // {X row offset, invalid-tap mask} of this thread's k rows
+        f32x4 ra[KA], rb[KB];
+        int mrowa = (a * 32) + KA * ksa, mrowb = (a * 32) + KB * ksb;  // first rows of the next table reads
         auto load_rows = [&]() {
 #pragma unroll
-            for (int i = 0; i < RP; ++i) ri[i] = P.rowinfo[mrow + i];
-            mrow += 32;
+            for (int i = 0; i < KA; ++i) ya[i] = ((const int*)P.rowinfo)[4 * (mrowa + i) + 2];
+#pragma unroll
+            for (int i = 0; i < KB; ++i) xb[i] = ((const int2*)P.rowinfo)[2 * (mrowb + i)];
+            mrowa += 32;
+            mrowb += 32;
         };
         int left = b - a;
-        auto load = [&]() {  // data of the step whose table rows are in ri; past the end of the segment: masked
+        auto load = [&]() {  // data of the step whose table rows are in ya / xb; past the end of the segment: masked
             const unsigned off_mask = left > 0 ? 0u : SK_OOB;
 #pragma unroll
-            for (int i = 0; i < RP; ++i) {
-                const unsigned oa = ((unsigned)ri[i].z + acol) | off_mask;  // rows past M carry SK_OOB in z already
+            for (int i = 0; i < KA; ++i) {
+                const unsigned oa = ((unsigned)ya[i] + acol) | off_mask;  // rows past M carry SK_OOB already
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
-                const unsigned ob = (((unsigned)ri[i].x + bcol) & 0x7fffffffu) | (((unsigned)ri[i].y << sh) & 0x80000000u) | off_mask;
+            }
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask;
                 rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
             }
             --left;
         };
-        auto stage = [&](int buf) {  // 4x4 register transpose: column e of the block = the 4 k values of row (chunk * 4 + e)
-            float* wA = sA + buf * 32 * BM + (kg * BM + cq * 4) * 4;
-            float* wB = sB + buf * 32 * BN + (kg * BN + cq * 4) * 4;
+        auto stage = [&](int buf) {  // register transpose: column e of the block = the k values of row (chunk * 4 + e)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 va = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
-                const f32x4 vb = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
-                *(f32x4*)&wA[e * 4] = va;
-                *(f32x4*)&wB[e * 4] = vb;
+                if constexpr (KA == 4) {
+                    const f32x4 va = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+                    *(f32x4*)&sA[buf * 32 * BM + (ksa * BM + cqa * 4 + e) * 4] = va;
+                } else {
+                    const f32x2 va = {ra[0][e], ra[1][e]};
+                    *(f32x2*)&sA[buf * 32 * BM + ((ksa >> 1) * BM + cqa * 4 + e) * 4 + (ksa & 1) * 2] = va;
+                }
+                if constexpr (KB == 4) {
+                    const f32x4 vb = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
+                    *(f32x4*)&sB[buf * 32 * BN + (ksb * BN + cqb * 4 + e) * 4] = vb;
+                } else {
+                    const f32x2 vb = {rb[0][e], rb[1][e]};
+                    *(f32x2*)&sB[buf * 32 * BN + ((ksb >> 1) * BN + cqb * 4 + e) * 4 + (ksb & 1) * 2] = vb;
+                }
             }
         };
         f32x16 acc[1][TM][TN], tot[TM][TN];
@@ -712,21 +732,26 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
             DW_READ(a1, b1, pa, pb, 3);
             DW_MFMA(a0, b0);
             {
-                constexpr int NF = TM + TN, NW = 2 * RP, NL = 3 * RP;  // fragment reads / LDS stores / global loads (data + tables)
+                constexpr int NF = TM + TN, NW = 8, NL = 2 * (KA + KB);  // fragment reads / LDS stores / global loads (data + tables)
+                constexpr int NMF = NM > NF ? NM : NF;                    // MFMAs of a k-group available to pair with
 #pragma unroll
                 for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
 #pragma unroll
                 for (int q = 0; q < NW; ++q) { SK_SGB(0x8, 1); SK_SGB(0x200, 1); }
 #pragma unroll
                 for (int q = 0; q < NL; ++q) { SK_SGB(0x8, 1); SK_SGB(0x20, 1); }
-                constexpr int u1 = NF + NW + NL;  // 24 > 16: runs into k-group 1
+                constexpr int u1 = NF + NW + NL;
+                constexpr int v1 = u1 < NMF ? NMF : u1;
+                if constexpr (u1 < NM) SK_SGB(0x8, NM - u1);
 #pragma unroll
                 for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
-                constexpr int u2 = u1 + NF;
+                constexpr int u2 = v1 + NF;
+                constexpr int v2 = u2 < 2 * NM ? 2 * NM : u2;
                 if constexpr (u2 < 2 * NM) SK_SGB(0x8, 2 * NM - u2);
 #pragma unroll
                 for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
-                SK_SGB(0x8, NM - NF);
+                constexpr int u3 = v2 + NF;
+                if constexpr (u3 < 3 * NM) SK_SGB(0x8, 3 * NM - u3);
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my writes of LDS[next] are done
@@ -736,7 +761,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
             DW_MFMA(a1, b1);
 #pragma unroll
             for (int q = 0; q < TM + TN; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
-            SK_SGB(0x8, NM - (TM + TN));
+            if constexpr (NM > TM + TN) SK_SGB(0x8, NM - (TM + TN));
             __builtin_amdgcn_sched_barrier(0);
         };
         auto flush = [&]() {
@@ -766,8 +791,8 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int nl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                    const int jl = wn * 64 + tn * 32 + (lane & 31);
+                    const int nl = wm * (BM / 2) + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                    const int jl = wn * (BN / 2) + tn * 32 + (lane & 31);
                     slab[nl * BN + jl] = tot[tm][tn][q];
                 }
     }
@@ -775,14 +800,14 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
 
 // dw[n, wt(t), c] += the slabs of tile (nt, ct), chunk 0 first.  One thread per 4 consecutive columns of a tile row.
 __global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, const sk_args P, const int ncol,
-                                                           const int nchunk, const int Cout, const int Tw) {
-    constexpr int BM = 128, BN = 128;
-    const int tile = blockIdx.x >> 4;                      // 16 workgroups per tile
-    const int e = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile
-    const int nl = e >> 5, jl = (e & 31) * 4;
+                                                           const int nchunk, const int Cout, const int Tw, const int BM, const int BN) {
+    const int per_tile = BM * BN / 4 / 256;                  // workgroups per tile
+    const int tile = blockIdx.x / per_tile;
+    const int e = (blockIdx.x % per_tile) * 256 + threadIdx.x;  // float4 index inside the tile
+    const int nl = e / (BN / 4), jl = (e % (BN / 4)) * 4;
     const int nt = tile / ncol, ct = tile - nt * ncol;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nchunk; ++ch) sum += *(const f32x4*)(slabs + ((size_t)ch * P.T + tile) * (BM * BN) + nl * BN + jl);
+    for (int ch = 0; ch < nchunk; ++ch) sum += *(const f32x4*)(slabs + ((size_t)ch * P.T + tile) * (size_t)(BM * BN) + nl * BN + jl);
     const sk_class& cl = P.cls[0];
     const int j = ct * BN + jl, t = j / cl.Cin, c = j - t * cl.Cin;
     const int n = nt * BM + nl;
@@ -1128,13 +1153,14 @@ extern "C" int sdt_convsk_dw_supported(const sdt_conv_geom* g) {
     if (!g) return 0;
     const sdt_conv_geom* gs[1] = {g};
     if (!sk_supported(gs, 1, 128, 64)) return 0;  // Cin % 32, sizes
-    if (g->Cout % 128 != 0 || (g->ntaps * g->Cin) % 128 != 0 || g->ntaps != g->Tw) return 0;
+    if (g->Cout % 64 != 0 || (g->ntaps * g->Cin) % 64 != 0 || g->Cin % 64 != 0 || g->ntaps != g->Tw) return 0;
     if (g->osy != 1 || g->osx != 1 || g->ooy != 0 || g->oox != 0 || g->Hy != g->Ho || g->Wy != g->Wo) return 0;  // dense dY
     for (int t = 0; t < g->ntaps; ++t)
         for (int u = 0; u < t; ++u)
             if (g->wt[t] == g->wt[u]) return 0;
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    const int64_t K = cdiv64(M, 32), T = (int64_t)(g->Cout / 128) * ((int64_t)g->ntaps * g->Cin / 128);
+    const int bm = g->Cout % 128 == 0 ? 128 : 64, bn = (g->ntaps * g->Cin) % 128 == 0 ? 128 : 64;
+    const int64_t K = cdiv64(M, 32), T = (int64_t)(g->Cout / bm) * ((int64_t)g->ntaps * g->Cin / bn);
     const int G = 256 * g_sk_wpc;
     return T <= G && K >= 8 * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 steps each
 }
@@ -1153,8 +1179,9 @@ extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int6
     int* P = (int*)out;
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
     const int64_t K = cdiv64(M, 32), rows = (K + 3) * 32;
-    const int ncol = g.ntaps * g.Cin / 128;
-    const int64_t T = (int64_t)(g.Cout / 128) * ncol;
+    const int bm = g.Cout % 128 == 0 ? 128 : 64, bn = (g.ntaps * g.Cin) % 128 == 0 ? 128 : 64;
+    const int ncol = g.ntaps * g.Cin / bn;
+    const int64_t T = (int64_t)(g.Cout / bm) * ncol;
     const int G = 256 * g_sk_wpc;
     int* rowinfo = P + SK_HDR;
     for (int64_t m = 0; m < rows; ++m) {
@@ -1183,7 +1210,7 @@ extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int6
         cp[11 + SDT_MAX_TAPS + t] = on ? g.wt[t] : 0;  // the weight-gradient kernels read wt[t] here
         cp[11 + 2 * SDT_MAX_TAPS + t] = 0;
     }
-    P[0] = SK_MAGIC + 1, P[1] = 128, P[2] = 128, P[3] = G, P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
+    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G, P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
     P[10] = SK_HDR, P[11] = 0, P[12] = 0, P[13] = 0, P[14] = (int)(SK_HDR + rows * 4), P[15] = (int)(SK_HDR + rows * 4 + SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1211,19 +1238,29 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
     for (int c = 1; c < SK_MAXC; ++c) A.cls[c] = A.cls[0];
     A.xbytes = (unsigned)xbytes, A.wbytes = 0, A.ybytes = (unsigned)ybytes;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * 32 * (128 + 128) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)convsk_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)convsk_dw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    const int bm = P[1], bn = P[2];
+    const size_t lds = (size_t)2 * 32 * (bm + bn) * 4;
     const int nchunk = A.G / A.T;  // T * nchunk <= G workgroups have work (>= 98 % of them on this network's layers)
-    if (A.G == 256)
-        hipLaunchKernelGGL((convsk_dw_kernel<1>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace);
-    else
-        hipLaunchKernelGGL((convsk_dw_kernel<2>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace);
-    hipLaunchKernelGGL(dw_sk_reduce_kernel, dim3(A.T * 16), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw);
+#define DW_GO(BM_, BN_, WPC_)                                                                                                  \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)convsk_dw_kernel<BM_, BN_, WPC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((convsk_dw_kernel<BM_, BN_, WPC_>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace); \
+    } while (0)
+    const int wpc = A.G / 256;
+    if (bm == 128 && bn == 128 && wpc == 2) DW_GO(128, 128, 2);
+    else if (bm == 128 && bn == 128) DW_GO(128, 128, 1);
+    else if (bm == 128 && bn == 64 && wpc == 2) DW_GO(128, 64, 2);
+    else if (bm == 128 && bn == 64) DW_GO(128, 64, 1);
+    else if (bm == 64 && bn == 128 && wpc == 2) DW_GO(64, 128, 2);
+    else if (bm == 64 && bn == 128) DW_GO(64, 128, 1);
+    else if (bm == 64 && bn == 64 && wpc == 2) DW_GO(64, 64, 2);
+    else DW_GO(64, 64, 1);
+#undef DW_GO
+    hipLaunchKernelGGL(dw_sk_reduce_kernel, dim3(A.T * (bm * bn / 4 / 256)), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
