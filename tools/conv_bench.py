@@ -65,13 +65,27 @@ def main():
         y = ops.conv_forward(x, w, None, s, p)
         gy = torch.randn_like(y)
         flops = 2.0 * y.numel() * Cin * kh * kw
+        def holder(groups):
+            h = ops.NormBwdHolder()
+            h.y = torch.randn_like(x)
+            h.mean = torch.zeros((groups, Cin), device="cuda")
+            h.rstd = torch.ones((groups, Cin), device="cuda")
+            h.gamma, h.beta = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+            h.groups, h.slope = groups, 0.2
+            return h
+        hs = {1: holder(1), B: holder(B)}
         fns = {"fwd": lambda: ops.conv_forward(x, w, None, s, p),
+               # + the statistics epilogues of the step: BatchNorm (one group) / InstanceNorm (one group per item)
+               "fwdS1": lambda: ops.ConvStatsFn.apply(x, w, s, p, 1), "fwdSB": lambda: ops.ConvStatsFn.apply(x, w, s, p, B),
+               "dXS1": lambda: ops.conv_input_grad(gy, w, x.shape, s, p, hs[1]), "dXSB": lambda: ops.conv_input_grad(gy, w, x.shape, s, p, hs[B]),
                "dX": lambda: ops.conv_input_grad(gy, w, x.shape, s, p),
                "dW": lambda: ops.conv_weight_grad(x, gy, w, s, p)}
         for role in roles:
-            if role == "dX" and name == "L0":
+            if (role.startswith("dX") and name == "L0") or (role not in ("fwd", "dX", "dW") and one_d):
                 continue
             fn = fns[role]
+            if role not in ("fwd", "dX", "dW"):
+                fn = (lambda f: lambda: (ops.begin_step(), f())[1])(fns[role])  # recycles the zeroed statistics arena (one small fill)
             err = ""
             if a.math != "f32":
                 def run():
@@ -94,7 +108,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
             ops.set_conv_math("f32")
-            print("%-14s %-3s  %8.1f us  %6.1f TFLOP/s  (%.1f GFLOP, out %s)%s" % (name, role, us, flops / us / 1e6, flops / 1e9, tuple(y.shape), err), flush=True)
+            print("%-14s %-5s  %8.1f us  %6.1f TFLOP/s  (%.1f GFLOP, out %s)%s" % (name, role, us, flops / us / 1e6, flops / 1e9, tuple(y.shape), err), flush=True)
 
 
 if __name__ == "__main__":
