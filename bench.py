@@ -40,6 +40,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 N_CLIPS = 4096
 # Algorithmic work of the Conv1d stacks per 32-clip step (weights counted once per step): generator U-Net + decoder
@@ -364,7 +365,11 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw,
+                       # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
+                       # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
+                       # fp32 does not depend on the arrival order
+                       "deterministic": bool(not args.atomic_dw and not args.no_streamk_dw and args.conv_math == "f32")},
             "final_G_loss": final_loss,
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included
@@ -459,10 +464,33 @@ def main(argv=None):
                 ops.set_conv_math("f32")
             alt_loss = float(losses_alt["G_loss" if "G_loss" in losses_alt else "loss"].detach())
             assert alt_loss == alt_loss and alt_loss < 10.0, "bf16x6 leg diverged: G_loss=%r" % alt_loss
-            out["alt_conv_math"] = {"mode": "bf16x6", "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt,
+            out["alt_conv_math"] = {"mode": "bf16x6", "dtype": "bf16x6 (3-piece bf16 split of fp32 operands, 6 MFMA products, fp32 accumulate)",
+                                    "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt,
                                     "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
                                     "note": "not the headline: 20 further steps of the same run with --conv-math bf16x6 (exact 3-piece bf16 "
                                             "split of both operands inside the conv kernels, 6 MFMA products, fp32 accumulation), no sampling events"}
+            if prof is not None:
+                # its own roofline: two more steps with per-launch events (side stream off), priced against the dense bf16 MFMA peak / 6
+                ops.set_conv_math("bf16x6")
+                aprof = ops.ConvProfiler(pool=2 * 200 * 2)
+                try:
+                    ops.PROFILER, ops.OVERLAP_DW = aprof, False
+                    for i in range(2):
+                        runner(args.warmup + args.steps + 23 + i)
+                    sync()
+                finally:
+                    ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
+                    ops.set_conv_math("f32")
+                asum = aprof.summary()
+                aname, ad = max(asum.items(), key=lambda kv: kv[1]["us"])
+                a_ach = ad["flops"] / (ad["us"] * 1e-6) / 1e12
+                a_all = sum(v["flops"] for v in asum.values()) / (sum(v["us"] for v in asum.values()) * 1e-6) / 1e12
+                out["alt_conv_math"]["roofline"] = {
+                    "bound": "mfma", "kernel": aname, "achieved": a_ach, "peak": BF16_MATRIX_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s (fp32-equivalent)",
+                    "frac": a_ach / (BF16_MATRIX_PEAK_TFLOPS / 6.0), "avg_launch_us": ad["us"] / ad["launches"], "launches_per_step": ad["launches"] / 2.0,
+                    "all_conv_launches_achieved": a_all, "event_sampled_steps": 2,
+                    "note": "peak = dense bf16 MFMA peak (%.0f TFLOP/s) / 6 products per fp32 product; algorithmic fp32 FLOPs of the layer / event window"
+                            % BF16_MATRIX_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(B)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -97,6 +97,33 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                                             const int wn, const int lane, const float* __restrict__ bias, const __amdgpu_buffer_rsrc_t rsY,
                                             const int Cout, double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes) {
     constexpr int TN = BN / 64;  // accumulator rows TMB .. TME-1 of the wave (the callers interleave other work between halves)
+    // EPI 2 reads the forward output y at every position of the tile (64 dwords per lane, HBM misses): all of them are issued before
+    // anything else of the epilogue -- one exposed memory latency per tile instead of one per 32x32 block (the K loop's fragment and
+    // staging registers are dead here, so the 64 values have room)
+    float yv[(TME - TMB) * TN * 16];
+    __amdgpu_buffer_rsrc_t rsNY = rsY;
+    if constexpr (EPI == 2) {
+        rsNY = __builtin_amdgcn_make_buffer_rsrc((void*)nb.y, 0, (int)ybytes, 0x00020000);
+#pragma unroll
+        for (int tm = TMB; tm < TME; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const unsigned nb4 = (unsigned)(n0 + wn * (BN / 2) + tn * 32 + (lane & 31)) * 4u;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int4 o4 = *(const int4*)&sOut[wm * (BM / 2) + tm * 32 + 8 * qq + 4 * (lane >> 5)];
+                    const int offs[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#ifdef SK_NO_YLOAD  // ablation (wrong results): cost of the epilogue's reads of the forward output
+                        yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] = (float)offs[e];
+#else
+                        yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] =
+                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + nb4), 0, 0));
+#endif
+                }
+            }
+    }
 #pragma unroll
     for (int tm = TMB; tm < TME; ++tm)
 #pragma unroll
@@ -122,9 +149,7 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                 const int gfirst = sGrp[rb0], glast = sGrp[rb0 + 31];
                 const bool two = glast != gfirst && glast >= 0;
                 float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f;
-                __amdgpu_buffer_rsrc_t rsNY = rsY;
                 if constexpr (EPI == 2) {
-                    rsNY = __builtin_amdgcn_make_buffer_rsrc((void*)nb.y, 0, (int)ybytes, 0x00020000);
                     if (gfirst >= 0) {
                         mu0 = nb.mean[(size_t)gfirst * Cout + n];
                         rs0 = nb.rstd[(size_t)gfirst * Cout + n];
@@ -150,8 +175,8 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                             u = valid ? tot[tm][tn][4 * qq + e] + bv : 0.f;
                             v = u;
                         } else {
-                            const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + (unsigned)n * 4u), 0, 0));
-                            v = (yv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
+                            const float yvv = yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e];
+                            v = (yvv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
                             u = valid ? tot[tm][tn][4 * qq + e] * act_grad(v * ga + be, nb.slope) : 0.f;
                         }
                         if (!second) {
@@ -168,7 +193,11 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                 s1 += __shfl_xor(s1, 32, 64);
                 q1 += __shfl_xor(q1, 32, 64);
                 double* acc_out = EPI == 1 ? stats : nb.sums;
+#ifdef SK_NO_ATOM  // ablation (wrong results): cost of the statistics atomics
+                if (lane < 32 && gfirst >= 0 && s0 == 123.456f) {
+#else
                 if (lane < 32 && gfirst >= 0) {
+#endif
                     double* d = acc_out + ((size_t)gfirst * Cout + n) * 2;
                     atomicAdd(d, (double)s0);
                     atomicAdd(d + 1, (double)q0);
