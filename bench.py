@@ -198,6 +198,7 @@ def main(argv=None):
     ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
     ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
+    ap.add_argument("--streamk-min-cout", type=int, default=None, help="experiment: GEMM width from which an input-gradient launch takes the stream-K kernel")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
 
@@ -248,6 +249,8 @@ def main(argv=None):
         ops.USE_STREAMK_DW = not args.no_streamk and not args.no_streamk_dw
         if args.streamk_min_steps is not None:
             ops.STREAMK_MIN_STEPS = args.streamk_min_steps
+        if args.streamk_min_cout is not None:
+            ops.STREAMK_MIN_COUT = args.streamk_min_cout
             ops.STREAMK_MIN_COUT = 64
         ops.DEFER_SMALL_DW = not args.no_defer_dw
         ops.DETERMINISTIC_DW = not args.atomic_dw

@@ -935,6 +935,14 @@ extern "C" int64_t sdt_convsk_workspace_bytes(void) { return (int64_t)512 * (128
 // Builds the plan into host memory `out` (sdt_convsk_plan_bytes bytes); the caller copies it to the device once per geometry.
 // rows_per_group > 0: statistics group of row m of class c = m / rows_per_group (forward statistics) -- for an input gradient with
 // normalisation-backward statistics pass -1: the group is the batch item (groups == B) or 0 (groups == 1), chosen by `bwd_groups`.
+static int g_sk_perm_pct = 95, g_sk_perm_pct_bwd = 95;  // image-row-major tile order when it leaves <= this many % of the K steps
+#ifdef SDT_TUNING
+extern "C" int sdt_convsk_set_perm_pct(int pct) {  // forward plans: pct % 1000, input-gradient plans: pct / 1000
+    g_sk_perm_pct = pct % 1000;
+    g_sk_perm_pct_bwd = pct / 1000;
+    return SDT_OK;
+}
+#endif
 static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes, int kind) {
     SDT_CHECK_ARG(plan_supported(geoms, ncls, kind), "geometry not supported by this kernel");
     SDT_CHECK_ARG(out != nullptr && out_bytes >= plan_bytes(geoms, ncls, kind), "plan buffer too small");
@@ -1003,10 +1011,15 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
             return mask;
         };
         bool perm = false;
-        if (g.Hi > 1 && g.ntaps > 4 && g.Wo >= 32 && g.Ho > 1) {
+        if (g.Hi > 1 && g.ntaps > 4 && g.Wo >= 32 && g.Ho > 1 && nmb >= 64) {  // small launches are latency-bound: nothing to gain
             int64_t s_nat = 0, s_perm = 0;
             for (int mt = 0; mt < nmb; ++mt) s_nat += __builtin_popcount(tile_mask(mt, false)), s_perm += __builtin_popcount(tile_mask(mt, true));
-            perm = s_perm * 100 <= s_nat * 95;
+            perm = s_perm * 100 <= s_nat * (int64_t)(rows_per_group < 0 ? g_sk_perm_pct_bwd : g_sk_perm_pct);
+#ifdef SDT_TUNING
+            if (getenv("SDT_SK_PLAN_LOG"))
+                fprintf(stderr, "plan B%d %dx%d -> %dx%d Cin %d Cout %d taps %d rpg %d bwd_groups %d: steps natural %ld, row-major %ld -> %s\n", g.B, g.Hi, g.Wi,
+                        g.Ho, g.Wo, g.Cin, g.Cout, g.ntaps, rows_per_group, bwd_groups, (long)s_nat, (long)s_perm, perm ? "row-major" : "natural");
+#endif
         }
         for (int mt = 0; mt < nmb; ++mt) {
             unsigned mask = 0;
