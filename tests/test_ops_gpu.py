@@ -882,3 +882,79 @@ def test_lsgan_mse_terms(ops):
         torch.cuda.synchronize()
         check("lsgan term %s" % (shape,), out.reshape(1), ref.detach().reshape(1), 1e-6)
         check("lsgan term gradient %s" % (shape,), sd.grad, sr.grad, 1e-6)
+
+
+# (tag, B, Hi, Wi, Cin, Cout, k, s, p): one case per tile shape of convsk_dw_kernel (rows x columns of the dW tile)
+SK_DW = [("128x128 tile", 8, 20, 106, 128, 256, 3, 1, 1), ("128x64 tile", 4, 40, 213, 64, 128, 3, 1, 1), ("64x128 tile", 4, 80, 427, 64, 64, 4, 2, 1),
+         ("64x64 tile", 4, 40, 213, 64, 64, 3, 1, 1), ("128x64 tile, Cout 192", 4, 20, 106, 64, 192, 3, 1, 1), ("64x128 tile, ragged rows", 5, 33, 77, 192, 64, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", SK_DW, ids=lambda c: c[0])
+def test_streamk_weight_gradient_tile_shapes(ops, case):
+    """sdt_convsk_dw_f32 (ordered (tile, K-chunk) units + fixed-order slab reduce) on every tile shape it instantiates: the launch takes
+    that kernel (sdt_convsk_dw_supported), equals the float64 weight gradient, repeats bit-identically and accumulates."""
+    from speechdrivestemplates_amd import _lib
+    tag, B, Hi, Wi, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) * (2.0 / (Cin * k * k)) ** 0.5
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    geom = ops.conv_geom_for(xd.shape, wd, s, p)
+    assert ops.USE_STREAMK_DW and _lib.load().sdt_convsk_dw_supported(geom), "this case must run on the stream-K weight-gradient kernel"
+    runs = []
+    for _ in range(2):
+        wd.grad = None
+        ops.conv_weight_grad(xd, gyd, wd, s, p)
+        torch.cuda.synchronize()
+        runs.append(wd.grad.clone())
+    assert torch.equal(runs[0], runs[1]), "stream-K weight gradient differs between runs"
+    check("streamk dW " + tag, runs[0], wr.grad, 5e-6)
+    ops.conv_weight_grad(xd, gyd, wd, s, p)
+    check("streamk dW accumulated " + tag, wd.grad, 2 * wr.grad, 5e-6)
+    assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
+
+
+@pytest.mark.parametrize("case", [("(6,3) valid", 16, 10, 53, 256, 256, 6, 3, 1, 0), ("3x3 pad 1", 16, 10, 53, 256, 256, 3, 3, 1, 1)], ids=lambda c: c[0])
+@pytest.mark.parametrize("groups", ["IN", "BN"])
+def test_streamk_row_major_tile_order(ops, case, groups):
+    """Launches whose plan orders the GEMM rows image-row-major ((oy, b, ox): convsk.hip plan_build -- short images, >= 64 row tiles, >= 5 %
+    of the K steps culled): forward (+ statistics epilogue), input gradient and its normalisation-backward sums against float64."""
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    ng = B if groups == "IN" else 1
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    ops.begin_step()
+    yd, sums = ops.ConvStatsFn.apply(xd, wd, s, p, ng)
+    torch.cuda.synchronize()
+    check("row-major fwd %s %s" % (tag, groups), ops.cf_view(yd), y, 3e-6)
+    yg = y.permute(0, 2, 3, 1).reshape(ng, -1, Cout)
+    check("row-major fwd statistics %s %s" % (tag, groups), sums.view(ng, Cout, 2), torch.stack([yg.sum(1), (yg * yg).sum(1)], -1), 3e-6)
+    # input gradient with the statistics of the normalisation that produced x: sum gg, sum gg * yhat with gg = dx * act'(gamma * yhat + beta)
+    h = ops.NormBwdHolder()
+    h.y = ops.cl(torch.randn(x.shape, generator=g)).to(DEV)
+    h.mean = (torch.randn(ng, Cin, generator=g) * 0.1).to(DEV)
+    h.rstd = (torch.rand(ng, Cin, generator=g) + 0.5).to(DEV)
+    h.gamma, h.beta = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (torch.randn(Cin, generator=g) * 0.1).to(DEV)
+    h.groups, h.slope = ng, 0.2
+    dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p, h)
+    torch.cuda.synchronize()
+    check("row-major dX %s %s" % (tag, groups), ops.cf_view(dx), xr.grad, 3e-6)
+    assert h.sums is not None, "the input-gradient launch did not fuse the backward statistics"
+    dxg = xr.grad.permute(0, 2, 3, 1).reshape(ng, -1, Cin)
+    yh = (h.y.double().cpu().reshape(ng, -1, Cin) - h.mean.double().cpu()[:, None]) * h.rstd.double().cpu()[:, None]
+    pre = yh * h.gamma.double().cpu() + h.beta.double().cpu()
+    gg = dxg * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2))
+    check("row-major dX statistics %s %s" % (tag, groups), h.sums.view(ng, Cin, 2), torch.stack([gg.sum(1), (gg * yh).sum(1)], -1), 3e-6)
+    assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
