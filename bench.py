@@ -445,9 +445,9 @@ def main(argv=None):
                                 "by launch latency, not by HBM: at the MFMA roofline (%.0f us) it would still reach only %.0f %% of 8 TB/s"
                                 % (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) * 1e6,
                                    100 * mb * 1e6 / (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12)) / 1e12 / HBM_PEAK_TBS)}
-            hb = os.path.join(REPO, "profiles", "r02_hbm_kernels.txt")
-            if os.path.exists(hb):
-                out["hbm_kernels_table"] = "profiles/r02_hbm_kernels.txt (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)"
+            hbs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_kernels.txt")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
+            if hbs:
+                out["hbm_kernels_table"] = "profiles/%s (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)" % hbs[-1]
         if world == 1 and not stub and not args.no_alt_mode and args.conv_math == "f32" and not args.graph and on_gpu:
             # informational, OUTSIDE the timed region and not part of `value`: the same step with the conv products evaluated as
             # six bf16 MFMA products of exactly split operands (fp32-equivalent: passes the B=32 float64-calibrated parity tests,

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round evidence, run on the MI355X box: bash tools/collect_profiles.sh r02   (writes gpurun_out/<tag>_final/)
+# Round evidence, run on the MI355X box: bash tools/collect_profiles.sh r03   (writes gpurun_out/<tag>_final/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_final
@@ -16,10 +16,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 python tools/trace_summary.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape.txt" 2>&1
 python tools/stream_summary.py "$OUT/trace/b_kernel_trace.csv" 35 14 > "$OUT/streams.txt" 2>&1
 python tools/hbm_kernels.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 > "$OUT/hbm_kernels.txt" 2>&1
-# (3b) the opt-in launch-per-layer Conv1d stage: launch counts / durations by shape
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_fused" -o b -- $CMD --no-overlap-dw --no-kernel-events --fused-conv1d > "$OUT/trace_fused.log" 2>&1
-python tools/trace_summary.py "$OUT/trace_fused/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape_fused.txt" 2>&1
-rm -rf "$OUT/trace_fused"
+# (3b) PMC of the MFMA kernels, one launch set per layer and role (two passes: issue / stall split, instruction mix)
+bash tools/debug/pmc_conv.sh L1,L2,L3,L4,L5,L6,L7 fwd,dX,dW > "$OUT/pmc_conv.txt" 2>&1
 # (4) fabric-side traffic: two PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_fetch.log" 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_write.log" 2>&1

@@ -30,6 +30,7 @@ def per_kernel(path, counter):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         # the three epilogue instantiations (EPI = plain / + forward statistics / + backward statistics) are one kernel for bench.py
         name = re.sub(r"^(conv_taps_kernel<\d+, \d+, \w+, \d+), \d+>", r"\1>", name)
+        name = re.sub(r"^(convsk_kernel<\d+, \d+), \d+, \d+>", r"\1>", name)  # <BM, BN, EPI, workgroups per CU> -> bench.py's name
         tot[name] += float(r["Counter_Value"]) * 1024.0
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
@@ -49,7 +50,7 @@ def main():
                       "write_mb_per_launch": w[k] / nw[k] / 1e6}
     total = {k: (v["fetch_x2_mb_per_launch"] + v["write_mb_per_launch"]) * v["launches"] for k, v in kernels.items()}
     order = sorted(kernels, key=lambda k: -total[k])
-    dom = next(k for k in order if k.startswith("conv_taps_kernel"))
+    dom = next(k for k in order if k.startswith(("convsk_kernel", "conv_taps_kernel")))
     from bench import kernel_source_digest
     try:
         head = subprocess.run(["git", "-C", REPO, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
