@@ -26,6 +26,8 @@
 //     (profiles/r03_stage_errors_before.txt: the error grew with sqrt(K)); chunking brings it level.
 #include <type_traits>
 
+#include <vector>
+
 #include "common.h"
 
 #define SK_BK 32
@@ -46,6 +48,7 @@ struct sk_class {
 struct sk_args {
     sk_class cls[SK_MAXC];
     int ncls, nnb, T, G;
+    int ntmajor;            // one class only: tiles ordered n-tile major (tile = nt * nmb + mt), see plan_build
     int S;                  // total live K steps of the launch
     unsigned xbytes, wbytes, ybytes;
     const int4* rowinfo;    // [rows padded to BM per class]
@@ -251,6 +254,10 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
     while (c + 1 < P.ncls && tile >= P.cls[c + 1].tile_begin) ++c;
     int mt = (tile - P.cls[c].tile_begin) / P.nnb;
     int nt = (tile - P.cls[c].tile_begin) - mt * P.nnb;
+    if (P.ntmajor) {
+        nt = tile / P.cls[0].nmb;
+        mt = tile - nt * P.cls[0].nmb;
+    }
 
     // ------------------------------------------------------------------ per tile: set-up, pipeline fill, K loop, end phase.
     // (Issuing the next tile's set-up reads and first K steps under the stores of the finished tile was built and measured: it helps
@@ -489,7 +496,12 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
         pos = tbeg + b;
         if (pos >= s_end) break;
         ++tile;
-        if (++nt == P.nnb) {
+        if (P.ntmajor) {
+            if (++mt == P.cls[0].nmb) {
+                mt = 0;
+                ++nt;
+            }
+        } else if (++nt == P.nnb) {
             nt = 0;
             if (++mt == P.cls[c].nmb) {
                 mt = 0;
@@ -935,8 +947,13 @@ extern "C" int64_t sdt_convsk_workspace_bytes(void) { return (int64_t)512 * (128
 // Builds the plan into host memory `out` (sdt_convsk_plan_bytes bytes); the caller copies it to the device once per geometry.
 // rows_per_group > 0: statistics group of row m of class c = m / rows_per_group (forward statistics) -- for an input gradient with
 // normalisation-backward statistics pass -1: the group is the batch item (groups == B) or 0 (groups == 1), chosen by `bwd_groups`.
+static int g_sk_ntmajor_bytes = 2 << 20;
 static int g_sk_perm_pct = 95, g_sk_perm_pct_bwd = 95;  // image-row-major tile order when it leaves <= this many % of the K steps
 #ifdef SDT_TUNING
+extern "C" int sdt_convsk_set_ntmajor_bytes(int bytes) {
+    g_sk_ntmajor_bytes = bytes;
+    return SDT_OK;
+}
 extern "C" int sdt_convsk_set_perm_pct(int pct) {  // forward plans: pct % 1000, input-gradient plans: pct / 1000
     g_sk_perm_pct = pct % 1000;
     g_sk_perm_pct_bwd = pct / 1000;
@@ -967,6 +984,12 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     int* clsp = P + o_cls;
     int64_t row_begin = 0, mt_begin = 0, tile_begin = 0, S = 0;
     tilecum[0] = 0;
+    // Tile order.  Default: m-tile major, the n-tiles of an m-tile adjacent (they share the A rows).  With several n-tiles and weights that
+    // do not fit an XCD's L2 next to the streaming A rows (> 2 MB: L5-L7), n-tile major: the workgroups of an XCD own consecutive ranges
+    // = consecutive tiles, so an XCD then works on ONE n-tile's half of the weights for most of the launch.  (Workgroups of a stream-K launch
+    // sit at different K positions of their tiles, so unlike the one-tile-per-workgroup kernel nothing else keeps the weight reads of an XCD
+    // together: measured fabric traffic 2*FETCH+WRITE of the 128x128 launches 481 MB against 99 MB algorithmic before this.)
+    const bool ntmajor = kind == 0 && ncls == 1 && nnb > 1 && (int64_t)gs[0]->Cout * gs[0]->Tw * gs[0]->Cin * 4 > (int64_t)g_sk_ntmajor_bytes;
     for (int c = 0; c < ncls; ++c) {
         const sdt_conv_geom& g = *gs[c];
         const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
@@ -1070,11 +1093,24 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
             tileinfo[(mt_begin + mt) * 2] = (int)rmask;
             tileinfo[(mt_begin + mt) * 2 + 1] = rot;
             const int live = __builtin_popcount(mask) * nkc;
-            for (int nt = 0; nt < nnb; ++nt) {
-                const int64_t tile = tile_begin + (int64_t)mt * nnb + nt;
-                S += live;
-                tilecum[tile + 1] = (int)S;
+            if (ntmajor) {
+                tilecum[mt + 1] = live;  // per-m-tile step counts for now: the prefix sums in n-tile-major order follow the loop
+            } else {
+                for (int nt = 0; nt < nnb; ++nt) {
+                    const int64_t tile = tile_begin + (int64_t)mt * nnb + nt;
+                    S += live;
+                    tilecum[tile + 1] = (int)S;
+                }
             }
+        }
+        if (ntmajor) {
+            std::vector<int> live(nmb);
+            for (int mt = 0; mt < nmb; ++mt) live[mt] = tilecum[mt + 1];
+            for (int nt = 0; nt < nnb; ++nt)
+                for (int mt = 0; mt < nmb; ++mt) {
+                    S += live[mt];
+                    tilecum[(int64_t)nt * nmb + mt + 1] = (int)S;
+                }
         }
         int* cp = clsp + c * SK_CLS_INTS;
         cp[0] = g.Hi, cp[1] = g.Wi, cp[2] = g.Cin, cp[3] = g.Cout, cp[4] = g.ntaps, cp[5] = nkc;
@@ -1098,7 +1134,7 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
         while (tile + 1 < T && tilecum[tile + 1] <= s0) ++tile;
         range_tile[r] = (int)tile;
     }
-    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G, P[4] = ncls, P[5] = nnb, P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
+    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G, P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
     P[10] = (int)o_row, P[11] = (int)o_ti, P[12] = (int)o_cum, P[13] = (int)o_rt, P[14] = (int)o_cls, P[15] = (int)(o_cls + (int64_t)ncls * SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1128,7 +1164,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
     SDT_CHECK_ARG(P[0] == SK_MAGIC, "not a conv plan");
     SDT_CHECK_ARG(xbytes > 0 && wbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && wbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536,
                   "tensor sizes out of range");
-    A.G = P[3], A.ncls = P[4], A.nnb = P[5], A.T = P[6], A.S = P[7];
+    A.G = P[3], A.ncls = P[4], A.nnb = P[5] & 0xffff, A.ntmajor = P[5] >> 16, A.T = P[6], A.S = P[7];
     const int* D = (const int*)plan_dev;
     A.rowinfo = (const int4*)(D + P[10]);
     A.tileinfo = (const int2*)(D + P[11]);
@@ -1305,7 +1341,7 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
     SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
     SDT_CHECK_ARG(xbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536, "tensor sizes out of range");
     sk_args A;
-    A.G = P[3], A.ncls = 1, A.nnb = P[5], A.T = P[6], A.S = P[7];
+    A.G = P[3], A.ncls = 1, A.nnb = P[5], A.ntmajor = 0, A.T = P[6], A.S = P[7];
     const int K = P[9], ncol = P[5];
     const int* D = (const int*)plan_dev;
     A.rowinfo = (const int4*)(D + P[10]);

@@ -53,6 +53,9 @@ def main():
     if a.streamk > 0:
         from speechdrivestemplates_amd import _lib
         _lib.check(_lib.load().sdt_convsk_set_wg_per_cu(a.streamk))
+    if os.environ.get("SDT_SK_NTMAJOR"):  # tuning library: weight bytes above which a stream-K plan orders its tiles n-tile major
+        import ctypes
+        _lib.check(_lib.load().sdt_convsk_set_ntmajor_bytes(ctypes.c_int(int(os.environ["SDT_SK_NTMAJOR"]))))
     B = a.batch
     roles = a.roles.split(",")
     for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
