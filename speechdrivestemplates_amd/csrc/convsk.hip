@@ -8,14 +8,14 @@
 // peak -- and one wave per SIMD on a 128x128 tile with the feeding instructions interleaved between its own MFMAs sustains 0.91.
 //
 // Design.
-//   * grid = one workgroup (4 waves, 2x2) per CU slot, G = 256 * R workgroups, R = 1.  The launch's work is the list of (tile, live K step)
+//   * grid = one workgroup (4 waves, 2x2) per CU slot, G = 256 * R workgroups, R = 2 (R = 1 instantiated for A/B).  The launch's work is the list of (tile, live K step)
 //     pairs in tile order; workgroup r owns the contiguous range [r*S/G, (r+1)*S/G) of that list (stream-K): every CU gets the same
 //     number of K steps whatever the tile count, tap culling included (the host counts LIVE steps per tile).
 //   * a tile that straddles a range boundary is finished by the workgroup that owns its first step: the others store their partial
 //     accumulators write-through into a slab, drain, and raise a flag; the owner -- which reaches that tile at the END of its range, when
 //     the others (who meet it at the START of theirs) are long done -- polls the flags, adds the slabs in range order and runs the
 //     epilogue.  Fixed split points, fixed order: bit-identical from run to run.  (MI355X_MICROARCH.md, Guideline 16 recipe R1.)
-//   * tile 128x128x32 (wave tile 64x64 = 2x2 accumulators) or 256x64x32 (N = 64 layers; wave tile 128x32); two LDS buffers, ONE barrier
+//   * tile 128x128x32 (wave tile 64x64 = 2x2 accumulators) or 128x64x32 (N = 64 layers; wave tile 64x32); two LDS buffers, ONE barrier
 //     per K step; tile s+1 goes registers -> LDS[next] and the global loads of tile s+2 are issued BETWEEN the MFMAs of tile s
 //     (sched_group_barrier), so the in-order wave overlaps its own feeding with its own MFMAs.
 //   * no index arithmetic in the kernel: the host builds a PLAN per geometry pack (sdt_convsk_plan_*): per GEMM row {byte offset of the

@@ -58,8 +58,24 @@ class GraphedStep:
                 dst[k].copy_(v, non_blocking=True)
             elif isinstance(v, dict):
                 GraphedStep._copy_into(dst[k], v)
-            elif v != dst[k] and k != 'speaker':
+            elif k == 'speaker':
+                # the step resolves speaker[0]'s normalisation statistics on the HOST at capture time and bakes them into the graph:
+                # a batch of another speaker must not replay with them
+                if list(v)[:1] != list(dst[k])[:1]:
+                    raise RuntimeError('GraphedStep: speaker %r differs from the captured %r (its statistics are part of the graph)'
+                                       % (list(v)[:1], list(dst[k])[:1]))
+            elif not GraphedStep._same(v, dst[k]):
                 raise RuntimeError('GraphedStep: non-tensor field %r differs from the captured value' % k)
+
+    @staticmethod
+    def _same(a, b):
+        """equality that is safe for numpy arrays / lists of arrays (``a != b`` on arrays has no truth value)"""
+        import numpy as np
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+            return isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.shape == b.shape and bool(np.array_equal(a, b))
+        if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+            return len(a) == len(b) and all(GraphedStep._same(x, y) for x, y in zip(a, b))
+        return a == b
 
     def run(self, batch):
         """One training step on ``batch`` (device tensors with the collated layout).  The first ``warmup`` calls run

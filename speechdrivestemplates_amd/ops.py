@@ -246,12 +246,28 @@ class NormBwdHolder:
     output, for ONE-consumer chains (the audio encoder): the consumer's input-gradient launch accumulates the statistics the
     normalisation's backward needs in its epilogue (sdt_conv_taps_multi_f32 with sdt_norm_bwd) and leaves them in ``sums``; the
     normalisation's backward then skips its statistics pass over dz and y."""
-    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums", "zp")
+    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums", "zp", "dx_id")
 
     def __init__(self):
         self.y = self.mean = self.rstd = self.gamma = self.beta = self.sums = None
         self.groups, self.slope = 0, 0.0
+        self.dx_id = None  # (data_ptr, _version) of the gradient tensor whose launch accumulated ``sums``: see grad_matches()
         self.zp = None  # bf16 planes [3][numel] of the normalisation's OUTPUT z (pre-split pipeline, presplit.hip)
+
+
+HOLDER_HANDOVERS = {"used": 0, "refused": 0}  # tests: how often a normalisation backward took / refused the fused statistics
+
+
+def _holder_filled(h, dx):
+    """The consumer's input-gradient launch wrote ``dx`` and accumulated ``h.sums`` from exactly those values."""
+    h.dx_id = (dx.data_ptr(), dx._version, tuple(dx.shape))
+
+
+def _holder_grad_matches(h, gz):
+    """``h.sums`` describes the gradient the normalisation's backward receives only if that gradient IS the tensor the consumer's launch
+    wrote: one consumer, no hook that rescaled / clipped it (a new tensor), no in-place edit (version bump), no autograd accumulation of
+    a second consumer's gradient.  Otherwise the statistics pass runs."""
+    return h.dx_id is not None and h.dx_id == (gz.data_ptr(), gz._version, tuple(gz.shape))
 
 
 class BlockLink:
@@ -716,6 +732,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
                     and all((g.B * g.Ho * g.Wo if h.groups == 1 else g.Ho * g.Wo) >= 128 for g in gs)):
                 h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
                 nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+                _holder_filled(h, dx)
             _conv_launch_multi("dX", True, gs,
                                lambda: lib.sdt_conv_taps_pre_f32(_p(gy_planes), gy_planes.shape[1], _p(wpl[1]), wpl[1].shape[1], _p(dx),
                                                                  arr, n, None, 0, nb, st), pre=True,
@@ -733,6 +750,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
             if fuse:
                 h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
                 nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+                _holder_filled(h, dx)
             _conv_launch_multi("dX", True, gs, lambda: _sk_launch(plan, gy4, wt, None, dx, None, nb, st),
                                extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops, name=_sk_name(plan))
             return dx
@@ -747,6 +765,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
             h = norm_holder
             h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
             nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+            _holder_filled(h, dx)
         _conv_launch_multi("dX", not one_d, gs,
                            lambda: lib.sdt_conv_taps_multi_f32(_p(gy4), _p(wt), _p(dx), arr, n, k, _p(part), nb, st),
                            extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops)
@@ -1095,10 +1114,13 @@ class ColNormActFn(torch.autograd.Function):
         R = y.numel() // C // ctx.groups
         dy = torch.empty_like(y)
         h = ctx.holder
-        ready = h is not None and h.sums is not None  # accumulated by the epilogue of the conv that produced gz
+        # accumulated by the epilogue of the conv that produced gz -- trusted only if gz IS that launch's output tensor
+        ready = h is not None and h.sums is not None and _holder_grad_matches(h, gz)
+        if h is not None and h.sums is not None:
+            HOLDER_HANDOVERS["used" if ready else "refused"] += 1
         sums = h.sums if ready else _ARENA.take(2 * ctx.groups * C, y.device)
         if h is not None:
-            h.sums = None
+            h.sums = h.dx_id = None
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
         dyp = planes_like(dy) if (ctx.link is not None and presplit_on() and y.dim() == 4 and C % 32 == 0) else None

@@ -658,13 +658,34 @@ def test_fused_dx_classes_and_backward_statistics(ops, norm, stride):
             z2 = blk2.forward_cl(z1, h1, h2)
             if gout is None:
                 gout = torch.randn_like(z2)
+            before = dict(ops.HOLDER_HANDOVERS)
             z2.backward(gout)
             torch.cuda.synchronize()
             res[fused] = [xin.grad.clone()] + [p.grad.clone() for b in (blk1, blk2) for p in b.parameters()]
+            if fused:  # block 1's normalisation backward took the sums that block 2's input-gradient launch accumulated (the stride-1
+                # case is K-split at this size and does not fuse the statistics: nothing handed over, nothing refused)
+                assert ops.HOLDER_HANDOVERS["used"] == before["used"] + (1 if stride == 2 else 0) and ops.HOLDER_HANDOVERS["refused"] == before["refused"]
         finally:
             ops.FUSE_DX_CLASSES = ops.FUSE_BWD_STATS = True
     for a, b in zip(res[True], res[False]):
         check("fused vs unfused launches", a, b, 2e-5)
+    # the hand-over is refused when the gradient that reaches the normalisation is not the tensor the consumer's launch wrote (here: a
+    # hook that rescales it) -- the statistics pass runs and the result is the gradient of the modified graph
+    for b in (blk1, blk2):
+        for p in b.parameters():
+            p.grad = None
+    xin = x.clone().requires_grad_(True)
+    h1, h2 = ops.NormBwdHolder(), ops.NormBwdHolder()
+    z1 = blk1.forward_cl(xin, None, h1)
+    z1.register_hook(lambda g: g * 0.5)
+    z2 = blk2.forward_cl(z1, h1, h2)
+    before = dict(ops.HOLDER_HANDOVERS)
+    z2.backward(gout)
+    torch.cuda.synchronize()
+    assert ops.HOLDER_HANDOVERS["refused"] == before["refused"] + (1 if stride == 2 else 0) and ops.HOLDER_HANDOVERS["used"] == before["used"]
+    check("hooked gradient: dX is half the unhooked one", xin.grad, 0.5 * res[False][0], 2e-5)
+    for got, ref in zip([p.grad for p in blk1.parameters()], res[False][1:]):
+        check("hooked gradient: block-1 parameter gradients are half the unhooked ones", got, 0.5 * ref, 2e-5)
     # float64 reference of the chain
     def ref_block(blk, t):
         w = blk.conv.weight.detach().double().cpu().requires_grad_(True)

@@ -74,10 +74,11 @@ def main():
     lib.sdt_debug_set_timeline.restype = ctypes.c_int
     B = a.batch
     for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
-        if name not in a.only.split(",") or Hi == 1:
+        if name not in a.only.split(","):
             continue
-        x = torch.randn((B, Hi, Wi, Cin), device="cuda")
-        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kh, kw), device="cuda") * 0.05))
+        one_d = Hi == 1
+        x = torch.randn((B, Wi, Cin) if one_d else (B, Hi, Wi, Cin), device="cuda")
+        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kw) if one_d else (Cout, Cin, kh, kw), device="cuda") * 0.05))
         y = ops.conv_forward(x, w, None, s, p)
         gy = torch.randn_like(y)
         flops = 2.0 * y.numel() * Cin * kh * kw
