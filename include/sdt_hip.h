@@ -88,12 +88,13 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
 /*
  * Persistent stream-K form of the same convolution (csrc/convsk.hip; round 3) for the MFMA-bound Conv2d launches of the audio
  * encoder (generator.py:15-30 through building_blocks.py:15-22): forward (ncls = 1) or input gradient (ncls parity classes) with
- * Cin % 32 == 0 and Cout % 64 == 0.  One workgroup per CU walks a contiguous range of the launch's (tile, live K step) list, so every
+ * Cin % 32 == 0 and Cout % 64 == 0.  One or two resident workgroups per CU each walk a contiguous range of the launch's (tile, live K step) list, so every
  * CU gets the same number of K steps whatever the tile count; tiles that straddle two ranges are combined in a fixed order
- * (bit-identical from run to run).  128x128x32 or 256x64x32 tiles, software-pipelined, fp32 accumulation in chunks of 256 products.
+ * (bit-identical from run to run).  128x128x32 or 128x64x32 tiles, software-pipelined, fp32 accumulation in chunks of 256 products.
  *   sdt_convsk_supported     1 if the geometry pack qualifies
- *   sdt_convsk_plan_bytes    size of the PLAN of a geometry pack: per GEMM row {X byte offset, iy0 | ix0 << 16, Y element offset,
- *                            statistics group}, per m-tile {live-tap mask, tap rotation}, prefix sums of live K steps, first tile of
+ *   sdt_convsk_plan_bytes    size of the PLAN of a geometry pack: per GEMM row {X byte offset, mask of the taps outside X, Y byte offset,
+ *                            statistics group} (the row ORDER is the plan's choice: image-row-major where that culls >= 5 % of the K
+ *                            steps), per m-tile {live-tap mask, tap rotation}, prefix sums of live K steps, first tile of
  *                            each workgroup's range.  Built on the host once per geometry (sdt_convsk_plan_build), kept by the caller
  *                            in host AND device memory and handed to every launch
  *   rows_per_group > 0       statistics group of output row m = m / rows_per_group (forward statistics, as sdt_conv_taps_stats_f32);
@@ -111,7 +112,7 @@ int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls);
 int64_t sdt_convsk_workspace_bytes(void);
 int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes);
 /* Weight gradient of a forward geometry on the same persistent machinery (dense dY, Cout % 64 == 0, Cin % 64 == 0; 128- or 64-wide tiles):
- * the reduction over the output positions is split over the workgroups, partial 128x128 tiles go to slabs of `workspace`
+ * the reduction over the output positions is split over the workgroups, partial tiles go to slabs of `workspace`
  * (sdt_convsk_dw_workspace_bytes() bytes, contents irrelevant) and a second kernel adds them to dw (Cout, Tw, Cin) in a fixed order:
  * no atomics, bit-identical from run to run (what the reference asks of cuDNN with cudnn.deterministic = True, main.py:37-38).
  * ACCUMULATES into dw like sdt_conv_dw_f32.  Plan: sdt_convsk_dw_plan_bytes / _build, host + device copy as above. */
