@@ -199,6 +199,7 @@ def main(argv=None):
     ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
     ap.add_argument("--streamk-min-cout", type=int, default=None, help="experiment: GEMM width from which an input-gradient launch takes the stream-K kernel")
+    ap.add_argument("--no-small1d", action="store_true", help="tuning library only (SDT_HIP_LIB): 1-D launches on conv_taps_kernel instead of conv1d_small_kernel (A/B)")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
 
@@ -251,6 +252,10 @@ def main(argv=None):
             ops.STREAMK_MIN_STEPS = args.streamk_min_steps
         if args.streamk_min_cout is not None:
             ops.STREAMK_MIN_COUT = args.streamk_min_cout
+        if args.no_small1d:
+            import ctypes
+            from speechdrivestemplates_amd import _lib
+            _lib.check(_lib.load().sdt_debug_set_small1d(ctypes.c_int(0)))
             ops.STREAMK_MIN_COUT = 64
         ops.DEFER_SMALL_DW = not args.no_defer_dw
         ops.DETERMINISTIC_DW = not args.atomic_dw

@@ -571,6 +571,124 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The same contract for the launches of the 1-D stage (U-Net / decoder / pose encoder / discriminator: Hi = 1, M = B*T <= 2048 rows,
+// K split over blockIdx.z so that a workgroup has at most NS K steps).  These launches are latency-bound: the per-workgroup timeline of
+// conv_taps_kernel on them (tools/debug/taps_timeline.py --only c1d_k3_T64) reads 2.3 us of dispatch, 2.5 us prologue (tap tables through
+// LDS, two barriers), 0.9 us until the first tile is in LDS, 7.8 us for 6 K steps whose MFMA floor at two workgroups per CU is 5.1 us (each
+// step waits for the loads issued one step earlier), 2.2 us epilogue.  Here a workgroup issues the loads of ALL its K steps up front
+// (NS * 4 16-byte loads per thread: the whole latency is paid once), derives its row offsets with one division per row (1-D rows are
+// contiguous), and stores through branch-free buffer stores.  The products are accumulated in the order of conv_taps_kernel (same LDS
+// layout, same k permutation, same split points): results are BIT-identical to that kernel's.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void conv1d_small_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ Y, const geom_pack gp,
+                                                               const int splitk, float* __restrict__ partial, const size_t ysize) {
+    constexpr int BM = 64, BN = 64;
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDP];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDP];
+    __shared__ __attribute__((aligned(16))) int sOut[BM];
+    const sdt_conv_geom& gt = gp.g[blockIdx.y];
+    const int B = __builtin_amdgcn_readfirstlane(gt.B), Wi = __builtin_amdgcn_readfirstlane(gt.Wi), Cin = __builtin_amdgcn_readfirstlane(gt.Cin);
+    const int Wo = __builtin_amdgcn_readfirstlane(gt.Wo), Wy = __builtin_amdgcn_readfirstlane(gt.Wy), Cout = __builtin_amdgcn_readfirstlane(gt.Cout);
+    const int sx = __builtin_amdgcn_readfirstlane(gt.sx), osx = __builtin_amdgcn_readfirstlane(gt.osx), oox = __builtin_amdgcn_readfirstlane(gt.oox);
+    const int ntaps = __builtin_amdgcn_readfirstlane(gt.ntaps), Tw = __builtin_amdgcn_readfirstlane(gt.Tw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = B * Wo;
+    const int nmb = (M + BM - 1) / BM, nnb = Cout / BN;
+    if ((int)blockIdx.x >= nmb * nnb) return;  // the grid is sized for the largest class of the launch
+    const int lin = xcd_remap(blockIdx.x, nmb * nnb);
+    const int m0 = (lin / nnb) * BM, n0 = (lin % nnb) * BN;
+    const int nkc = Cin / BK;
+    const int nsteps_all = ntaps * nkc;
+    const int step0 = (int)(((long)blockIdx.z * nsteps_all) / splitk);
+    const int nsteps = (int)(((long)(blockIdx.z + 1) * nsteps_all) / splitk) - step0;  // <= NS (host-checked)
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((unsigned)B * Wi * Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((unsigned)Cout * Tw * Cin * 4u), 0x00020000);
+    const int kv = tid & 7, r0 = tid >> 3;
+    // this thread's two A rows: element index of input position ix0 = ox * sx (tap dx = 0) and ix0 itself; rows past M never load
+    int abase[2], aix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int b = m / Wo, ox = m - b * Wo;
+        aix[i] = m < M ? ox * sx : -(1 << 24);
+        abase[i] = (b * Wi + ox * sx) * Cin;
+    }
+    const int bbase[2] = {(n0 + r0) * Tw * Cin, (n0 + r0 + 32) * Tw * Cin};
+    f32x4 ra[NS][2], rb[NS][2];
+    {
+        int t = step0 / nkc, kc = step0 - t * nkc;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // branch-free masks (a uniform branch around a load makes hipcc drain vmcnt(0) at the merge): bit 31 of an offset = "no load"
+            const unsigned offm = (unsigned)(nsteps - 1 - s) & SDT_OOB;  // s >= nsteps
+            const int tt = min(t, ntaps - 1);
+            const int dx = gt.dx[tt], wt = gt.wt[tt];  // uniform: scalar loads from the kernel arguments
+            const int cs = (kc * BK + kv * 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ix = aix[i] + dx;
+                const unsigned rowm = ((unsigned)ix | (unsigned)(Wi - 1 - ix)) & SDT_OOB;  // ix < 0 or ix >= Wi (rows past M: ix << 0)
+                const unsigned ao = ((unsigned)((abase[i] + dx * Cin) * 4 + cs) & 0x7fffffffu) | rowm | offm;
+                ra[s][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ao, 0, 0));
+                const unsigned bo = (unsigned)((bbase[i] + wt * Cin) * 4 + cs) | offm;
+                rb[s][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)bo, 0, 0));
+            }
+            if (++kc == nkc) kc = 0, ++t;
+        }
+    }
+    if (tid < BM) {  // byte offset of the tile's output rows (SDT_OOB: past M)
+        const int m = m0 + tid;
+        const int b = m / Wo, ox = m - b * Wo;
+        sOut[tid] = m < M ? (int)((unsigned)((b * Wy + ox * osx + oox) * Cout) * 4u) : (int)SDT_OOB;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wofs = r0 * LDP + kv * 4;
+    const int fa = (wm * 32 + (lane & 31)) * LDP + (lane >> 5) * 4, fb = (wn * 32 + (lane & 31)) * LDP + (lane >> 5) * 4;
+    auto stage = [&](int s, int buf) {
+        *(f32x4*)&sA[buf][wofs] = ra[s][0];
+        *(f32x4*)&sA[buf][wofs + 32 * LDP] = ra[s][1];
+        *(f32x4*)&sB[buf][wofs] = rb[s][0];
+        *(f32x4*)&sB[buf][wofs + 32 * LDP] = rb[s][1];
+    };
+    stage(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s < nsteps) {  // uniform
+            if (s + 1 < NS && s + 1 < nsteps) stage(s + 1, (s + 1) & 1);  // the other buffer: its last readers passed the barrier below
+            const float* qa = &sA[s & 1][fa];
+            const float* qb = &sB[s & 1][fb];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *(const f32x4*)(qa + j * 8), b = *(const f32x4*)(qb + j * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); rows past M carry the out-of-range offset
+    float* out = splitk > 1 ? partial + (size_t)blockIdx.z * ysize : Y;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((unsigned)ysize * 4u), 0x00020000);
+    const int n = n0 + wn * 32 + (lane & 31);
+    const float bv = (bias != nullptr && splitk == 1) ? bias[n] : 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int4 o4 = *(const int4*)&sOut[wm * 32 + 8 * qq + 4 * (lane >> 5)];
+        const unsigned nb4 = (unsigned)n * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * qq + 0] + bv), rsY, (int)((unsigned)o4.x + nb4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * qq + 1] + bv), rsY, (int)((unsigned)o4.y + nb4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * qq + 2] + bv), rsY, (int)((unsigned)o4.z + nb4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * qq + 3] + bv), rsY, (int)((unsigned)o4.w + nb4), 0, 0);
+    }
+}
+
 #ifdef SDT_TUNING  // rejected experiment, kept only in the tuning build (tools/conv_bench.py)
 // ---------------------------------------------------------------------------------------------
 // conv_taps with asynchronous global->LDS staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, two
@@ -1378,6 +1496,29 @@ static geom_pack pack_of(const sdt_conv_geom* const* gs, int n) {
     return gp;
 }
 
+// conv1d_small_kernel takes a launch when every class is 1-D with full 32-channel chunks and 64-column tiles, the K slice of a workgroup
+// is at most SMALL1D_NS steps, the arithmetic is exact fp32 and no statistics epilogue is asked for
+#define SMALL1D_NS 8
+static bool g_small1d = true;
+#ifdef SDT_TUNING
+extern "C" int sdt_debug_set_small1d(int on) {
+    g_small1d = on != 0;
+    return SDT_OK;
+}
+#endif
+static bool small1d_ok(bool vec4, const sdt_conv_geom* const* gs, int ncls, int splitk, const norm_bwd_args& nb) {
+    if (!g_small1d || !vec4 || g_conv_math != SDT_MATH_F32 || nb.sums != nullptr) return false;
+    for (int c = 0; c < ncls; ++c) {
+        const sdt_conv_geom& g = *gs[c];
+        if (g.Hi != 1 || g.Ho != 1 || g.Hy != 1 || g.Cin % BK != 0 || g.Cout % 64 != 0) return false;
+        const int nsteps_all = g.ntaps * (g.Cin / BK);
+        if (cdiv(nsteps_all, splitk) > SMALL1D_NS) return false;
+        for (int t = 0; t < g.ntaps; ++t)
+            if (g.dy[t] != 0) return false;
+    }
+    return true;
+}
+
 // One launch for ``ncls`` geometries that share X, W and Y (blockIdx.y = class; the x extent covers the largest class).
 template <int BM, int BN>
 static void launch_taps(bool vec4, const float* x, const float* w, const float* bias, float* y,
@@ -1404,6 +1545,10 @@ static void launch_taps(bool vec4, const float* x, const float* w, const float* 
             case SDT_MATH_BF16X3: hipLaunchKernelGGL((conv_taps_bf_kernel<3, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
             default: hipLaunchKernelGGL((conv_taps_bf_kernel<6, BM, BN>), dim3(tiles, 1, splitk), dim3(256), 0, s, x, w, bias, y, g, splitk, partial, ysize); break;
         }
+        return;
+    }
+    if (small1d_ok(vec4, gs, ncls, splitk, nb) && BM == 64 && BN == 64) {
+        hipLaunchKernelGGL((conv1d_small_kernel<SMALL1D_NS>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize);
         return;
     }
 #define SDT_TAPS(PRIO) hipLaunchKernelGGL((conv_taps_kernel<BM, BN, true, PRIO>), grid, dim3(256), 0, s, x, w, bias, y, gp, splitk, partial, ysize, (double*)nullptr, 0, nb)
