@@ -989,7 +989,9 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     // = consecutive tiles, so an XCD then works on ONE n-tile's half of the weights for most of the launch.  (Workgroups of a stream-K launch
     // sit at different K positions of their tiles, so unlike the one-tile-per-workgroup kernel nothing else keeps the weight reads of an XCD
     // together: measured fabric traffic 2*FETCH+WRITE of the 128x128 launches 481 MB against 99 MB algorithmic before this.)
-    const bool ntmajor = kind == 0 && ncls == 1 && nnb > 1 && (int64_t)gs[0]->Cout * gs[0]->Tw * gs[0]->Cin * 4 > (int64_t)g_sk_ntmajor_bytes;
+    // (from 64 row tiles up, like the row-major order below: on small launches neither ordering buys anything)
+    const bool ntmajor = kind == 0 && ncls == 1 && nnb > 1 && (int64_t)gs[0]->Cout * gs[0]->Tw * gs[0]->Cin * 4 > (int64_t)g_sk_ntmajor_bytes &&
+                         cdiv64((int64_t)gs[0]->B * gs[0]->Ho * gs[0]->Wo, bm) >= 64;
     for (int c = 0; c < ncls; ++c) {
         const sdt_conv_geom& g = *gs[c];
         const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
