@@ -138,6 +138,9 @@ int sdt_conv_dw_det_f32(const float* x, const float* dy, float* dw, const sdt_co
 /* Which kernel instantiation the two entry points above pick for a geometry (16-B aligned operands assumed):
  * (BM*1000+BN)*10 + vec4, e.g. 1281281 = conv_taps_kernel<128,128,true>.  Used by bench.py to attribute timings. */
 int sdt_conv_taps_variant(const sdt_conv_geom* g);
+/* 1 when sdt_conv_taps_f32 / _splitk_f32 / _multi_f32 on these classes with this K split run the 1-D stage's small-K kernel
+ * (conv1d_small_kernel: Hi = 1, Cin % 32 == 0, Cout % 64 == 0, <= 8 K steps per workgroup, exact fp32, no statistics epilogue) */
+int sdt_conv1d_small_used(const sdt_conv_geom* geoms, int ncls, int splitk);
 int sdt_conv_dw_variant(const sdt_conv_geom* g);
 /* (Cout,T,Cin) -> (Cin,T,Cout): operand layout for the input-gradient GEMM. */
 int sdt_weight_transpose_f32(const float* w, float* wt, int cout, int taps, int cin, void* stream);

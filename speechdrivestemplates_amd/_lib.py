@@ -57,6 +57,7 @@ SIGNATURES = {
     "sdt_conv_taps_splitk_f32": [_p, _p, _p, _p, _G, _i, _p, _p],
     "sdt_splitk_reduce_f32": [_p, _p, _p, _i64, _i, _i, _p],
     "sdt_conv_taps_variant": [_G],
+    "sdt_conv1d_small_used": [_G, _i, _i],
     "sdt_conv_dw_variant": [_G],
     "sdt_weight_transpose_f32": [_p, _p, _i, _i, _i, _p],
     "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],

@@ -1612,6 +1612,15 @@ static int taps_variant(const sdt_conv_geom* g, bool aligned) {
     return 64064 * 10 + vec4;
 }
 extern "C" int sdt_conv_taps_variant(const sdt_conv_geom* g) { return g ? taps_variant(g, true) : SDT_ERR_ARG; }
+// 1 when a launch of these classes with this K split runs conv1d_small_kernel (16-byte aligned operands assumed), else 0: lets the host
+// label its per-launch timings with the kernel that a trace will show
+extern "C" int sdt_conv1d_small_used(const sdt_conv_geom* geoms, int ncls, int splitk) {
+    if (!geoms || ncls < 1 || ncls > SDT_MAX_CLASSES || splitk < 1) return SDT_ERR_ARG;
+    const sdt_conv_geom* gs[SDT_MAX_CLASSES];
+    for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
+    const int var = taps_variant(gs[0], true);
+    return (var / 10 == 64064 && small1d_ok(var % 10, gs, ncls, splitk, kNoNormBwd)) ? 1 : 0;
+}
 
 // Suggested split of the K loop for launches that cannot fill 256 CUs with output tiles (the 1-D stage:
 // M = B*T <= 2048 rows): enough slices for >= 2 workgroups per CU while keeping >= 4 K-steps per slice.

@@ -383,6 +383,8 @@ def _conv_launch(kind, is2d, g, call, flops=None, name=None):
     e0.record()
     check(call())
     e1.record()
+    if name is None and kind != "dW" and not is2d and _CONV_MATH_NOW[0] == 0 and lib.sdt_conv1d_small_used(g, 1, max(1, _splitk_hint(lib, g))) == 1:
+        name = "conv1d_small_kernel<8>"
     PROFILER.records.append((name or ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
@@ -404,6 +406,10 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=N
     e0.record()
     check(call())
     e1.record()
+    if name is None and not pre and not is2d and _CONV_MATH_NOW[0] == 0:
+        arr = (ConvGeom * len(gs))(*gs)
+        if lib.sdt_conv1d_small_used(arr, len(gs), max(_splitk_hint(lib, g) for g in gs)) == 1:
+            name = "conv1d_small_kernel<8>"
     name = name or ("conv_taps_pre_kernel (bf16x6 products, pre-split operands)" if pre else ConvProfiler.kernel_name(kind, var))
     PROFILER.records.append((name, kind, is2d, flops, nbytes, e0, e1))
 
