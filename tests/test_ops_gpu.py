@@ -790,7 +790,6 @@ def test_presplit_chain_matches_float64(ops, norm):
     blk1 = ConvNormRelu('2d', 32, 64, downsample=False, norm=norm, leaky=True).to(DEV).train()
     blk2 = ConvNormRelu('2d', 64, 64, downsample=True, norm=norm, leaky=True).to(DEV).train()
     blk3 = ConvNormRelu('2d', 64, 32, downsample=False, norm=norm, leaky=True).to(DEV).train()
-    opt = FlatAdam([p for b in (blk1, blk2, blk3) for p in b.parameters()])  # owns the weight mirrors / planes
     x = torch.randn(B, H, W, 32, device=DEV)
     calls = []
     lib = _lib.load()
@@ -803,7 +802,9 @@ def test_presplit_chain_matches_float64(ops, norm):
     ops.set_conv_math("bf16x6")
     prev_presplit = ops.PRESPLIT
     ops.PRESPLIT = True  # experiment (tuning library)
+    opt = None
     try:
+        opt = FlatAdam([p for b in (blk1, blk2, blk3) for p in b.parameters()])  # owns the weight mirrors and, with PRESPLIT on, their bf16 planes
         lib.sdt_conv_taps_pre_f32 = Spy()
         xin = x.clone().requires_grad_(True)
         h1, h2, h3 = ops.NormBwdHolder(), ops.NormBwdHolder(), ops.NormBwdHolder()
