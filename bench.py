@@ -376,7 +376,7 @@ def main(argv=None):
                        "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw,
                        # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
                        # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
-                       # fp32 depends on the arrival order with probability ~1e-3 per step (Normalisation)
+                       # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)
                        "deterministic": bool(not args.atomic_dw and not args.no_streamk_dw and args.conv_math == "f32")},
             "final_G_loss": final_loss,
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
