@@ -48,7 +48,7 @@ def golden_traj():
 # Every `check(name, got, ref, tol)` of the GPU tests keeps its STATED tolerance `tol` (the claim) and is additionally held to 10x the
 # error this very check measured when tests/golden/margins.json was recorded (the kernels are deterministic: the same seeded inputs give
 # the same error on every box, up to the order noise of the few fp32-atomic opt-out paths), with a floor of 2e-7 (fp32 resolution).
-# Re-record after an intended numerical change:  SDT_RECORD_MARGINS=tests/golden/margins.json python -m pytest tests -m gpu
+# Re-record after an intended numerical change:  bash tools/debug/record_margins.sh (SDT_RECORD_MARGINS=... python -m pytest tests -m gpu)
 MARGIN_FACTOR, MARGIN_FLOOR = 10.0, 2e-7
 _MARGINS, _SEEN = None, {}
 

@@ -1,3 +1,4 @@
+# re-record tests/golden/margins.json + the parity tables on the MI355X box (outputs under gpurun_out/; copy margins.json to tests/golden/ afterwards)
 cd $GRAFT_REPO_ROOT
 rm -f gpurun_out/margins.json gpurun_out/parity_tables.txt
 SDT_PARITY_TABLES=gpurun_out/parity_tables.txt SDT_RECORD_MARGINS=gpurun_out/margins.json SDT_RECORD_MARGINS_MAX=1 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_rec1.txt 2>&1
