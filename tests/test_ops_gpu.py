@@ -980,3 +980,32 @@ def test_streamk_row_major_tile_order(ops, case, groups):
     gg = dxg * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2))
     check("row-major dX statistics %s %s" % (tag, groups), h.sums.view(ng, Cin, 2), torch.stack([gg.sum(1), (gg * yh).sum(1)], -1), 3e-6)
     assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
+
+
+def test_statistics_sums_do_not_depend_on_the_arrival_order(ops):
+    """The normalisation statistics are fp64 atomics over per-32-row-block fp32 partial sums.  Such a sum is exact in fp64 (24-bit terms of similar
+    magnitude, <= 2^10 of them), hence independent of the order in which the workgroups arrive: repeated launches of the forward
+    and the backward statistics epilogues give BITWISE identical fp64 sums."""
+    torch.manual_seed(5)
+    B = 16
+    for (Hi, Wi, Cin, Cout, k, s, p) in [(20, 106, 128, 256, 3, 1, 1), (40, 213, 64, 128, 3, 1, 1)]:
+        x = torch.randn((B, Hi, Wi, Cin), device=DEV)
+        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, k, k), device=DEV) * 0.05))
+        first = None
+        for rep in range(6):
+            ops.begin_step()
+            y, sums = ops.ConvStatsFn.apply(x, w, s, p, B)
+            if rep == 0:
+                gy = torch.randn_like(y)
+                hy, hm, hr = torch.randn_like(x), torch.randn((B, Cin), device=DEV) * 0.1, torch.rand((B, Cin), device=DEV) + 0.5
+            h = ops.NormBwdHolder()
+            h.y, h.mean, h.rstd, h.gamma, h.beta, h.groups, h.slope = hy, hm, hr, None, None, B, 0.2
+            ops.conv_input_grad(gy, w, x.shape, s, p, h)
+            torch.cuda.synchronize()
+            assert h.sums is not None
+            now = (sums.clone().view(torch.int64), h.sums.clone().view(torch.int64))
+            if first is None:
+                first = now
+            else:
+                assert torch.equal(now[0], first[0]), "forward statistics differ between launches"
+                assert torch.equal(now[1], first[1]), "backward statistics differ between launches"
