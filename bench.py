@@ -338,6 +338,9 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     if ops is not None:
         ops.PROFILER, ops.STAGES, ops.OVERLAP_DW = None, None, overlap_dw
+        if on_gpu and not stub:  # a stream-K launch that gave up waiting for a partial tile would have left a code (and wrong results)
+            codes = ops.streamk_error_codes()
+            assert not codes, "stream-K error words: %r" % codes
     prof_steps = n_alone
     if marks is not None:
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]

@@ -33,6 +33,8 @@ def main():
     # (the very first steps have no KL term: zero-initialised clip codes have zero batch variance and the reference skips
     #  the term then, voice2pose.py:154 -- compare from the first sample after that)
     assert hist[-1] < hist[1], "loss did not decrease"
+    from speechdrivestemplates_amd import ops
+    assert not ops.streamk_error_codes(), "stream-K error words: %r" % ops.streamk_error_codes()
     # blocks handed to the side streams (record_stream) are recycled only when the GPU has passed their last use; with the
     # host's lead bounded (ops.MAX_STEPS_IN_FLIGHT) the caching allocator's reserve settles at ~3.5x the 1.2 GiB working
     # set (it was ~17x, and creeping, with an unbounded lead) and must be flat over the second half of the run
