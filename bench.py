@@ -376,7 +376,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
                        # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
                        # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
                        # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)

@@ -108,6 +108,9 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
 int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls);
 int sdt_convsk_grid(void);
 int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for plans built afterwards (default 2) */
+/* Workgroup slots (multiple of 8, < 256) that plans built afterwards leave free: a persistent launch that fills the GPU cannot share it with another
+ * long-lived kernel (a collective's); data-parallel runs plan their backward launches with a reserve.  Default 0. */
+int sdt_convsk_set_reserved_slots(int n);
 int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls);
 int64_t sdt_convsk_workspace_bytes(void);
 int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes);

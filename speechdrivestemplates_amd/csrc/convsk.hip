@@ -886,6 +886,18 @@ extern "C" int sdt_convsk_set_wg_per_cu(int n) {
     return SDT_OK;
 }
 
+// Workgroup slots left free by plans built afterwards (multiple of 8, < 256): a persistent launch that fills every slot of the GPU cannot share it
+// with another long-lived kernel -- the kernels of a collective (RCCL all-reduce: a few dozen workgroups that live for the whole exchange) take slots,
+// the conv workgroups that find none start when the first ones END, and the launch takes twice as long with 6 % of the GPU working
+// (tools/debug/comm_emulation.py: 32 such workgroups for 1.2 ms of a step cost 5.5 %, for 3 ms 23 %).  Data-parallel runs therefore plan their BACKWARD
+// launches -- the ones a gradient exchange overlaps -- with a reserve (speechdrivestemplates_amd/dp.py).
+static int g_sk_reserve = 0;
+extern "C" int sdt_convsk_set_reserved_slots(int n) {
+    SDT_CHECK_ARG(n >= 0 && n < 256 && n % 8 == 0, "reserve must be a multiple of 8 below 256");
+    g_sk_reserve = n;
+    return SDT_OK;
+}
+
 static void sk_tile_choice(const sdt_conv_geom& g, int& bm, int& bn) {
     if (g.Cout % 128 == 0) bm = 128, bn = 128;
     else if (g_sk_wpc == 1) bm = 256, bn = 64;
@@ -911,7 +923,7 @@ static void plan_shape(const sdt_conv_geom& g, int kind, int& bm, int& bn, int& 
         bm = 64, bn = 64, G = 8;
     } else {
         sk_tile_choice(g, bm, bn);
-        G = 256 * g_sk_wpc;
+        G = 256 * g_sk_wpc - g_sk_reserve;
     }
 }
 
@@ -927,7 +939,7 @@ extern "C" int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls) { retu
 extern "C" int sdt_convtab_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 1); }
 
 // grid of a plan (number of persistent workgroups): one per CU
-extern "C" int sdt_convsk_grid(void) { return 256 * g_sk_wpc; }
+extern "C" int sdt_convsk_grid(void) { return 256 * g_sk_wpc - g_sk_reserve; }
 
 static int64_t plan_bytes(const sdt_conv_geom* geoms, int ncls, int kind) {
     if (!plan_supported(geoms, ncls, kind)) return -1;
@@ -1136,7 +1148,7 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
         while (tile + 1 < T && tilecum[tile + 1] <= s0) ++tile;
         range_tile[r] = (int)tile;
     }
-    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G, P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
+    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G | ((kind == 1 ? 0 : g_sk_wpc) << 16), P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
     P[10] = (int)o_row, P[11] = (int)o_ti, P[12] = (int)o_cum, P[13] = (int)o_rt, P[14] = (int)o_cls, P[15] = (int)(o_cls + (int64_t)ncls * SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1166,7 +1178,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
     SDT_CHECK_ARG(P[0] == SK_MAGIC, "not a conv plan");
     SDT_CHECK_ARG(xbytes > 0 && wbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && wbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536,
                   "tensor sizes out of range");
-    A.G = P[3], A.ncls = P[4], A.nnb = P[5] & 0xffff, A.ntmajor = P[5] >> 16, A.T = P[6], A.S = P[7];
+    A.G = P[3] & 0xffff, A.ncls = P[4], A.nnb = P[5] & 0xffff, A.ntmajor = P[5] >> 16, A.T = P[6], A.S = P[7];
     const int* D = (const int*)plan_dev;
     A.rowinfo = (const int4*)(D + P[10]);
     A.tileinfo = (const int2*)(D + P[11]);
@@ -1216,8 +1228,8 @@ extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias,
     const int bm = P[1], bn = P[2];
     hipStream_t s = (hipStream_t)stream;
     const int epi = stats ? 1 : (nbw ? 2 : 0);
-    const int wpc = A.G / 256;
-    SDT_CHECK_ARG(A.G == 256 || A.G == 512, "plan built for an unknown grid");
+    const int wpc = P[3] >> 16;  // workgroups per CU the plan was built for (its grid may leave reserved slots free)
+    SDT_CHECK_ARG((wpc == 1 || wpc == 2) && A.G > 0 && A.G <= 256 * wpc && A.G % 8 == 0, "plan built for an unknown grid");
 #define SK_GO(BM_, BN_, WPC_)                                                              \
     do {                                                                                    \
         if (epi == 0) sk_launch<BM_, BN_, 0, WPC_>(x, w, bias, y, A, stats, 0, nb, s);      \
@@ -1279,7 +1291,7 @@ extern "C" int sdt_convsk_dw_supported(const sdt_conv_geom* g) {
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
     const int bm = g->Cout % 128 == 0 ? 128 : 64, bn = (g->ntaps * g->Cin) % 128 == 0 ? 128 : 64;
     const int64_t K = cdiv64(M, 32), T = (int64_t)(g->Cout / bm) * ((int64_t)g->ntaps * g->Cin / bn);
-    const int G = 256 * g_sk_wpc;
+    const int G = 256 * g_sk_wpc - g_sk_reserve;
     return T <= G && K >= 8 * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 steps each
 }
 // plan of a weight gradient: header + per-row table of the forward geometry (rows padded to a multiple of 32 + two extra steps)
@@ -1300,7 +1312,7 @@ extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int6
     const int bm = g.Cout % 128 == 0 ? 128 : 64, bn = (g.ntaps * g.Cin) % 128 == 0 ? 128 : 64;
     const int ncol = g.ntaps * g.Cin / bn;
     const int64_t T = (int64_t)(g.Cout / bm) * ncol;
-    const int G = 256 * g_sk_wpc;
+    const int G = 256 * g_sk_wpc - g_sk_reserve;
     int* rowinfo = P + SK_HDR;
     for (int64_t m = 0; m < rows; ++m) {
         int* ri = rowinfo + m * 4;
@@ -1328,7 +1340,7 @@ extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int6
         cp[11 + SDT_MAX_TAPS + t] = on ? g.wt[t] : 0;  // the weight-gradient kernels read wt[t] here
         cp[11 + 2 * SDT_MAX_TAPS + t] = 0;
     }
-    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G, P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
+    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16), P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
     P[10] = SK_HDR, P[11] = 0, P[12] = 0, P[13] = 0, P[14] = (int)(SK_HDR + rows * 4), P[15] = (int)(SK_HDR + rows * 4 + SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1343,7 +1355,7 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
     SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
     SDT_CHECK_ARG(xbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536, "tensor sizes out of range");
     sk_args A;
-    A.G = P[3], A.ncls = 1, A.nnb = P[5], A.ntmajor = 0, A.T = P[6], A.S = P[7];
+    A.G = P[3] & 0xffff, A.ncls = 1, A.nnb = P[5], A.ntmajor = 0, A.T = P[6], A.S = P[7];
     const int K = P[9], ncol = P[5];
     const int* D = (const int*)plan_dev;
     A.rowinfo = (const int4*)(D + P[10]);
@@ -1368,7 +1380,7 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
         }                                                                                                                      \
         hipLaunchKernelGGL((convsk_dw_kernel<BM_, BN_, WPC_>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace); \
     } while (0)
-    const int wpc = A.G / 256;
+    const int wpc = P[3] >> 16;
     if (bm == 128 && bn == 128 && wpc == 2) DW_GO(128, 128, 2);
     else if (bm == 128 && bn == 128) DW_GO(128, 128, 1);
     else if (bm == 128 && bn == 64 && wpc == 2) DW_GO(128, 64, 2);

@@ -744,3 +744,20 @@ extern "C" int sdt_time_diff_bwd_f32(const float* dy, float* dx, int B, int T, i
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
+
+#ifdef SDT_TUNING
+// tools/debug/comm_emulation.py: `wgs` workgroups of 256 threads that hold their CU slots for `us` microseconds -- what a collective's kernels
+// (RCCL all-reduce: a few dozen long-lived workgroups) look like to the persistent conv kernels that share the GPU with them.
+__global__ __launch_bounds__(256) void debug_spin_kernel(long long ticks) {
+    extern __shared__ float spin_lds[];  // sized by the launch: an LDS footprint keeps the workgroup from slipping in beside two conv workgroups
+    if (ticks < 0) spin_lds[threadIdx.x] = 0.f;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int sdt_debug_spin(int wgs, int us, int lds_bytes, void* stream) {
+    SDT_CHECK_ARG(wgs > 0 && wgs <= 4096 && us > 0 && lds_bytes >= 0 && lds_bytes <= 65536, "bad arguments");
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (long long)us * 100);  // 100 MHz counter
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+#endif

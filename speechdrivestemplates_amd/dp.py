@@ -14,6 +14,12 @@ import torch
 import torch.distributed as dist
 
 
+# Workgroup slots (of 512) that backward stream-K launches leave free while a gradient exchange can be in flight.  Measured on one GPU with an
+# emulated collective (tools/debug/comm_emulation.py: 32 workgroups holding their slots for 1.2 ms of each step): 8.00 ms per step without a
+# reserve, 7.90 with 32; the reserve itself costs 2.8 % when nothing else runs (7.54 -> 7.78 ms), which is why it is not the single-GPU default.
+RESERVED_SLOTS = 32
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -104,6 +110,11 @@ class GradReducer:
         self.comm_stream = None
         if self.active and overlap and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
             self.comm_stream = torch.cuda.Stream()
+        if self.active and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
+            # the exchange's kernels (RCCL: a few dozen workgroups that live for a whole all-reduce) overlap the Conv2d backward, whose
+            # persistent stream-K launches would otherwise occupy every workgroup slot of the GPU: leave the collective room (ops.SK_RESERVED_SLOTS)
+            from . import ops
+            ops.SK_RESERVED_SLOTS = RESERVED_SLOTS
         self._pending = []
         # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
         # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide

@@ -428,13 +428,17 @@ class _SKPlan:
     """Host + device copy of a stream-K plan (built once per geometry pack; geometries are cached objects, see fwd_geom / dx_pack)."""
     __slots__ = ("host", "dev", "keep", "kind")
 
-    def __init__(self, garr, n, rpg, bwd_groups, dev, kind="sk"):
+    def __init__(self, garr, n, rpg, bwd_groups, dev, kind="sk", reserve=0):
         import ctypes as C
         lib = _lib.load()
-        nbytes = (lib.sdt_convsk_plan_bytes if kind == "sk" else lib.sdt_convtab_plan_bytes)(garr, n)
-        self.host = (C.c_int32 * (nbytes // 4))()
         self.kind = kind
-        check((lib.sdt_convsk_plan_build if kind == "sk" else lib.sdt_convtab_plan_build)(garr, n, int(rpg), int(bwd_groups), C.addressof(self.host), nbytes))
+        check(lib.sdt_convsk_set_reserved_slots(int(reserve) if kind == "sk" else 0))  # process-wide knob of the plan builder: set, build, reset
+        try:
+            nbytes = (lib.sdt_convsk_plan_bytes if kind == "sk" else lib.sdt_convtab_plan_bytes)(garr, n)
+            self.host = (C.c_int32 * (nbytes // 4))()
+            check((lib.sdt_convsk_plan_build if kind == "sk" else lib.sdt_convtab_plan_build)(garr, n, int(rpg), int(bwd_groups), C.addressof(self.host), nbytes))
+        finally:
+            check(lib.sdt_convsk_set_reserved_slots(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
         self.keep = garr  # the key holds id(garr): keep it alive
 
@@ -444,6 +448,10 @@ class _SKPlan:
 # tile) and loses on the 64-wide outputs and on the 2x2-tap parity classes of strided input gradients, which stay with the 64x64 kernel.
 # FORWARD launches all take it (where it loses, L4: -3 %, L1 / L2: par): its chunked accumulation is what puts the forward error of
 # every Conv2d layer level with the reference's blocked sums (tests/test_fullsize_gpu.py::test_b32_forward_stage_error_table).
+# Workgroup slots that the plans of BACKWARD launches (input gradients, weight gradients) leave free.  0 on one GPU.  dp.GradReducer sets it in
+# data-parallel runs: a persistent launch that fills every slot cannot share the GPU with the long-lived workgroups of a collective -- they wait
+# for slots, or take them and strand the conv workgroups that find none (tools/debug/comm_emulation.py) -- and the gradient exchange overlaps backward
+SK_RESERVED_SLOTS = 0
 STREAMK_MIN_STEPS = 48   # input gradients: K steps (of 32) per output tile, nominal: taps * Cin / 32
 STREAMK_MIN_COUT = 128
 STREAMK_ALL_FORWARD = True
@@ -462,7 +470,8 @@ TAB_CHUNK = 8        # K steps per accumulation chunk of that kernel (0: one acc
 def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the plan (stream-K where that kernel is wanted, else the
     64x64 table-driven kernel's) or None when the pack qualifies for neither."""
-    key = (id(garr), int(rpg), int(bwd_groups), dev.index, bool(forward))
+    reserve = 0 if forward else int(SK_RESERVED_SLOTS)
+    key = (id(garr), int(rpg), int(bwd_groups), dev.index, bool(forward), reserve)
     plan = _SK_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
@@ -472,7 +481,7 @@ def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False):
             "tab" if (USE_TAB and g0.Hi > 1 and lib.sdt_convtab_supported(garr, n)) else None)
         if kind is not None:
             try:
-                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, kind)
+                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, kind, reserve)
             except RuntimeError:  # e.g. too few K steps for a 256-way split (the 1-D stage): the 64x64 kernel takes it
                 plan = None
         _SK_PLANS[key] = plan
@@ -520,21 +529,32 @@ USE_STREAMK_DW = True  # weight gradients of the 2-D layers with Cout % 128 == 0
 class _SKDwPlan:
     __slots__ = ("host", "dev", "keep")
 
-    def __init__(self, g, dev):
+    def __init__(self, g, dev, reserve=0):
         import ctypes as C
         lib = _lib.load()
-        nbytes = lib.sdt_convsk_dw_plan_bytes(g)
-        self.host = (C.c_int32 * (nbytes // 4))()
-        check(lib.sdt_convsk_dw_plan_build(g, C.addressof(self.host), nbytes))
+        check(lib.sdt_convsk_set_reserved_slots(int(reserve)))
+        try:
+            nbytes = lib.sdt_convsk_dw_plan_bytes(g)
+            self.host = (C.c_int32 * (nbytes // 4))()
+            check(lib.sdt_convsk_dw_plan_build(g, C.addressof(self.host), nbytes))
+        finally:
+            check(lib.sdt_convsk_set_reserved_slots(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
         self.keep = g
 
 
 def _sk_dw_plan(g, dev):
-    key = (id(g), dev.index)
+    reserve = int(SK_RESERVED_SLOTS)
+    key = (id(g), dev.index, reserve)
     plan = _SK_DW_PLANS.get(key, False)
     if plan is False:
-        plan = _SKDwPlan(g, dev) if _lib.load().sdt_convsk_dw_supported(g) else None
+        lib = _lib.load()
+        check(lib.sdt_convsk_set_reserved_slots(reserve))  # "supported" depends on the grid (K steps per chunk)
+        try:
+            ok = lib.sdt_convsk_dw_supported(g)
+        finally:
+            check(lib.sdt_convsk_set_reserved_slots(0))
+        plan = _SKDwPlan(g, dev, reserve) if ok else None
         _SK_DW_PLANS[key] = plan
         if plan is None:
             _SK_DW_PLANS[("keep", id(g))] = g

@@ -404,6 +404,9 @@ def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
             if forced:
                 os.environ.pop("SDT_DP_FORCE", None)
                 dist.destroy_process_group()
+                from speechdrivestemplates_amd import ops as _ops
+                assert _ops.SK_RESERVED_SLOTS == dp.RESERVED_SLOTS  # an active reducer makes the backward stream-K launches leave room for the collective
+                _ops.SK_RESERVED_SLOTS = 0                          # ... a process-wide setting: back to the single-GPU default for the tests that follow
     for a, b in zip(hist[False][0], hist[True][0]):
         assert abs(a - b) <= tol * abs(a), hist
     assert torch.isfinite(hist[True][1]).all()

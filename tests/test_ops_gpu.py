@@ -1009,3 +1009,37 @@ def test_statistics_sums_do_not_depend_on_the_arrival_order(ops):
             else:
                 assert torch.equal(now[0], first[0]), "forward statistics differ between launches"
                 assert torch.equal(now[1], first[1]), "backward statistics differ between launches"
+
+
+def test_streamk_plans_with_reserved_slots(ops):
+    """Data-parallel runs plan their backward stream-K launches with workgroup slots left free for the collective's kernels
+    (ops.SK_RESERVED_SLOTS, set by dp.GradReducer): the grid shrinks, forward plans keep the whole GPU, results stay within the fp32 bars."""
+    tag, B, Hi, Wi, Cin, Cout, k, s, p = ("reserve", 16, 20, 106, 128, 256, 3, 1, 1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) * (2.0 / (Cin * k * k)) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    prev = ops.SK_RESERVED_SLOTS
+    try:
+        ops.SK_RESERVED_SLOTS = 32
+        yd = ops.conv_forward(xd, wd, None, s, p)
+        dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
+        ops.conv_weight_grad(xd, gyd, wd, s, p)
+        torch.cuda.synchronize()
+        grids = {(key[4], key[5]): plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if len(key) == 6 and plan is not None and key[5] == 32}
+        dw_grids = [plan.host[3] & 0xffff for key, plan in ops._SK_DW_PLANS.items() if len(key) == 3 and plan is not None and key[2] == 32]
+    finally:
+        ops.SK_RESERVED_SLOTS = prev
+    assert grids and all(v == 480 for v in grids.values()), grids       # backward plans: 512 - 32 workgroups
+    assert dw_grids and all(v == 480 for v in dw_grids), dw_grids
+    fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if len(key) == 6 and plan is not None and key[4] and key[5] == 0]
+    assert fwd and all(v == 512 for v in fwd), fwd                       # forward plans keep every slot
+    check("reserve fwd", ops.cf_view(yd), y, 3e-6)
+    check("reserve dX", ops.cf_view(dx), xr.grad, 3e-6)
+    check("reserve dW", wd.grad, wr.grad, 5e-6)
+    assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
