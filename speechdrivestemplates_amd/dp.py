@@ -15,8 +15,9 @@ import torch.distributed as dist
 
 
 # Workgroup slots (of 512) that backward stream-K launches leave free while a gradient exchange can be in flight.  Measured on one GPU with an
-# emulated collective (tools/debug/comm_emulation.py: 32 workgroups holding their slots for 1.2 ms of each step): 8.00 ms per step without a
-# reserve, 7.90 with 32; the reserve itself costs 2.8 % when nothing else runs (7.54 -> 7.78 ms), which is why it is not the single-GPU default.
+# emulated collective (tools/debug/comm_emulation.py, profiles/r03_comm_emulation.txt: 32 workgroups holding their slots for 0.6 / 1.2 ms of each
+# step): 7.67 -> 7.89 / 8.12 ms per step without a reserve, 7.8 -> 7.9 with 32 (64 buys nothing more); the reserve costs ~0.1 ms when nothing else
+# runs, which is why it is not the single-GPU default.
 RESERVED_SLOTS = 32
 
 

@@ -25,13 +25,13 @@ def main():
     ap.add_argument("--wgs", type=int, default=32)
     ap.add_argument("--us", type=int, default=1200)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--reserve", type=int, default=0, help="workgroup slots the stream-K plans leave free (sdt_convsk_set_reserved_slots)")
+    ap.add_argument("--reserve", type=int, default=0, help="workgroup slots the BACKWARD stream-K plans leave free (ops.SK_RESERVED_SLOTS -> sdt_convsk_set_reserved_slots)")
     ap.add_argument("--lds", type=int, default=65536, help="LDS bytes per spinning workgroup (65536: cannot share a CU with two conv workgroups)")
     a = ap.parse_args()
     lib = _lib.load()
     lib.sdt_debug_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sdt_debug_spin.restype = ctypes.c_int
-    _lib.check(lib.sdt_convsk_set_reserved_slots(a.reserve))
+    ops.SK_RESERVED_SLOTS = a.reserve  # what dp.GradReducer sets in a data-parallel run: backward plans leave this many slots free
     pipe, _ = make_pipeline("voice2pose_sdt_bp", bench.N_CLIPS, batch_global=32)
     batches = bench.stage_batches(4, 32, 0, torch.device("cuda", 0))
     comm = torch.cuda.Stream()
