@@ -6,6 +6,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -209,3 +210,116 @@ def test_fgd_matches_reference_fixture():
         assert abs(got - ref) <= 2e-6 * abs(ref) + 1e-6, (tag, got, ref)
         if tag + "/fgd_aa" in g:
             assert abs(compute_fgd(g[tag + "/a"], g[tag + "/a"]) - float(g[tag + "/fgd_aa"][0])) <= 1e-5, tag
+
+
+def _plan_tables(ops, garr, n, rpg, bwd_groups, reserve=0):
+    """Build a stream-K plan on the host (no GPU involved) and return its header and tables as numpy arrays."""
+    lib = _lib.load()
+    assert lib.sdt_convsk_supported(garr, n) == 1
+    assert lib.sdt_convsk_set_reserved_slots(reserve) == 0
+    try:
+        nbytes = lib.sdt_convsk_plan_bytes(garr, n)
+        blob = (ctypes.c_int32 * (nbytes // 4))()
+        assert lib.sdt_convsk_plan_build(garr, n, rpg, bwd_groups, ctypes.addressof(blob), nbytes) == 0, lib.sdt_last_error()
+    finally:
+        lib.sdt_convsk_set_reserved_slots(0)
+    P = np.frombuffer(blob, dtype=np.int32).copy()
+    hdr = dict(bm=int(P[1]), bn=int(P[2]), G=int(P[3] & 0xffff), wpc=int(P[3] >> 16), ncls=int(P[4]), nnb=int(P[5] & 0xffff), ntmajor=int(P[5] >> 16),
+               T=int(P[6]), S=int(P[7]), rows=int(P[8]), mts=int(P[9]))
+    rowinfo = P[P[10]:P[10] + 4 * hdr["rows"]].reshape(-1, 4)
+    tileinfo = P[P[11]:P[11] + 2 * hdr["mts"]].reshape(-1, 2)
+    tilecum = P[P[12]:P[12] + hdr["T"] + 1]
+    range_tile = P[P[13]:P[13] + hdr["G"]]
+    return hdr, rowinfo, tileinfo, tilecum, range_tile
+
+
+@pytest.mark.parametrize("case", [("3x3 pad 1, 10-row images (row-major, n-tile-major)", 32, 10, 53, 256, 256, 3, 3, 1, 1, "fwd", 0),
+                                  ("(6,3) valid: input gradient (row-major, n-tile-major)", 32, 10, 53, 256, 256, 6, 3, 1, 0, "dx", 32),
+                                  ("4x4 stride 2: input gradient, 4 parity classes", 8, 40, 213, 128, 128, 4, 4, 2, 1, "dx", 0),
+                                  ("3x3 pad 1, 40-row images (natural order)", 8, 40, 213, 64, 128, 3, 3, 1, 1, "fwd", 0)], ids=lambda c: c[0])
+def test_streamk_plan_is_a_partition_of_the_work(case):
+    """sdt_convsk_plan_build is host code: every output row appears exactly once with the offsets / tap masks a brute-force statement gives,
+    whatever ORDER the plan chose for the rows; a tile's live-tap mask is the union over its rows; the step prefix sums, the split into G
+    ranges (with reserved slots: fewer ranges) and the first tile of every range are consistent."""
+    from speechdrivestemplates_amd import ops
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p, role, reserve = case
+    if role == "fwd":
+        g = ops.fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p)
+        garr, n, gs = g, 1, [g]
+        rpg = g.Ho * g.Wo  # InstanceNorm groups: one per clip
+    else:
+        garr, n, gs = ops.dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, s, p, False)
+        rpg = -1
+    hdr, rowinfo, tileinfo, tilecum, range_tile = _plan_tables(ops, garr, n, rpg, B if role == "dx" else 1, reserve)
+    bm, nnb = hdr["bm"], hdr["nnb"]
+    assert hdr["G"] == 256 * hdr["wpc"] - reserve and hdr["ncls"] == n and hdr["bn"] * nnb == gs[0].Cout
+    SK_OOB = -(1 << 31)
+    row0 = mt0 = 0
+    total_live = 0
+    per_mt_live = []
+    for g in gs:
+        M = g.B * g.Ho * g.Wo
+        nmb = -(-M // bm)
+        ri = rowinfo[row0:row0 + nmb * bm]
+        real = ri[ri[:, 2] != SK_OOB]
+        assert len(real) == M and (ri[:, 2] == SK_OOB).sum() == nmb * bm - M          # padding rows only past the last real row
+        # brute force per output position (b, oy, ox), keyed by the byte offset of its output row
+        b, oy, ox = np.meshgrid(np.arange(g.B), np.arange(g.Ho), np.arange(g.Wo), indexing="ij")
+        yoff = (((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout * 4).ravel().astype(np.int64)
+        xoff = (((b * g.Hi + oy * g.sy) * g.Wi + ox * g.sx) * g.Cin * 4).ravel().astype(np.int64)
+        inval = np.full(M, 1 << 31, dtype=np.int64)
+        for t in range(g.ntaps):
+            iy, ix = oy * g.sy + g.dy[t], ox * g.sx + g.dx[t]
+            bad = ((iy < 0) | (iy >= g.Hi) | (ix < 0) | (ix >= g.Wi)).ravel()
+            inval |= bad.astype(np.int64) << t
+        grp = (b.ravel() if (role == "dx" or rpg == g.Ho * g.Wo) else np.zeros(M, dtype=np.int64))
+        order = np.argsort(yoff)
+        got = real[np.argsort(real[:, 2].astype(np.int64))]
+        assert np.array_equal(got[:, 2].astype(np.int64), yoff[order]), "every output row exactly once"
+        assert np.array_equal(got[:, 0].astype(np.int64) & 0xffffffff, xoff[order] & 0xffffffff)
+        assert np.array_equal(got[:, 1].astype(np.int64) & 0xffffffff, inval[order] & 0xffffffff)
+        assert np.array_equal(got[:, 3].astype(np.int64), grp[order])
+        # which order did the plan choose?  row-major: the rows after the first image row of clip 0 are the same image row of clip 1
+        if g.B > 1 and g.Ho > 1:
+            second_run = int(ri[g.Wo, 2])
+            row_major = second_run == int(yoff.reshape(g.B, g.Ho, g.Wo)[1, 0, 0])
+            assert row_major == ("row-major" in tag), (tag, "row-major" if row_major else "natural")
+        # a group's rows come in runs of >= 32 consecutive plan rows, at most two groups per 32-row block (what the statistics epilogues assume)
+        blocks = ri[:, 3].reshape(-1, 32)
+        assert all(len(set(int(v) for v in blk if v >= 0)) <= 2 for blk in blocks)
+        # tiles: the live mask (un-rotated) is the union of the valid taps of the tile's rows; culling is skipped on short tap lists
+        nkc = g.Cin // 32
+        for mt in range(nmb):
+            rows = ri[mt * bm:(mt + 1) * bm]
+            rows = rows[rows[:, 2] != SK_OOB]
+            union = 0
+            for v in rows[:, 1].astype(np.int64) & ((1 << g.ntaps) - 1):
+                union |= ((1 << g.ntaps) - 1) & ~int(v)
+            if g.ntaps <= 4:
+                union = (1 << g.ntaps) - 1
+            rmask, rot = int(tileinfo[mt0 + mt, 0]) & 0xffffffff, int(tileinfo[mt0 + mt, 1])
+            unrot = 0
+            for i in range(g.ntaps):
+                if rmask >> i & 1:
+                    unrot |= 1 << ((rot + i) % g.ntaps)
+            assert unrot == union, (tag, mt, bin(unrot), bin(union))
+            per_mt_live.append(bin(union).count("1") * nkc)
+        total_live += sum(per_mt_live[mt0:mt0 + nmb]) * nnb
+        row0 += nmb * bm
+        mt0 += nmb
+    assert hdr["S"] == total_live == int(tilecum[-1]) and tilecum[0] == 0 and np.all(np.diff(tilecum) > 0)
+    # tile -> m-tile in the plan's tile order; per-tile step counts match the m-tile's live steps
+    steps = np.diff(tilecum)
+    assert bool(hdr["ntmajor"]) == ("n-tile-major" in tag), (tag, hdr["ntmajor"])
+    if hdr["ntmajor"]:
+        assert n == 1
+        expect = np.tile(np.array(per_mt_live), nnb)
+    else:
+        expect = np.repeat(np.array(per_mt_live), nnb)
+    assert np.array_equal(steps, expect)
+    # ranges: range r starts at step floor(r * S / G); its first tile is the one that contains that step
+    G, S = hdr["G"], hdr["S"]
+    for r in range(G):
+        s0 = r * S // G
+        t = int(range_tile[r])
+        assert tilecum[t] <= s0 < tilecum[t + 1], (r, s0, t)
