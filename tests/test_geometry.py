@@ -323,3 +323,34 @@ def test_streamk_plan_is_a_partition_of_the_work(case):
         s0 = r * S // G
         t = int(range_tile[r])
         assert tilecum[t] <= s0 < tilecum[t + 1], (r, s0, t)
+
+
+@pytest.mark.parametrize("case", [("128x128 tiles", 32, 20, 106, 128, 256, 3, 3, 1, 1, 128, 128), ("64-row tiles (Cout 64)", 32, 80, 427, 64, 64, 4, 4, 2, 1, 64, 128),
+                                  ("64-column tiles (9 x 64 columns)", 32, 40, 213, 64, 128, 3, 3, 1, 1, 128, 64)], ids=lambda c: c[0])
+def test_streamk_weight_gradient_plan(case):
+    """sdt_convsk_dw_plan_build (host code): tile shape by divisibility, one row-table entry per output position (offset of its (0,0) tap in X,
+    invalid-tap mask, offset of its dY row), K steps of 32 positions, at least 8 steps per (tile, K-chunk) unit."""
+    from speechdrivestemplates_amd import ops
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p, bm, bn = case
+    g = ops.fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p)
+    lib = _lib.load()
+    assert lib.sdt_convsk_dw_supported(g) == 1
+    nbytes = lib.sdt_convsk_dw_plan_bytes(g)
+    blob = (ctypes.c_int32 * (nbytes // 4))()
+    assert lib.sdt_convsk_dw_plan_build(g, ctypes.addressof(blob), nbytes) == 0, lib.sdt_last_error()
+    P = np.frombuffer(blob, dtype=np.int32)
+    M = g.B * g.Ho * g.Wo
+    K, T, G = int(P[9]), int(P[6]), int(P[3] & 0xffff)
+    assert (int(P[1]), int(P[2])) == (bm, bn) and K == -(-M // 32) and T == (Cout // bm) * (g.ntaps * Cin // bn) and G == 512
+    assert T <= G and K >= 8 * (G // T)
+    ri = P[P[10]:P[10] + 4 * int(P[8])].reshape(-1, 4)
+    b, oy, ox = np.meshgrid(np.arange(g.B), np.arange(g.Ho), np.arange(g.Wo), indexing="ij")
+    xoff = (((b * g.Hi + oy * g.sy) * g.Wi + ox * g.sx) * g.Cin * 4).ravel().astype(np.int64)
+    inval = np.full(M, 1 << 31, dtype=np.int64)
+    for t in range(g.ntaps):
+        iy, ix = oy * g.sy + g.dy[t], ox * g.sx + g.dx[t]
+        inval |= ((iy < 0) | (iy >= g.Hi) | (ix < 0) | (ix >= g.Wi)).ravel().astype(np.int64) << t
+    assert np.array_equal(ri[:M, 0].astype(np.int64) & 0xffffffff, xoff & 0xffffffff)
+    assert np.array_equal(ri[:M, 1].astype(np.int64) & 0xffffffff, inval & 0xffffffff)
+    assert np.array_equal(ri[:M, 2].astype(np.int64), np.arange(M, dtype=np.int64) * g.Cout * 4)
+    assert np.all(ri[M:, 2] == -(1 << 31)) and np.all(ri[M:, 1] == -1)  # rows past M: every tap invalid, dY offset out of range
