@@ -16,7 +16,7 @@ Forward quantities (losses, prediction) are continuous in the rounding noise: ea
         |HIP - f64| <= K_FWD * |ref_fp32 - f64| + floor.
 Gradients are NOT: the network is piecewise linear (|.| loss, LeakyReLU), so two fp32 runs whose forward passes differ by 1e-6
 take a different branch at a handful of elements, and ONE such event moves whole gradient tensors by 1e-3..1e-1 of their
-max-norm.  tools/debug/p2p_flip.py shows it on the pose2pose B=4 fixture: the HIP prediction is as accurate as the fp32
+max-norm.  tests/tools/p2p_flip.py shows it on the pose2pose B=4 fixture: the HIP prediction is as accurate as the fp32
 reference's (6.6e-6 vs 5.1e-6 of float64) yet sign(pred - gt) differs at exactly 1 of 61952 elements, and that single sign is
 the whole "100x worse" gradient gap (the head-bias gradient is off by exactly 2/N at one channel); at B=32 per-tensor ratios
 |HIP-f64| / |ref32-f64| scatter from 0.03 to 1500 in BOTH directions (profiles/r02_parity_tables.txt).  Therefore:
