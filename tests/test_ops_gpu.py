@@ -1043,3 +1043,42 @@ def test_streamk_plans_with_reserved_slots(ops):
     check("reserve dX", ops.cf_view(dx), xr.grad, 3e-6)
     check("reserve dW", wd.grad, wr.grad, 5e-6)
     assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
+
+
+def _random_conv_cases(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    while len(out) < n:
+        B = int(rng.choice([1, 2, 3, 5, 8, 17]))
+        Cin, Cout = int(rng.choice([64, 128, 192, 256])), int(rng.choice([64, 128, 192, 256]))
+        kh, kw, s, p = [(3, 3, 1, 1), (4, 4, 2, 1), (6, 3, 1, 0), (1, 1, 1, 0), (3, 3, 1, 0), (3, 3, 2, 1), (4, 4, 2, 0)][int(rng.integers(7))]  # (the tap table holds 20 taps: the reference stops at 6x3)
+        Hi, Wi = int(rng.integers(max(kh, 6), 48)), int(rng.integers(max(kw, 33), 120))
+        if (Hi + 2 * p - kh) // s + 1 < 1 or (Wi + 2 * p - kw) // s + 1 < 1:
+            continue
+        out.append(("B%d %dx%d %d->%d k%dx%d s%d p%d" % (B, Hi, Wi, Cin, Cout, kh, kw, s, p), B, Hi, Wi, Cin, Cout, kh, kw, s, p))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(24, 2026), ids=lambda c: c[0])
+def test_conv_random_shapes_through_the_production_routing(ops, case):
+    """Seeded sweep of awkward shapes (odd images, ragged row counts, 1..17 clips, all channel widths the kernels tile differently, strides,
+    valid / padded / 1x1 kernels) through ops.conv_forward / conv_input_grad / conv_weight_grad exactly as the model calls them -- whichever
+    kernel the routing picks (stream-K plans where they exist and have enough work, the 64x64 kernels otherwise) -- against float64."""
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    yd = ops.conv_forward(xd, wd, None, s, p)
+    dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
+    ops.conv_weight_grad(xd, gyd, wd, s, p)
+    torch.cuda.synchronize()
+    check("random fwd " + tag, ops.cf_view(yd), y, 4e-6)
+    check("random dX " + tag, ops.cf_view(dx), xr.grad, 4e-6)
+    check("random dW " + tag, wd.grad, wr.grad, 8e-6)
+    assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
