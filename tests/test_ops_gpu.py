@@ -1082,3 +1082,43 @@ def test_conv_random_shapes_through_the_production_routing(ops, case):
     check("random dX " + tag, ops.cf_view(dx), xr.grad, 4e-6)
     check("random dW " + tag, wd.grad, wr.grad, 8e-6)
     assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
+
+
+def _random_conv1d_cases(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    while len(out) < n:
+        B = int(rng.choice([1, 2, 4, 7, 32]))
+        Cin, Cout = int(rng.choice([32, 64, 256, 288])), int(rng.choice([64, 128, 256, 242]))
+        k, s, p = [(3, 1, 1), (4, 2, 1), (1, 1, 0), (3, 1, 0), (4, 2, 0), (2, 2, 0)][int(rng.integers(6))]
+        T = int(rng.integers(max(k, 1), 70))
+        if (T + 2 * p - k) // s + 1 < 1:
+            continue
+        out.append(("B%d T%d %d->%d k%d s%d p%d" % (B, T, Cin, Cout, k, s, p), B, T, Cin, Cout, k, s, p))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_conv1d_cases(20, 7), ids=lambda c: c[0])
+def test_conv1d_random_shapes_through_the_production_routing(ops, case):
+    """The 1-D stage's launches on a seeded sweep of lengths (1..69 frames), clip counts, strides and channel widths -- including the widths the
+    small-K kernel does not take (Cout = 242) -- with and without bias, against float64: conv1d_small_kernel / conv_taps_kernel, K-split or not,
+    two parity classes for the strided input gradients."""
+    tag, B, T, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, T, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, generator=g, dtype=torch.float64) * (2.0 / (Cin * k)) ** 0.5
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64) if (len(tag) % 2) else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv1d(xr, wr, bias, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    bd = bias.float().to(DEV) if bias is not None else None
+    yd = ops.conv_forward(xd, wd, bd, s, p)
+    dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
+    ops.conv_weight_grad(xd, gyd, wd, s, p)
+    torch.cuda.synchronize()
+    check("random 1-D fwd " + tag, ops.cf_view(yd), y, 4e-6)
+    check("random 1-D dX " + tag, ops.cf_view(dx), xr.grad, 4e-6)
+    check("random 1-D dW " + tag, wd.grad, wr.grad, 1e-5)
