@@ -1122,3 +1122,59 @@ def test_conv1d_random_shapes_through_the_production_routing(ops, case):
     check("random 1-D fwd " + tag, ops.cf_view(yd), y, 4e-6)
     check("random 1-D dX " + tag, ops.cf_view(dx), xr.grad, 4e-6)
     check("random 1-D dW " + tag, wd.grad, wr.grad, 1e-5)
+
+
+def _random_stats_cases(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    while len(out) < n:
+        B = int(rng.choice([2, 3, 8, 16, 32]))
+        Cin, Cout = int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))
+        kh, kw, s, p = [(3, 3, 1, 1), (4, 4, 2, 1), (6, 3, 1, 0), (3, 3, 1, 0)][int(rng.integers(4))]
+        Hi, Wi = int(rng.integers(max(kh, 6), 44)), int(rng.integers(max(kw, 40), 110))
+        norm = "IN" if rng.integers(2) else "BN"
+        out.append(("%s B%d %dx%d %d->%d k%dx%d s%d p%d" % (norm, B, Hi, Wi, Cin, Cout, kh, kw, s, p), norm, B, Hi, Wi, Cin, Cout, kh, kw, s, p))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_stats_cases(14, 99), ids=lambda c: c[0])
+def test_statistics_epilogues_random_shapes(ops, case):
+    """Forward statistics (sum, sum of squares per group and channel) and normalisation-backward statistics (sum gg, sum gg * yhat) out of the
+    conv epilogues -- whichever kernel and row order the routing picks, InstanceNorm (one group per clip) or BatchNorm (one group) -- on a seeded
+    sweep of shapes against float64.  Where a launch does not fuse the statistics (too few rows, K-split) only the conv results are checked."""
+    tag, norm, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    ng = B if norm == "IN" else 1
+    g = torch.Generator().manual_seed(sum(map(ord, tag)))
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    ops.begin_step()
+    if ops.conv_stats_fusable(xd, wd, s, p, ng):
+        yd, sums = ops.ConvStatsFn.apply(xd, wd, s, p, ng)
+        torch.cuda.synchronize()
+        yg = y.permute(0, 2, 3, 1).reshape(ng, -1, Cout)
+        check("random forward statistics " + tag, sums.view(ng, Cout, 2), torch.stack([yg.sum(1), (yg * yg).sum(1)], -1), 4e-6)
+    else:
+        yd = ops.conv_forward(xd, wd, None, s, p)
+    check("random stats fwd " + tag, ops.cf_view(yd), y, 4e-6)
+    h = ops.NormBwdHolder()
+    h.y = ops.cl(torch.randn(x.shape, generator=g)).to(DEV)
+    h.mean = (torch.randn(ng, Cin, generator=g) * 0.1).to(DEV)
+    h.rstd = (torch.rand(ng, Cin, generator=g) + 0.5).to(DEV)
+    h.gamma, h.beta = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (torch.randn(Cin, generator=g) * 0.1).to(DEV)
+    h.groups, h.slope = ng, 0.2
+    dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p, h)
+    torch.cuda.synchronize()
+    check("random stats dX " + tag, ops.cf_view(dx), xr.grad, 4e-6)
+    if h.sums is not None:
+        dxg = xr.grad.permute(0, 2, 3, 1).reshape(ng, -1, Cin)
+        yh = (h.y.double().cpu().reshape(ng, -1, Cin) - h.mean.double().cpu()[:, None]) * h.rstd.double().cpu()[:, None]
+        pre = yh * h.gamma.double().cpu() + h.beta.double().cpu()
+        gg = dxg * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2))
+        check("random backward statistics " + tag, h.sums.view(ng, Cin, 2), torch.stack([gg.sum(1), (gg * yh).sum(1)], -1), 4e-6)
+    assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
