@@ -934,6 +934,27 @@ def side_stream_if_any():
     return _SIDE.get((torch._C._cuda_getDevice(), 0))
 
 
+# autograd's contract: when backward() returns, every .grad is ready on the stream backward ran on.  Weight gradients launched on the side stream
+# (or deferred) break it unless that stream is joined when the backward pass ends: _conv_backward queues ONE engine callback per pass for that.
+# (The train step joined before its optimiser anyway; a stand-alone `loss.backward(); torch_optimizer.step()` on these modules did not.)
+_JOIN_QUEUED = [False]
+
+
+def _end_of_backward():
+    _JOIN_QUEUED[0] = False
+    join_side_stream()
+
+
+def _queue_backward_join():
+    if _JOIN_QUEUED[0]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _JOIN_QUEUED[0] = True
+    except RuntimeError:  # not inside a backward pass (a direct call of the op): the caller joins
+        pass
+
+
 def join_side_stream():
     if _DEFERRED:
         flush_deferred_dw()
@@ -974,8 +995,10 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None, gy_p
                 conv_weight_grad(x_cl, gy, w, stride, pad)
             gy.record_stream(side)  # keep the caching allocator from recycling gy under the side stream
             x_cl.record_stream(side)
+            _queue_backward_join()
         elif _DEFER_ON[0] and not big:
             _DEFERRED.append((x_cl, gy, w, stride, pad))
+            _queue_backward_join()
         else:
             conv_weight_grad(x_cl, gy, w, stride, pad)
     if bias is not None and bias.requires_grad:

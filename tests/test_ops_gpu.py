@@ -1178,3 +1178,25 @@ def test_statistics_epilogues_random_shapes(ops, case):
         gg = dxg * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2))
         check("random backward statistics " + tag, h.sums.view(ng, Cin, 2), torch.stack([gg.sum(1), (gg * yh).sum(1)], -1), 4e-6)
     assert ops.streamk_error_codes() == {}, ops.streamk_error_codes()
+
+
+def test_gradients_are_ready_when_backward_returns(ops):
+    """Weight-gradient launches go to a side stream; autograd's contract -- .grad is ready on the current stream when backward() returns -- is
+    kept by joining that stream in an engine callback at the end of the pass: a consumer on the main stream right after backward() (a plain torch
+    optimiser, a .cpu() copy) sees the finished gradient.  Repeated to give a race a chance to show."""
+    torch.manual_seed(2)
+    B, H, W, Cin, Cout = 8, 40, 213, 64, 128  # 10 GFLOP: above ops.OVERLAP_DW_MIN_FLOPS, the weight gradient takes the side stream
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.05))
+    gy = torch.randn(B, H, W, Cout, device=DEV)
+    ref = None
+    for rep in range(6):
+        w.grad = None
+        y = ops.ConvFn.apply(x, w, None, 1, 1)
+        y.backward(gy)
+        got = w.grad.clone()          # main stream, immediately after backward()
+        if ref is None:
+            torch.cuda.synchronize()
+            ref = w.grad.clone()
+            assert float(ref.abs().max()) > 0
+        assert torch.equal(got, ref), "repetition %d read an unfinished weight gradient" % rep
