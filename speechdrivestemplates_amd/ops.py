@@ -470,6 +470,8 @@ TAB_CHUNK = 8        # K steps per accumulation chunk of that kernel (0: one acc
 def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the plan (stream-K where that kernel is wanted, else the
     64x64 table-driven kernel's) or None when the pack qualifies for neither."""
+    if torch.cuda.is_current_stream_capturing():
+        return None  # a stream-K launch carries an epoch that must grow from launch to launch: a captured graph would replay one value
     reserve = 0 if forward else int(SK_RESERVED_SLOTS)
     key = (id(garr), int(rpg), int(bwd_groups), dev.index, bool(forward), reserve)
     plan = _SK_PLANS.get(key, False)
