@@ -676,7 +676,21 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)P.ybytes, 0x00020000);
     // fragment read offsets (floats): lane half h reads the k group 2 j + h of its row
-    const int fa = ((lane >> 5) * BM + wm * (BM / 2) + (lane & 31)) * 4, fb = ((lane >> 5) * BN + wn * (BN / 2) + (lane & 31)) * 4;
+    // LDS bank swizzle: row r of a k group sits in the 16-byte slot r ^ ((r >> 3) & 7).  The loader's lanes store rows 4 apart (64 B: only two
+    // of the eight 16-byte bank groups of a 128-byte LDS cycle, a 4x slower ds_write_b128: SQ_LDS_BANK_CONFLICT was non-zero for these kernels only);
+    // XOR-ing the row's bits 3..5 into its low three bits spreads 8 consecutive loader lanes over all eight groups and keeps 8 consecutive
+    // fragment rows (bits 3..5 equal) a permutation of them
+    int fa[TM], fb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = wm * (BM / 2) + tm * 32 + (lane & 31);
+        fa[tm] = ((lane >> 5) * BM + (r ^ ((r >> 3) & 7))) * 4;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int r = wn * (BN / 2) + tn * 32 + (lane & 31);
+        fb[tn] = ((lane >> 5) * BN + (r ^ ((r >> 3) & 7))) * 4;
+    }
     {
         const int a = (int)((long)chunk * K / nchunk), b = (int)((long)(chunk + 1) * K / nchunk);
         const int nt = tile / ncol, ct = tile - nt * ncol;
@@ -718,19 +732,20 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                const int rwa = (cqa * 4 + e) ^ ((cqa >> 1) & 7), rwb = (cqb * 4 + e) ^ ((cqb >> 1) & 7);  // row ^ ((row >> 3) & 7)
                 if constexpr (KA == 4) {
                     const f32x4 va = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
-                    *(f32x4*)&sA[buf * 32 * BM + (ksa * BM + cqa * 4 + e) * 4] = va;
+                    *(f32x4*)&sA[buf * 32 * BM + (ksa * BM + rwa) * 4] = va;
                 } else {
                     const f32x2 va = {ra[0][e], ra[1][e]};
-                    *(f32x2*)&sA[buf * 32 * BM + ((ksa >> 1) * BM + cqa * 4 + e) * 4 + (ksa & 1) * 2] = va;
+                    *(f32x2*)&sA[buf * 32 * BM + ((ksa >> 1) * BM + rwa) * 4 + (ksa & 1) * 2] = va;
                 }
                 if constexpr (KB == 4) {
                     const f32x4 vb = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
-                    *(f32x4*)&sB[buf * 32 * BN + (ksb * BN + cqb * 4 + e) * 4] = vb;
+                    *(f32x4*)&sB[buf * 32 * BN + (ksb * BN + rwb) * 4] = vb;
                 } else {
                     const f32x2 vb = {rb[0][e], rb[1][e]};
-                    *(f32x2*)&sB[buf * 32 * BN + ((ksb >> 1) * BN + cqb * 4 + e) * 4 + (ksb & 1) * 2] = vb;
+                    *(f32x2*)&sB[buf * 32 * BN + ((ksb >> 1) * BN + rwb) * 4 + (ksb & 1) * 2] = vb;
                 }
             }
         };
@@ -751,16 +766,16 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
         __syncthreads();
         f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
 #define DW_READ(A, B, PA, PB, J)                                                                                            \
-    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = *(const f32x4*)((PA) + tm * 32 * 4 + (J) * 2 * BM * 4);        \
-    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) B[tn] = *(const f32x4*)((PB) + tn * 32 * 4 + (J) * 2 * BN * 4)
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = *(const f32x4*)((PA) + fa[tm] + (J) * 2 * BM * 4);              \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) B[tn] = *(const f32x4*)((PB) + fb[tn] + (J) * 2 * BN * 4)
 #define DW_MFMA(A, B)                                                                                                       \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                         \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                                   \
             acc[0][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], B[tn][e], acc[0][tm][tn], 0, 0, 0)
-        DW_READ(a0, b0, sA + fa, sB + fb, 0);
+        DW_READ(a0, b0, sA, sB, 0);
         auto step = [&](const int cur) {
-            const float* pa = sA + cur * 32 * BM + fa;
-            const float* pb = sB + cur * 32 * BN + fb;
+            const float* pa = sA + cur * 32 * BM;
+            const float* pb = sB + cur * 32 * BN;
             // as the forward kernel's step: k-group 0 + fragments of k-group 1 + registers (step+1) -> LDS[next] + the global loads of
             // step+2 + the table rows of step+3
             DW_READ(a1, b1, pa, pb, 1);
@@ -798,7 +813,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my writes of LDS[next] are done
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            DW_READ(a0, b0, sA + (cur ^ 1) * 32 * BM + fa, sB + (cur ^ 1) * 32 * BN + fb, 0);
+            DW_READ(a0, b0, sA + (cur ^ 1) * 32 * BM, sB + (cur ^ 1) * 32 * BN, 0);
             DW_MFMA(a1, b1);
 #pragma unroll
             for (int q = 0; q < TM + TN; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
