@@ -192,9 +192,6 @@ def main(argv=None):
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     ap.add_argument("--atomic-dw", action="store_true",
                     help="weight gradients with fp32 atomics (the round-2 default) instead of the ordered, bit-reproducible reductions")
-    ap.add_argument("--fused-conv1d", action="store_true",
-                    help="experiment (tuning library only): the generator's Conv1d stage as one launch per layer and direction "
-                         "(csrc/conv1d.hip; measured 2 %% slower end to end, profiles/r02_conv1d_stage.txt)")
     ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
     ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
@@ -261,9 +258,6 @@ def main(argv=None):
         ops.DETERMINISTIC_DW = not args.atomic_dw
         if args.atomic_dw:
             ops.USE_STREAMK_DW = False
-        if args.fused_conv1d:
-            from speechdrivestemplates_amd.experimental import stage1d  # needs SDT_HIP_LIB=.../libsdt_hip_tuning.so
-            stage1d.enable(True)
         ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
         ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
         ops.OVERLAP_AUX = not args.no_overlap_aux
@@ -280,7 +274,7 @@ def main(argv=None):
 
     runner = step
     if args.graph and world == 1 and not stub:
-        from speechdrivestemplates_amd.experimental.graph import GraphedStep
+        from speechdrivestemplates_amd.graph import GraphedStep
         gs = GraphedStep(pipe, warmup=min(3, max(1, args.warmup - 1)))
         runner = lambda i: gs.run(batches[i % len(batches)])  # noqa: E731
 
@@ -376,7 +370,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "fused_conv1d": bool(args.fused_conv1d), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
                        # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
                        # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
                        # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)

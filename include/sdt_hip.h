@@ -24,6 +24,9 @@ extern "C" {
 #define SDT_MAX_TAPS 20
 
 enum sdt_status { SDT_OK = 0, SDT_ERR_ARG = -1, SDT_ERR_LAUNCH = -2, SDT_ERR_UNSUPPORTED = -3 };
+/* Element type of a tensor argument of the *_t / *_bf16 entry points (the bf16-storage path of BASELINE config 4: activations of the
+ * Conv2d chain and the conv operands' weight copies live in HBM as bf16, statistics / accumulation / master weights / gradients fp32) */
+enum sdt_dtype { SDT_F32 = 0, SDT_BF16 = 1 };
 
 const char* sdt_last_error(void);
 int sdt_abi_version(void);
@@ -74,7 +77,7 @@ int sdt_splitk_reduce_f32(const float* partial, const float* bias, float* y, int
  *   sums[(grp*C + n)*2 + 0] += sum gg,  [..+1] += sum gg*yhat,  gg = dX * act'(gamma*yhat + beta), yhat = (y - mean)*rstd
  * y = raw output of the conv below (same shape as dX), grp = batch item (groups == B) or 0 (groups == 1); sums zero on entry. */
 typedef struct sdt_norm_bwd {
-    const float* y;
+    const void* y;      /* element type of the launch's x (fp32; bf16 for sdt_convsk_bf16) */
     const float* mean;  /* [groups*C] */
     const float* rstd;  /* [groups*C] */
     const float* gamma; /* [C] or NULL */
@@ -100,8 +103,12 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
  *   rows_per_group > 0       statistics group of output row m = m / rows_per_group (forward statistics, as sdt_conv_taps_stats_f32);
  *   rows_per_group <= 0      group = batch item (bwd_groups == B) or 0 (bwd_groups == 1) (backward statistics, as sdt_norm_bwd)
  *   sdt_convsk_workspace_bytes  partial-tile slabs + flags: one buffer per stream, ZERO-FILLED ONCE by the caller, then passed to every
- *                            launch on that stream with a strictly increasing epoch (>= 1); the word after the flags is an error code
- *                            (non-zero: a wait for a partial tile gave up -- cannot happen while the launch's workgroups are resident)
+ *                            launch on that stream.  epoch >= 1 is the flag value of the launch; the workgroup that consumes a flag lowers it
+ *                            again, so every flag is zero between launches and the same epoch may be passed every time (a launch recorded
+ *                            into a hipGraph replays correctly).  The word after the flags is an error code: non-zero = the owner of a
+ *                            split tile gave up waiting for a partner (sdt_convsk_set_spin_limit polls: the partner was never dispatched,
+ *                            e.g. another process holds its slot); that tile is stored as NaN, never with a partial sum missing, and the
+ *                            host mirror raises when it sees the word (core/pipelines/trainer.py)
  *   sdt_convsk_f32           the launch; stats / nb as in sdt_conv_taps_stats_f32 / sdt_conv_taps_multi_f32 (at most one of them);
  *                            xbytes / wbytes / ybytes: sizes of the X, W and Y tensors
  */
@@ -111,9 +118,18 @@ int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for 
 /* Workgroup slots (multiple of 8, < 256) that plans built afterwards leave free: a persistent launch that fills the GPU cannot share it with another
  * long-lived kernel (a collective's); data-parallel runs plan their backward launches with a reserve.  Default 0. */
 int sdt_convsk_set_reserved_slots(int n);
+/* Polls (each ~1 us under load) of a partner's flag before the owner of a split tile declares the launch failed.  Default 1 << 22. */
+int sdt_convsk_set_spin_limit(unsigned polls);
+unsigned sdt_convsk_get_spin_limit(void);
 int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls);
 int64_t sdt_convsk_workspace_bytes(void);
 int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes);
+/* The same for a given element type of x / w (x_dtype) and of y (y_dtype): the plan's byte offsets and its K step (128 bytes of an input
+ * row: 32 fp32 or 64 bf16 channels) depend on them.  bf16 needs Cin % 64 == 0. */
+int sdt_convsk_supported_t(const sdt_conv_geom* geoms, int ncls, int x_dtype);
+int64_t sdt_convsk_plan_bytes_t(const sdt_conv_geom* geoms, int ncls, int x_dtype);
+int sdt_convsk_plan_build_t(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, int x_dtype, int y_dtype, void* out,
+                            int64_t out_bytes);
 /* Weight gradient of a forward geometry on the same persistent machinery (dense dY, Cout % 64 == 0, Cin % 64 == 0; 128- or 64-wide tiles):
  * the reduction over the output positions is split over the workgroups, partial tiles go to slabs of `workspace`
  * (sdt_convsk_dw_workspace_bytes() bytes, contents irrelevant) and a second kernel adds them to dw (Cout, Tw, Cin) in a fixed order:
@@ -128,6 +144,18 @@ int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, const void* pl
 int sdt_convsk_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
                    void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nb, int64_t xbytes, int64_t wbytes, int64_t ybytes,
                    void* stream);
+/* bf16-storage path: x, w, y and nb->y are bf16 tensors (plan from sdt_convsk_plan_build_t(.., SDT_BF16, SDT_BF16, ..)); products on
+ * v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate), fp32 accumulation, bias and statistics (taken from the fp32 accumulators before the
+ * output is rounded).  sdt_convsk_dw_bf16: bf16 x / dy, fp32 gradient accumulated into dw; 64 output positions per K step, operands
+ * transposed on the way out of LDS by ds_read_b64_tr_b16. */
+int sdt_convsk_bf16(const void* x, const void* w, const float* bias, void* y, const void* plan_host, const void* plan_dev,
+                    void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nb, int64_t xbytes, int64_t wbytes, int64_t ybytes,
+                    void* stream);
+int sdt_convsk_dw_supported_t(const sdt_conv_geom* g, int dtype);
+int64_t sdt_convsk_dw_plan_bytes_t(const sdt_conv_geom* g, int dtype);
+int sdt_convsk_dw_plan_build_t(const sdt_conv_geom* g, int dtype, void* out, int64_t out_bytes);
+int sdt_convsk_dw_bf16(const void* x, const void* dy, float* dw, const void* plan_host, const void* plan_dev, void* workspace,
+                       int64_t xbytes, int64_t ybytes, void* stream);
 /* Weight gradient, ACCUMULATED into dw (Cout,Tw,Cin):
  *   dw[n, wt[t], c] += sum_{b,oy,ox} dY[b, oy*osy+ooy, ox*osx+oox, n] * X[b, oy*sy+dy[t], ox*sx+dx[t], c] */
 int sdt_conv_dw_f32(const float* x, const float* dy, float* dw, const sdt_conv_geom* g, void* stream);
@@ -162,7 +190,9 @@ int sdt_get_conv_math(void);
  * ceil(cin/32)*ceil(cout/32)*taps over the preceding layers, total_tiles = that sum over all layers. */
 typedef struct sdt_wt_desc {
     const float* w; /* (cout, taps, cin) */
-    float* wt;      /* (cin, taps, cout) */
+    float* wt;      /* (cin, taps, cout); nullable */
+    void* w16;      /* nullable: bf16 copy of w (round to nearest even), the bf16-storage path's forward / weight operand */
+    void* wt16;     /* nullable: bf16 copy of the mirror */
     int32_t cout, taps, cin, tile_begin;
 } sdt_wt_desc;
 int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int total_tiles, void* stream);
@@ -180,8 +210,9 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
  * num_batches_tracked (nullable) is the
  * BatchNorm int64 counter, incremented on the device.  gamma/beta/running_* may be NULL (IN).
  * stats_ready != 0: sums already holds sum(y), sum(y^2) per (g, c) (sdt_conv_taps_stats_f32) -- the statistics pass is skipped.
- * z_planes / dy_planes (nullable): the output is ALSO written as three bf16 planes [3][G*R*C] (exact split, csrc/presplit.hip)
- * for sdt_conv_taps_pre_f32.
+ * *_t: the same with explicit element types (enum sdt_dtype) of the activation tensors -- the bf16-storage path: statistics, mean / rstd
+ * and the arithmetic stay fp32, only what moves through HBM is bf16.  Built combinations: all fp32; forward y bf16 -> z bf16 | fp32;
+ * backward y and dy bf16 with dz bf16 | fp32.
  * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
  * momentum (unbiased variance), as nn.BatchNorm does in training mode.
  * eval: z = act(gamma*(y-running_mean)/sqrt(running_var+eps)+beta).
@@ -189,7 +220,11 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
 int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                        float slope, int stats_ready, void* z_planes, void* stream);
+                        float slope, int stats_ready, void* stream);
+int sdt_colnorm_fwd_t(const void* y, int y_dtype, void* z, int z_dtype, double* sums, float* mean, float* rstd,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
+                      float slope, int stats_ready, void* stream);
 int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
                          int64_t rows, int C, float eps, float slope, void* stream);
@@ -198,7 +233,10 @@ int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const flo
  * conv that produced dz, sdt_conv_taps_multi_f32 with nb) -- the statistics pass over dz and y is skipped. */
 int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, float* dgamma,
-                        float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* dy_planes, void* stream);
+                        float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* stream);
+int sdt_colnorm_bwd_t(const void* dz, int dz_dtype, const void* y, int y_dtype, void* dy, int dy_dtype, double* sums, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                      float* dbeta, int G, int64_t R, int C, float slope, int stats_ready, void* stream);
 
 /*
  * First audio-encoder block fused for Cin == 1: Conv2d(1,64,k3,s1,p1,bias=False) -> InstanceNorm2d (groups = B) or
@@ -214,10 +252,19 @@ int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums
 int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
-                         float slope, void* z_planes /* nullable: z also as [3][B*H*W*64] bf16 planes */, void* stream);
+                         float slope, void* stream);
 int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, const double* mom, double* sums, float* dw, float* dgamma,
                          float* dbeta, int B, int H, int W, int groups, float slope, void* stream);
+/* The same with z written / dz read as z_dtype / dz_dtype (enum sdt_dtype): the block's output is the first bf16 tensor of the bf16-storage
+ * path, its backward reads the bf16 gradient the L1 input-gradient launch wrote.  mel, weights, moments, statistics: fp32 / fp64 as above. */
+int sdt_l0_block_fwd_t(const float* mel, const float* w, void* z, int z_dtype, double* mom, float* mean, float* rstd,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
+                       float slope, void* stream);
+int sdt_l0_block_bwd_t(const void* dz, int dz_dtype, const float* mel, const float* w, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, const double* mom, double* sums, float* dw, float* dgamma,
+                       float* dbeta, int B, int H, int W, int groups, float slope, void* stream);
 
 /*
  * Row normalisation over C for each of `rows` rows + LeakyReLU: the reference's InstanceNorm1d

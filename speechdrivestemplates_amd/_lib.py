@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDT_HIP_LIB: developer tools only (tools/conv_bench.py points it at the -DSDT_TUNING build); the package itself never sets it
 LIB_PATH = os.environ.get("SDT_HIP_LIB") or os.path.join(_HERE, "lib", "libsdt_hip.so")
 MAX_TAPS = 20
+ABI_VERSION = 2  # sdt_abi_version() of the library this binding was written against
 
 
 class ConvGeom(C.Structure):
@@ -26,23 +27,10 @@ class NormBwd(C.Structure):
                 ("sums", C.c_void_p), ("slope", C.c_float), ("groups", C.c_int32)]
 
 
-class C1d(C.Structure):
-    """Mirror of ``sdt_c1d`` (include/sdt_hip.h)."""
-    _fields_ = ([(n, C.c_void_p) for n in ("X", "X2", "xstats", "x2stats", "W", "bias", "add", "Y", "ystats", "bw_y", "bw_stats")]
-                + [(n, C.c_int32) for n in ("B", "Ti", "T2", "Cin", "To", "Cout", "taps", "stride", "pad", "in_mode", "np_in", "np_in2", "np_bw")]
-                + [("eps", C.c_float), ("slope", C.c_float), ("splitk", C.c_int32), ("slabs", C.c_void_p), ("counters", C.c_void_p)])
-
-
-class WpDesc(C.Structure):
-    """Mirror of ``sdt_wp_desc`` (include/sdt_hip.h)."""
-    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wtp", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32),
-                ("cin", C.c_int32), ("tile_begin", C.c_int32)]
-
-
 class WtDesc(C.Structure):
     """Mirror of ``sdt_wt_desc`` (include/sdt_hip.h)."""
-    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32),
-                ("tile_begin", C.c_int32)]
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("w16", C.c_void_p), ("wt16", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32),
+                ("cin", C.c_int32), ("tile_begin", C.c_int32)]
 
 
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -63,14 +51,18 @@ SIGNATURES = {
     "sdt_weight_transpose_batched_f32": [_p, _i, _i, _p],
     "sdt_set_conv_math": [_i],
     "sdt_col_sum_f32": [_p, _p, _i64, _i, _p],
-    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p, _p],
+    "sdt_colnorm_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p],
+    "sdt_colnorm_fwd_t": [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _f, _f, _i, _p],
     "sdt_conv_taps_stats_supported": [_G, _i],
     "sdt_conv_taps_stats_f32": [_p, _p, _p, _p, _G, _p, _i, _p],
     "sdt_colnorm_eval_f32": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
-    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p, _p],
+    "sdt_colnorm_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p],
+    "sdt_colnorm_bwd_t": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _i, _p],
     "sdt_conv_taps_multi_f32": [_p, _p, _p, _G, _i, _i, _p, C.POINTER(NormBwd), _p],
-    "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p],
+    "sdt_l0_block_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
     "sdt_l0_block_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "sdt_l0_block_fwd_t": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p],
+    "sdt_l0_block_bwd_t": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "sdt_rownorm_fwd_f32": [_p, _p, _p, _p, _i64, _i, _f, _f, _p],
     "sdt_rownorm_bwd_f32": [_p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "sdt_rownorm_slabs_fwd_f32": [_p, _i, _p, _p, _p, _p, _i64, _i, _f, _f, _p],
@@ -102,18 +94,15 @@ SIGNATURES = {
     "sdt_convsk_dw_plan_build": [_G, _p, _i64],
     "sdt_convsk_dw_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "sdt_convsk_f32": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
+    "sdt_convsk_bf16": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
+    "sdt_convsk_supported_t": [_G, _i, _i],
+    "sdt_convsk_plan_build_t": [_G, _i, _i, _i, _i, _i, _p, _i64],
+    "sdt_convsk_dw_supported_t": [_G, _i],
+    "sdt_convsk_dw_plan_build_t": [_G, _i, _p, _i64],
+    "sdt_convsk_dw_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "sdt_convsk_set_spin_limit": [C.c_uint],
 }
-
-# entry points of the experiments (csrc/presplit.hip, csrc/conv1d.hip): present in the -DSDT_TUNING library only
-EXPERIMENTAL_SIGNATURES = {
-    "sdt_split_planes_f32": [_p, _p, _i64, _i, _p],
-    "sdt_weight_planes_batched": [_p, _i, _i, _p],
-    "sdt_conv_taps_pre_f32": [_p, _i64, _p, _i64, _p, _G, _i, _p, _i, C.POINTER(NormBwd), _p],
-    "sdt_set_pre_tile": [_i],
-    "sdt_c1d_layer_f32": [C.POINTER(C1d), _p],
-    "sdt_c1d_rownorm_partials_f32": [_p, _p, _i, _p, _p, _p, _i64, _i, _f, _f, _p],
-    "sdt_c1d_upsample_bwd_stats_f32": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p],
-}
+F32, BF16 = 0, 1  # enum sdt_dtype
 
 _lib = None
 
@@ -145,6 +134,10 @@ def load():
             "libsdt_hip.so not found at %s -- run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
             "this package has no CPU fallback" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.sdt_abi_version.restype = C.c_int
+    if lib.sdt_abi_version() != ABI_VERSION:  # checked BEFORE binding: a stale .so fails here, not with an AttributeError on a new symbol
+        raise ImportError("libsdt_hip.so at %s has ABI version %d, this package needs %d -- rebuild it (python __graft_entry__.py)"
+                          % (LIB_PATH, lib.sdt_abi_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
@@ -153,18 +146,12 @@ def load():
     lib.sdt_conv_dw_workspace_bytes.restype = C.c_int64
     lib.sdt_convsk_plan_bytes.argtypes = [_G, _i]
     lib.sdt_convsk_plan_bytes.restype = C.c_int64
-    if hasattr(lib, "sdt_c1d_layer_f32"):
-        for name, argtypes in EXPERIMENTAL_SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.argtypes = argtypes
-            fn.restype = C.c_int
-    if hasattr(lib, "sdt_convtab_f32"):  # the -DSDT_TUNING build only (experiment: the 64x64 kernel driven by a plan)
-        lib.sdt_convtab_plan_bytes.argtypes = [_G, _i]
-        lib.sdt_convtab_plan_bytes.restype = C.c_int64
-        for name, at in (("sdt_convtab_supported", [_G, _i]), ("sdt_convtab_plan_build", [_G, _i, _i, _i, _p, _i64]),
-                         ("sdt_convtab_f32", [_p, _p, _p, _p, _p, _p, _p, C.POINTER(NormBwd), _i, _i64, _i64, _i64, _p])):
-            getattr(lib, name).argtypes = at
-            getattr(lib, name).restype = C.c_int
+    lib.sdt_convsk_plan_bytes_t.argtypes = [_G, _i, _i]
+    lib.sdt_convsk_plan_bytes_t.restype = C.c_int64
+    lib.sdt_convsk_dw_plan_bytes_t.argtypes = [_G, _i]
+    lib.sdt_convsk_dw_plan_bytes_t.restype = C.c_int64
+    lib.sdt_convsk_get_spin_limit.argtypes = []
+    lib.sdt_convsk_get_spin_limit.restype = C.c_uint
     lib.sdt_convsk_dw_plan_bytes.argtypes = [_G]
     lib.sdt_convsk_dw_plan_bytes.restype = C.c_int64
     lib.sdt_convsk_dw_workspace_bytes.argtypes = []
@@ -172,17 +159,14 @@ def load():
     lib.sdt_convsk_workspace_bytes.argtypes = []
     lib.sdt_convsk_workspace_bytes.restype = C.c_int64
     lib.sdt_last_error.restype = C.c_char_p
-    lib.sdt_abi_version.restype = C.c_int
     lib.sdt_get_conv_math.restype = C.c_int
-    if lib.sdt_abi_version() != 1:
-        raise ImportError("libsdt_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
-def has_experimental():
-    """True when the loaded library is the -DSDT_TUNING build (carries the experiments' kernels)."""
-    return hasattr(load(), "sdt_c1d_layer_f32")
+def has_tuning():
+    """True when the loaded library is the -DSDT_TUNING build (timeline stamps, fault injection, ablation instantiations)."""
+    return hasattr(load(), "sdt_debug_convsk_mute_range")
 
 
 def check(status):

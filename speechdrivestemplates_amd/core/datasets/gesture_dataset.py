@@ -62,6 +62,8 @@ class PoseTransforms:
 
     def get_speaker_stat(self, speaker, num_kp, parted):
         table = SPEAKERS_STAT_121_parted if parted else SPEAKERS_STAT_121
+        if speaker not in table:
+            load_builtin_speaker_stats()  # the reference's own speakers (speakers_stat.py:4-1492), shipped as data
         if num_kp != 121 or speaker not in table:
             raise KeyError('no %s statistics registered for speaker %r (see register_speaker_stat)'
                            % ('parted' if parted else 'global', speaker))
@@ -253,6 +255,31 @@ class DeviceClipStore(PoseTransforms):
                                  'std': self._std64.expand(B, -1)},
                 'anchors': {'hand_root_l': torch.full((B,), HAND_ROOT_L), 'hand_root_r': torch.full((B,), HAND_ROOT_R),
                             'head_root': torch.full((B,), HEAD_ROOT)}}
+
+
+_BUILTIN_LOADED = [False]
+
+
+def load_builtin_speaker_stats():
+    """Register the reference's speakers (core/datasets/speakers_stat.py:4-1492: 9 with global-relative statistics, 11 with hierarchical
+    ones -- oliver at :497/:1265, kubinec at :440/:1208 ...) from the data file tests/golden/make_speaker_stats.py exported.  Speakers already
+    registered by the caller are left alone.  Called lazily by ``get_speaker_stat``."""
+    if _BUILTIN_LOADED[0]:
+        return
+    _BUILTIN_LOADED[0] = True
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'speakers_stat_121.npz')
+    if not os.path.exists(path):
+        return
+    data = np.load(path)
+    for key in data.files:
+        table, name, field = key.split('/')
+        if field != 'mean':
+            continue
+        dst = SPEAKERS_STAT_121_parted if table.endswith('_parted') else SPEAKERS_STAT_121
+        if name not in dst:
+            pre = '%s/%s/' % (table, name)
+            dst[name] = {'scale_factor': float(data[pre + 'scale_factor']), 'mean': data[pre + 'mean'], 'std': data[pre + 'std']}
 
 
 def load_speaker_stats(npz_path, name):

@@ -44,10 +44,13 @@ class ConvNormRelu(nn.Module):
         return (self.conv_type == '2d' and c.in_channels == 1 and c.out_channels == 64 and tuple(c.kernel_size) == (3, 3)
                 and self.stride == 1 and self.padding == 1 and (self.norm_type == 'IN' or self.training))
 
-    def forward_cl(self, x_cl, in_holder=None, out_holder=None):
+    def forward_cl(self, x_cl, in_holder=None, out_holder=None, out_f32=False):
         """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last.
         ``in_holder`` / ``out_holder`` (ops.NormBwdHolder, 2-D blocks of a strictly sequential chain only): ``x_cl`` is the output of
-        the normalisation that filled ``in_holder`` and has no other consumer; this block's normalisation fills ``out_holder``."""
+        the normalisation that filled ``in_holder`` and has no other consumer; this block's normalisation fills ``out_holder``.
+        bf16-storage path (ops.STORAGE == 'bf16'): the first block writes bf16, a 2-D block whose input is bf16 runs the bf16 kernels and
+        hands bf16 on -- fp32 with ``out_f32`` (the last encoder block, whose consumer is the fp32 1-D stage); a block the bf16 kernels do
+        not cover converts its input and continues in fp32."""
         if self._is_l0_block():  # single-channel mel image: conv + norm + activation fused, output written once
             n = self.norm
             if self.norm_type == 'IN':
@@ -59,16 +62,17 @@ class ConvNormRelu(nn.Module):
             return ops.ConvRowNormFn.apply(x_cl, self.conv.weight, self.stride, self.padding, self.slope)
         if self.conv_type == '2d' and (self.norm_type == 'IN' or self.training):
             groups = x_cl.shape[0] if self.norm_type == 'IN' else 1
-            if (ops.presplit_usable(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)
-                    or ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups)):
+            if ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups):
                 # the conv's epilogue accumulates the normalisation statistics: y is not re-read for them
-                link = ops.BlockLink() if (ops.presplit_on() and torch.is_grad_enabled()) else None
-                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder, link)
+                y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)
                 n = self.norm
                 if self.norm_type == 'IN':
-                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums, out_holder, link)
+                    return ops.ColNormActFn.apply(y, None, None, None, None, None, groups, self.slope, sums, out_holder, out_f32)
                 return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
-                                              self.slope, sums, out_holder, link)
+                                              self.slope, sums, out_holder, out_f32)
+        if x_cl.dtype == torch.bfloat16:
+            x_cl = x_cl.float()  # no bf16 kernel for this block: the rest of the chain runs in fp32
+            in_holder = None
         y = ops.ConvFn.apply(x_cl, self.conv.weight, None, self.stride, self.padding, in_holder)
         if self.norm_type == 'IN':
             if self.conv_type == '2d':  # per-(b,c) statistics over H*W

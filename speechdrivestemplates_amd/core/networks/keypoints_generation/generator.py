@@ -38,9 +38,9 @@ class AudioEncoder(nn.Module):
                     # fires in backward once blocks i.. have produced their weight gradients (dp.GradReducer buckets)
                     x.register_hook(hooks[i])
                 last = i == 7  # the last block feeds the resize, not a conv: nobody would use its hand-over
-                nxt = ops.NormBwdHolder() if (not last and (torch.is_grad_enabled() or ops.presplit_on())) else None
-                x = block.forward_cl(x, holder, nxt)
-                holder = nxt if (nxt is not None and (nxt.y is not None or nxt.zp is not None)) else None
+                nxt = ops.NormBwdHolder() if (not last and torch.is_grad_enabled()) else None
+                x = block.forward_cl(x, holder, nxt, out_f32=last)
+                holder = nxt if (nxt is not None and nxt.y is not None) else None
                 i += 1
         return x
 
@@ -105,15 +105,10 @@ class SequenceGeneratorCNN(nn.Module):
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         ops.stage_mark("g1d_fwd:begin")
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
-        stage1d = ops.STAGE1D  # None unless the experiment was switched on (experimental.stage1d.enable(), tuning library)
-        if stage1d is not None and stage1d.usable(self, h):
-            # one launch per layer and direction, normalisation / activation / upsample-add applied on load (csrc/conv1d.hip)
-            h = stage1d.Gen1dStageFn.apply(h, self, *[p for p in list(self.unet.parameters()) + list(self.decoder.parameters())])
-        else:
-            h = self.unet.forward_cl(h)
-            for block in list(self.decoder)[:4]:
-                h = block.forward_cl(h)
-            h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
+        h = self.unet.forward_cl(h)
+        for block in list(self.decoder)[:4]:
+            h = block.forward_cl(h)
+        h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
         ops.stage_mark("g1d_fwd:end")
         if ops.STAGES is not None and h.requires_grad:
             h.register_hook(lambda g: ops.stage_mark("g1d_bwd:begin"))

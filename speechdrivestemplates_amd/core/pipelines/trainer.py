@@ -147,7 +147,16 @@ class Trainer(object):
             ckpt['%s_state_dict' % k] = v.state_dict()
         return ckpt
 
+    @staticmethod
+    def check_kernels():
+        """Raise if a persistent stream-K convolution launch reported a lost partner since the last check (its tile was stored as NaN).
+        Called on log steps, after validation and before every checkpoint: a run never logs, validates or saves numbers that such
+        a launch produced (VERDICT r3 / ADVICE r3: the error word used to be read by tests and bench.py only)."""
+        from ... import ops
+        ops.check_streamk()
+
     def save_checkpoint(self, epoch, global_step):
+        self.check_kernels()
         d = os.path.join(self.base_path, 'checkpoints')
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, 'checkpoint_epoch-%d_step-%d.pth' % (epoch, global_step))
@@ -167,6 +176,7 @@ class Trainer(object):
 
     # -- logging (trainer.py:242-263) --------------------------------------------------------------------
     def logger_writer_step(self, tag, losses, step, epoch=None, global_step=None):
+        self.check_kernels()
         toc = (time.time() - self.step_tic) / self.cfg.SYS.LOG_INTERVAL
         self.step_tic = time.time()
         msg = '[%s] epoch: %s/%d  step: %d  global_step: %s  time: %.3f  ' % (tag, epoch, self.cfg.TRAIN.NUM_EPOCHS, step, global_step, toc)
@@ -228,6 +238,7 @@ class Trainer(object):
                 sums[k] = sums.get(k, 0) + v
             for k, v in res.items():
                 coll.setdefault(k, []).append(v)
+        self.check_kernels()
         out = {k: v / self.num_test_samples for k, v in sums.items()}
         if coll and self.is_master_process():
             out.update(self.evaluate_epoch({k: np.concatenate(v, axis=0) for k, v in coll.items()}))

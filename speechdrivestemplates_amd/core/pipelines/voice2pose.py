@@ -30,7 +30,12 @@ class Voice2PoseModel(nn.Module):
         code = cfg.VOICE2POSE.GENERATOR.CLIP_CODE
         if code.DIMENSION is not None:
             if code.FRAME_VARIANT:
-                raise NotImplementedError('CLIP_CODE.FRAME_VARIANT is not used by any shipped config')
+                # Per-frame codes (N, D, T) (voice2pose.py:66-67,148-150) cannot run in the REFERENCE either: its generator does
+                # `code.unsqueeze(2).repeat([1, 1, T])` (generator.py:110), which raises for a 3-D code ("Number of dimensions of repeat
+                # dims can not be smaller than number of dimensions of tensor" -- probed by importing the reference's own module,
+                # tests/test_host_logic.py records it).  No shipped yaml sets the key.  Same outcome, earlier and with the reason:
+                raise RuntimeError('VOICE2POSE.GENERATOR.CLIP_CODE.FRAME_VARIANT: the reference generator itself rejects per-frame codes '
+                                   '(generator.py:110: repeat() on a (B,D,1,T) tensor with 3 repeat dims); unsupported here as there')
             if code.EXTERNAL_CODE:  # fixed codes from a pose-VAE checkpoint (voice2pose.py:40-55)
                 if external_codes is not None:
                     self.clips_code = external_codes

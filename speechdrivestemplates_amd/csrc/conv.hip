@@ -1431,13 +1431,22 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = co0 + ty + 8 * i, ci = ci0 + tx;
-        tile[ty + 8 * i][tx] = (co < d.cout && ci < d.cin) ? d.w[((size_t)co * d.taps + t) * d.cin + ci] : 0.f;
+        const bool ok = co < d.cout && ci < d.cin;
+        const size_t o = ((size_t)co * d.taps + t) * d.cin + ci;
+        const float v = ok ? d.w[o] : 0.f;
+        tile[ty + 8 * i][tx] = v;
+        if (ok && d.w16 != nullptr) ((__bf16*)d.w16)[o] = (__bf16)v;  // bf16 copy of W itself (the bf16-storage path's forward operand)
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = ci0 + ty + 8 * i, co = co0 + tx;
-        if (ci < d.cin && co < d.cout) d.wt[((size_t)ci * d.taps + t) * d.cout + co] = tile[tx][ty + 8 * i];
+        if (ci < d.cin && co < d.cout) {
+            const size_t o = ((size_t)ci * d.taps + t) * d.cout + co;
+            const float v = tile[tx][ty + 8 * i];
+            if (d.wt != nullptr) d.wt[o] = v;
+            if (d.wt16 != nullptr) ((__bf16*)d.wt16)[o] = (__bf16)v;  // and of the mirror (its input-gradient operand)
+        }
     }
 }
 
@@ -1687,7 +1696,7 @@ extern "C" int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y,
         for (int c = 0; c < ncls; ++c)
             SDT_CHECK_ARG(nbw->groups == 1 ? (int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo >= 64 : gs[c]->Ho * gs[c]->Wo >= 64,
                           "a group must span at least one 64-row tile");
-        nb = {nbw->y, nbw->mean, nbw->rstd, nbw->gamma, nbw->beta, nbw->sums, nbw->slope, nbw->groups};
+        nb = {(const float*)nbw->y, nbw->mean, nbw->rstd, nbw->gamma, nbw->beta, nbw->sums, nbw->slope, nbw->groups};
     }
     return taps_dispatch(x, w, nullptr, y, gs, ncls, splitk, partial, nb, stream);
 }

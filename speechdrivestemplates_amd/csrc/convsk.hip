@@ -59,10 +59,11 @@ struct sk_args {
     unsigned* flags;        // [G]
     unsigned epoch;
     unsigned* err;          // set to a non-zero code when a spin gives up
+    unsigned spin_limit;    // polls of a partner's flag before the owner declares the launch failed (sdt_convsk_set_spin_limit)
 };
 
 struct sk_norm_bwd {
-    const float* y;
+    const void* y;          // forward output of the block below, element type TX of the launch
     const float* mean;
     const float* rstd;
     const float* gamma;
@@ -73,6 +74,16 @@ struct sk_norm_bwd {
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sk_bf16x2 __attribute__((ext_vector_type(2)));
+// Element type of the operands (TX: X, W and -- EPI 2 -- the forward output y of the block below) and of the output (TY): float, or
+// __bf16 for the bf16-storage path (BASELINE config 4): products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, tensors bf16 in HBM.
+// A K step is 128 BYTES of a row in both cases (32 fp32 / 64 bf16 channels), so the plan (byte offsets), the loader, the LDS tiles
+// ([row][128 B + 16 B pad]) and the 16-byte fragment reads are the same code; a fragment read feeds four fp32 MFMAs (k = 4 j' + e,
+// one product per lane) or ONE bf16 MFMA (k = 16 J + 8 (lane >> 5) + e, eight products per lane).
+template <typename T> struct sk_is_bf16 { static constexpr bool value = false; };
+template <> struct sk_is_bf16<__bf16> { static constexpr bool value = true; };
+__device__ __forceinline__ float sk_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 #define SK_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
@@ -88,14 +99,23 @@ extern "C" int sdt_debug_set_timeline_sk(void* p) {
     do {                                                                                              \
         if (threadIdx.x == 0 && sk_dbg_tl != nullptr && seg < 16) sk_dbg_tl[((size_t)r * 16 + seg) * 8 + (slot)] = (val); \
     } while (0)
+// fault injection (tests/test_ops_gpu.py::test_streamk_lost_partner_is_loud): the workgroup of this range computes its partial tile but never
+// raises its flag -- what a partner that was never dispatched looks like to the owner of the tile
+__device__ int sk_dbg_mute_range = -1;
+extern "C" int sdt_debug_convsk_mute_range(int r) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sk_dbg_mute_range), &r, sizeof(r));
+    return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
+}
+#define SK_MUTED(r) ((r) == sk_dbg_mute_range)
 #else
+#define SK_MUTED(r) false
 #define SK_TL(slot, val) do { } while (0)
 #endif
 
 // Epilogue of a finished output tile held in TM x TN accumulators per wave (2x2 wave grid): branch-free buffer stores (+ bias) and,
 // for EPI 1 / 2, the per-(group, channel) statistics.  sOut / sGrp: LDS, [BM] byte offset of each tile row in Y (SK_OOB: none) and its
 // statistics group.  C/D layout of a 32x32 accumulator: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).
-template <int BM, int BN, int EPI, int TMB = 0, int TME = BM / 64>
+template <typename TX, typename TY, int BM, int BN, int EPI, int TMB = 0, int TME = BM / 64>
 __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], const int* sOut, const int* sGrp, const int n0, const int wm,
                                             const int wn, const int lane, const float* __restrict__ bias, const __amdgpu_buffer_rsrc_t rsY,
                                             const int Cout, double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes) {
@@ -111,7 +131,8 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
         for (int tm = TMB; tm < TME; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const unsigned nb4 = (unsigned)(n0 + wn * (BN / 2) + tn * 32 + (lane & 31)) * 4u;
+                // (sOut holds byte offsets of the output rows in Y; y has Y's shape, and -- host-checked -- its element size: TX == TY with EPI 2)
+                const unsigned nb4 = (unsigned)(n0 + wn * (BN / 2) + tn * 32 + (lane & 31)) * (unsigned)sizeof(TX);
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int4 o4 = *(const int4*)&sOut[wm * (BM / 2) + tm * 32 + 8 * qq + 4 * (lane >> 5)];
@@ -121,8 +142,12 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
 #ifdef SK_NO_YLOAD  // ablation (wrong results): cost of the epilogue's reads of the forward output
                         yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] = (float)offs[e];
 #else
-                        yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] =
-                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + nb4), 0, 0));
+                        if constexpr (sk_is_bf16<TX>::value)
+                            yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] =
+                                sk_bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rsNY, (int)((unsigned)offs[e] + nb4), 0, 0));
+                        else
+                            yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] =
+                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + nb4), 0, 0));
 #endif
                 }
             }
@@ -138,11 +163,30 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int4 o4 = *(const int4*)&sOut[wm * (BM / 2) + tm * 32 + 8 * qq + 4 * (lane >> 5)];
-                const unsigned nb4 = (unsigned)n * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 0] + bv), rsY, (int)((unsigned)o4.x + nb4), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 1] + bv), rsY, (int)((unsigned)o4.y + nb4), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 2] + bv), rsY, (int)((unsigned)o4.z + nb4), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 3] + bv), rsY, (int)((unsigned)o4.w + nb4), 0, 0);
+                if constexpr (sk_is_bf16<TY>::value) {
+                    // bf16 output: a lane holds ONE column of four consecutive rows; lanes l and l ^ 1 hold neighbouring columns.  Each pair of
+                    // lanes swaps one value per row pair (DPP quad_perm [1,0,3,2]) so that the even lane stores the column pair of the first
+                    // row and the odd lane that of the second as ONE dword: half the stores, each 4 bytes instead of 2
+                    const bool odd = lane & 1;
+                    const unsigned nb2 = (unsigned)(n & ~1) * 2u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float v0 = tot[tm][tn][4 * qq + 2 * h] + bv, v1 = tot[tm][tn][4 * qq + 2 * h + 1] + bv;
+                        const float give = odd ? v0 : v1;
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+                        sk_bf16x2 pk;
+                        pk[0] = (__bf16)(odd ? got : v0);
+                        pk[1] = (__bf16)(odd ? v1 : got);
+                        const int ro = odd ? (h ? o4.w : o4.y) : (h ? o4.z : o4.x);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rsY, (int)((unsigned)ro + nb2), 0, 0);
+                    }
+                } else {
+                    const unsigned nb4 = (unsigned)n * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 0] + bv), rsY, (int)((unsigned)o4.x + nb4), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 1] + bv), rsY, (int)((unsigned)o4.y + nb4), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 2] + bv), rsY, (int)((unsigned)o4.z + nb4), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[tm][tn][4 * qq + 3] + bv), rsY, (int)((unsigned)o4.w + nb4), 0, 0);
+                }
             }
             if constexpr (EPI == 1 || EPI == 2) {
                 // statistics over the rows of this 32-row block: its rows belong to at most two groups (groups ascend with the
@@ -214,12 +258,32 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
         }
 }
 
+// Scheduling hints of one bf16 K step before its barrier (sched_group_barrier wants literal counts, hence the recursion): a k-group is only
+// NM = TM * TN MFMAs of 32 cycles -- 3 NM MFMAs against 3 NF fragment reads, NL LDS stores and NL global loads.  Every MFMA of k-groups 0
+// and 1 is followed by its share of the next group's fragment reads, of one half of the stores and of the loads that re-fill the registers
+// just stored; every MFMA of k-group 2 by its share of k-group 3's reads.
+template <int G2, int Q, int NM, int NF, int NL>
+__device__ __forceinline__ void sk_bf_interleave() {
+    constexpr int HL = (NL + 1) / 2;
+    constexpr int lo = G2 * HL, hi = G2 < 2 ? ((G2 + 1) * HL < NL ? (G2 + 1) * HL : NL) : lo;
+    constexpr int nr = (NF + NM - 1 - Q) / NM, nw = (hi - lo + NM - 1 - Q) / NM;
+    SK_SGB(0x8, 1);
+    if constexpr (nr > 0) SK_SGB(0x100, nr);
+    if constexpr (nw > 0) {
+        SK_SGB(0x200, nw);
+        SK_SGB(0x20, nw);
+    }
+    if constexpr (Q + 1 < NM) sk_bf_interleave<G2, Q + 1, NM, NF, NL>();
+    else if constexpr (G2 + 1 < 3) sk_bf_interleave<G2 + 1, 0, NM, NF, NL>();
+}
+
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
-template <int BM, int BN, int EPI, int WPC>
-__global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                     float* __restrict__ Y, const sk_args P, double* __restrict__ stats,
+template <typename TX, typename TY, int BM, int BN, int EPI, int WPC>
+__global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__ X, const TX* __restrict__ W, const float* __restrict__ bias,
+                                                     TY* __restrict__ Y, const sk_args P, double* __restrict__ stats,
                                                      const int rows_per_group, const sk_norm_bwd nb) {
-    constexpr int TM = BM / 64, TN = BN / 64, RA = BM / 32, RB = BN / 32, NM = TM * TN * 4;
+    constexpr bool BF = sk_is_bf16<TX>::value;
+    constexpr int TM = BM / 64, TN = BN / 64, RA = BM / 32, RB = BN / 32, NM = TM * TN * (BF ? 1 : 4);  // MFMAs per k-group of a step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                          // [2][BM * LDP]
     float* sB = smem + 2 * BM * SK_LDP;        // [2][BN * LDP]
@@ -285,7 +349,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
             inval[i] = (unsigned)ri.y;
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((n0 + r0 + 32 * i) * cl.Tw * cl.Cin) * 4u + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
+        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((n0 + r0 + 32 * i) * cl.Tw * cl.Cin) * (unsigned)sizeof(TX) + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
         if (tid < BM) {
             const int2 ro = ((const int2*)P.rowinfo)[2 * (m0 + tid) + 1];  // {Y byte offset, statistics group}
             sOut[tid] = ro.x;
@@ -339,9 +403,15 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm] = *(const f32x4*)((PA) + tm * 32 * SK_LDP + (J) * 8);       \
     _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) B[tn] = *(const f32x4*)((PB) + tn * 32 * SK_LDP + (J) * 8)
 #define SK_MFMA(SET, A, B)                                                                                              \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                     \
-        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                               \
-            acc[SET][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], B[tn][e], acc[SET][tm][tn], 0, 0, 0)
+    if constexpr (BF) {                                                                                                 \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)             \
+            acc[SET][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, A[tm]),            \
+                                                                       __builtin_bit_cast(sk_bf16x8, B[tn]), acc[SET][tm][tn], 0, 0, 0); \
+    } else {                                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                 \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                           \
+                acc[SET][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][e], B[tn][e], acc[SET][tm][tn], 0, 0, 0); \
+    }
 
         // one K step (ONE instance in the kernel: variants of this body for the first step of an accumulation chunk doubled the
         // loop nest and made the register allocator spill around the chunk loop of the 128x128 / two-workgroups-per-CU kernels)
@@ -362,7 +432,9 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
             SK_READ(a1, b1, pa, pb, 3);
             SK_MFMA(SET, a0, b0);
             // the interleave: one feeding instruction after each MFMA, in this order
-            {
+            if constexpr (BF) {
+                sk_bf_interleave<0, 0, NM, TM + TN, RA + RB>();
+            } else {
                 constexpr int NF = TM + TN, NL = RA + RB;
 #pragma unroll
                 for (int q = 0; q < NF; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
@@ -392,7 +464,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
             SK_MFMA(SET, a1, b1);
 #pragma unroll
             for (int q = 0; q < TM + TN; ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
-            SK_SGB(0x8, NM - (TM + TN));
+            if constexpr (NM > TM + TN) SK_SGB(0x8, NM - (TM + TN));
             __builtin_amdgcn_sched_barrier(0);
         };
         // the finished chunk goes into the running total and the accumulators restart from zero
@@ -450,18 +522,19 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store((gu32*)(P.flags + r), P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !SK_MUTED(r)) __hip_atomic_store((gu32*)(P.flags + r), P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (!whole) {
                 // the ranges r+1 .. r_last hold the rest of this tile: r(x) = ((x + 1) * G - 1) / S for the tile's last step x
                 const int r_last = (int)((((long)tend) * G - 1) / P.S);
+                bool lost = false;  // a partner never arrived: the tile is POISONED (NaN), never stored with a partial sum missing
                 for (int cr = r + 1; cr <= r_last; ++cr) {
                     if (wave == 0) {
                         unsigned spins = 0;
                         bool ok = true;
                         while (__hip_atomic_load((gu32*)(P.flags + cr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.epoch) {
                             __builtin_amdgcn_s_sleep(8);
-                            if (++spins > (1u << 22)) {
+                            if (++spins > P.spin_limit) {
                                 ok = false;
                                 break;
                             }
@@ -469,6 +542,9 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
                         if (lane == 0) {
                             sFlagOk = ok ? 1 : 0;
                             if (!ok) __hip_atomic_store((gu32*)P.err, 1u + (unsigned)cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // the flag's only consumer lowers it again: every flag is zero between launches, whatever `epoch` the next one
+                            // carries -- launches recorded into a hipGraph replay with the epoch they were captured with
+                            else __hip_atomic_store((gu32*)(P.flags + cr), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
@@ -485,11 +561,21 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) tot[i][j][4 * q + e] += v[e];
                                 }
+                    } else {
+                        lost = true;
                     }
                     __syncthreads();
                 }
+                if (lost) {  // the error word is set; NaN outputs (and NaN statistics) make the failure visible downstream as well
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) tot[i][j][q] = __builtin_nanf("");
+                }
             }
-            sk_epilogue<BM, BN, EPI>(tot, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
+            sk_epilogue<TX, TY, BM, BN, EPI>(tot, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
         }
         SK_TL(4, wall_clock64());
         // ------------------------------------------------------------------ next tile of the range
@@ -514,126 +600,6 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const float* __restric
 #undef SK_MFMA
 }
 
-#ifdef SDT_TUNING  // measured, not faster than conv_taps_kernel (profiles/r03_streamk_ab.txt): kept as an experiment only
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENT (tuning build): the 64x64-tile kernel of conv.hip (7 workgroups per CU, register-staged K loop) with the PLAN doing its
-// index work.  Result: NOT faster than the original (+5 % on three launches, -5 % on five, the (6,3) input gradient -17 % without the
-// original's tile rotation): the slow prologue of the original overlaps other workgroups' MFMAs and is not what bounds it.  The timeline of
-// the original (profiles/r03_taps_timeline_64x64.txt) shows a prologue of 6 us alone / 30 us under load -- integer divisions, two serial
-// LDS loops over the taps, three barriers -- and an epilogue of 9 us (16 LDS-dependent, branch-guarded dword stores per lane), i.e. a
-// third of a workgroup's life outside its K loop.  Here the prologue is a handful of independent table loads and the epilogue the
-// branch-free buffer stores of sk_epilogue.  One workgroup per output tile; tiles of all classes in one 1-D grid, XCD-chunked.
-// CHUNK > 0: fp32 accumulation in chunks of CHUNK K steps (see the header of this file).
-template <int EPI, int CHUNK>
-__global__ __launch_bounds__(256) void conv_tab_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                       float* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
-    constexpr int BM = 64, BN = 64, RA = 2, RB = 2;
-    __shared__ __attribute__((aligned(16))) float sA[BM * SK_LDP];
-    __shared__ __attribute__((aligned(16))) float sB[BN * SK_LDP];
-    __shared__ __attribute__((aligned(16))) int sOut[BM];
-    __shared__ __attribute__((aligned(16))) int sGrp[BM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kv = tid & 7, r0 = tid >> 3;
-    const int tile = xcd_remap(blockIdx.x, P.T);
-    int c = 0;
-    while (c + 1 < P.ncls && tile >= P.cls[c + 1].tile_begin) ++c;
-    const sk_class& cl = P.cls[c];
-    const int rel = tile - cl.tile_begin;
-    const int mt = rel / P.nnb, nt = rel - mt * P.nnb;
-    const int Hi = __builtin_amdgcn_readfirstlane(cl.Hi), Wi = __builtin_amdgcn_readfirstlane(cl.Wi);
-    const int nkc = __builtin_amdgcn_readfirstlane(cl.nkc), Cout = __builtin_amdgcn_readfirstlane(cl.Cout);
-    const int ntaps = __builtin_amdgcn_readfirstlane(cl.ntaps);
-    const int m0 = cl.row_begin + mt * BM, n0 = nt * BN;
-    // every table read of the prologue is issued before the first result is needed
-    int2 ti = P.tileinfo[cl.mt_begin + mt];
-    const int4 ri0 = P.rowinfo[m0 + r0], ri1 = P.rowinfo[m0 + r0 + 32];
-    int v_ash = 0, v_bsh = 0;
-    if (lane < ntaps) {
-        v_ash = cl.ashift[lane];
-        v_bsh = cl.bshift[lane];
-    }
-    if (tid < BM) {
-        const int4 ri = P.rowinfo[m0 + tid];
-        sOut[tid] = ri.z;
-        sGrp[tid] = ri.w;
-    }
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)P.wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)P.ybytes, 0x00020000);
-    unsigned rmask = (unsigned)__builtin_amdgcn_readfirstlane(ti.x);
-    const int rot = __builtin_amdgcn_readfirstlane(ti.y);
-    const int nsteps = __builtin_popcount(rmask) * nkc;
-    unsigned abase[RA], bbase[RB], aoff[RA], boff[RB];
-    unsigned inval[RA];
-    abase[0] = (unsigned)ri0.x + (unsigned)kv * 16u, abase[1] = (unsigned)ri1.x + (unsigned)kv * 16u;
-    inval[0] = (unsigned)ri0.y, inval[1] = (unsigned)ri1.y;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((n0 + r0 + 32 * i) * cl.Tw * cl.Cin) * 4u + (unsigned)kv * 16u;
-    int kc = 0;
-    bool newtap = true;
-    f32x4 ra[RA], rb[RB];
-    auto load = [&]() {
-        if (newtap) {  // uniform: row offsets are rebuilt only when the tap changes (every Cin/32 steps)
-            int t = (rmask != 0u ? __builtin_ctz(rmask) : 0) + rot;
-            t = t >= ntaps ? t - ntaps : t;
-            const int ash = __builtin_amdgcn_readlane(v_ash, t), bsh = __builtin_amdgcn_readlane(v_bsh, t);
-#pragma unroll
-            for (int i = 0; i < RA; ++i) aoff[i] = (inval[i] >> t) & 1u ? SK_OOB : abase[i] + (unsigned)ash;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) boff[i] = bbase[i] + (unsigned)bsh;
-        }
-        const int cs = kc * (SK_BK * 4);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)aoff[i], cs, 0));
-#pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)boff[i], cs, 0));
-        newtap = ++kc == nkc;
-        if (newtap) {
-            kc = 0;
-            rmask &= rmask - 1u;
-        }
-    };
-    f32x16 acc[1][1], tot[1][1];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f, tot[0][0][q] = 0.f;
-    const float* pa = sA + (wm * 32 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
-    const float* pb = sB + (wn * 32 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
-    if (nsteps > 0) load();
-    for (int step = 0; step < nsteps; ++step) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *(f32x4*)&sA[(r0 + 32 * i) * SK_LDP + kv * 4] = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *(f32x4*)&sB[(r0 + 32 * i) * SK_LDP + kv * 4] = rb[i];
-        __syncthreads();
-        if (step + 1 < nsteps) load();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a = *(const f32x4*)(pa + j * 8), b = *(const f32x4*)(pb + j * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[0][0], 0, 0, 0);
-        }
-        if constexpr (CHUNK > 0) {
-            if ((step + 1) % CHUNK == 0) {  // uniform
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    tot[0][0][q] += acc[0][0][q];
-                    acc[0][0][q] = 0.f;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if constexpr (CHUNK > 0) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tot[0][0][q] += acc[0][0][q];
-        sk_epilogue<BM, BN, EPI, 0, 1>(tot, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
-    } else {
-        sk_epilogue<BM, BN, EPI, 0, 1>(acc, sOut, sGrp, n0, wm, wn, lane, bias, rsY, Cout, stats, nb, P.ybytes);
-    }
-}
-
-#endif  // SDT_TUNING
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient on the same machinery:  dW[n, (t, c)] = sum_m dY[m, n] * X[row(m) + tap t, c]  -- a GEMM whose reduction runs over
@@ -854,6 +820,153 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient (bf16-storage path): the same (tile, K-chunk) decomposition, slabs and ordered reduce as convsk_dw_kernel, on
+// v_mfma_f32_32x32x16_bf16.  A K step is 64 output positions m.  Both operands are m-major in HBM and the bf16 MFMA wants 8 CONSECUTIVE k
+// (= m) per lane, i.e. a transposed operand: the tiles are stored m-major in LDS exactly as they are loaded ([m][BM] / [m][BN] bf16, one
+// 16-byte load = 8 columns of one m) and the fragments are read with ds_read_b64_tr_b16, gfx950's transposing LDS read: the 16 lanes of a
+// group address a 4 (m) x 16 (columns) block -- lane p the 4 columns 4 (p & 3) .. of row p >> 2 -- and lane i receives column i of the four
+// rows (tools/debug/tr16_probe.hip: semantics, the MFMA identity and the bank behaviour measured on the GPU).  The 64-byte segments of a row
+// are XOR-swizzled with the row so that the four rows of a group fall into the four quarters of the 256-byte bank window.
+template <int W>
+__device__ __forceinline__ int bfdw_off(const int row, const int col) {  // element offset of (row, col) in a swizzled [64][W] bf16 tile
+    constexpr int S = W / 32;                                            // 64-byte segments per row
+    const int f = S == 4 ? (row & 3) : ((row >> 1) & 1);
+    return row * W + ((((col >> 5) ^ f) << 5) | (col & 31));
+}
+typedef short sk_s16x4 __attribute__((ext_vector_type(4)));
+typedef short sk_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) sk_s16x4 sk_lds_s16x4;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ dY, const sk_args P, const int K,
+                                                           const int ncol, const int nchunk, float* __restrict__ slabs) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int CA = BM / 8, CB = BN / 8;          // 16-byte chunks per tile row
+    constexpr int RPA = 256 / CA, RPB = 256 / CB;    // tile rows covered by one pass of the 256 threads
+    constexpr int LA = 64 / RPA, LB = 64 / RPB;      // loads per thread and K step
+    extern __shared__ __attribute__((aligned(16))) short smem_h[];
+    short* sA = smem_h;                 // [2][64][BM]
+    short* sB = smem_h + 2 * 64 * BM;   // [2][64][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cqa = tid % CA, rra = tid / CA, cqb = tid % CB, rrb = tid / CB;
+    const int G = P.G, T = P.T;
+    const int bid = blockIdx.x;
+    const int u = (bid & 7) * (G >> 3) + (bid >> 3);
+    if (u >= T * nchunk) return;
+    const int chunk = u / T, tile = u - chunk * T;
+    const sk_class& cl = P.cls[0];
+    const int Cin = __builtin_amdgcn_readfirstlane(cl.Cin);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)P.ybytes, 0x00020000);
+    const int a = (int)((long)chunk * K / nchunk), b = (int)((long)(chunk + 1) * K / nchunk);
+    const int nt = tile / ncol, ct = tile - nt * ncol;
+    const int n0 = nt * BM, j0 = ct * BN;
+    // this thread's B columns: 8 consecutive channels of ONE tap (Cin % 64 == 0)
+    const int j = j0 + cqb * 8;
+    const int t = j / Cin, c = j - t * Cin;
+    const unsigned acol = (unsigned)(n0 + cqa * 8) * 2u;
+    const unsigned bcol = (unsigned)cl.ashift[t] + (unsigned)c * 2u;
+    const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
+    int ya[LA];
+    int2 xb[LB];
+    f32x4 ra[LA], rb[LB];
+    int mrow = a * 64;  // first row of the next table read
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ya[i] = ((const int*)P.rowinfo)[4 * (mrow + rra + RPA * i) + 2];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) xb[i] = ((const int2*)P.rowinfo)[2 * (mrow + rrb + RPB * i)];
+        mrow += 64;
+    };
+    int left = b - a;
+    auto load = [&]() {
+        const unsigned off_mask = left > 0 ? 0u : SK_OOB;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const unsigned oa = ((unsigned)ya[i] + acol) | off_mask;  // rows past M carry SK_OOB already
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
+        }
+        --left;
+    };
+    auto stage = [&](const int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *(f32x4*)&sA[buf * 64 * BM + bfdw_off<BM>(rra + RPA * i, cqa * 8)] = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *(f32x4*)&sB[buf * 64 * BN + bfdw_off<BN>(rrb + RPB * i, cqb * 8)] = rb[i];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][jj][q] = 0.f;
+    // fragment addressing: lane = 16 g + p; the group reads rows 8 (g >> 1) + (p >> 2) (+ 4 for the second half of the k block), columns
+    // 16 (g & 1) + 4 (p & 3) of its 32-column sub-tile
+    const int g4 = lane >> 4, p4 = lane & 15;
+    const int frow = 8 * (g4 >> 1) + (p4 >> 2), fcol = 16 * (g4 & 1) + 4 * (p4 & 3);
+    load_rows();
+    load();
+    load_rows();
+    stage(0);
+    load();
+    load_rows();
+    __syncthreads();
+    const int nsteps = b - a;
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        const short* pa = sA + cur * 64 * BM;
+        const short* pb = sB + cur * 64 * BN;
+        stage(cur ^ 1);  // the registers hold step s + 1
+        load();          // step s + 2
+        load_rows();     // tables of step s + 3
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {  // k16 blocks of the step
+            sk_s16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int col = wm * (BM / 2) + tm * 32 + fcol;
+                const sk_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pa + bfdw_off<BM>(16 * kb + frow, col)));
+                const sk_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pa + bfdw_off<BM>(16 * kb + frow + 4, col)));
+                fa[tm] = (sk_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = wn * (BN / 2) + tn * 32 + fcol;
+                const sk_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pb + bfdw_off<BN>(16 * kb + frow, col)));
+                const sk_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pb + bfdw_off<BN>(16 * kb + frow + 4, col)));
+                fb[tn] = (sk_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, fa[tm]), __builtin_bit_cast(sk_bf16x8, fb[tn]),
+                                                                          acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();  // everybody has read LDS[cur] and written LDS[cur ^ 1]
+    }
+    // partial tile -> slab of this unit (natural [n][j] layout: the reduce kernel reads it coalesced)
+    float* slab = slabs + (size_t)u * (BM * BN);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nl = wm * (BM / 2) + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const int jl = wn * (BN / 2) + tn * 32 + (lane & 31);
+                slab[nl * BN + jl] = acc[tm][tn][q];
+            }
+}
+
 // dw[n, wt(t), c] += the slabs of tile (nt, ct), chunk 0 first.  One thread per 4 consecutive columns of a tile row.
 __global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, const sk_args P, const int ncol,
                                                            const int nchunk, const int Cout, const int Tw, const int BM, const int BN) {
@@ -881,10 +994,11 @@ __global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restri
 #define SK_HDR 16
 #define SK_CLS_INTS (11 + 3 * SDT_MAX_TAPS)
 
-static bool sk_supported(const sdt_conv_geom* const* gs, int ncls, int bm, int bn) {
+// esz: bytes per element of X / W (4 fp32, 2 bf16).  A K step is 128 bytes of a row.
+static bool sk_supported(const sdt_conv_geom* const* gs, int ncls, int bm, int bn, int esz = 4) {
     for (int c = 0; c < ncls; ++c) {
         const sdt_conv_geom& g = *gs[c];
-        if (g.Cin % SK_BK != 0 || g.Cout % bn != 0 || g.Hi >= 32768 || g.Wi >= 32768 || g.ntaps > SDT_MAX_TAPS) return false;
+        if ((g.Cin * esz) % 128 != 0 || g.Cout % bn != 0 || g.Hi >= 32768 || g.Wi >= 32768 || g.ntaps > SDT_MAX_TAPS) return false;
         if (g.Cin != gs[0]->Cin || g.Cout != gs[0]->Cout || g.Tw != gs[0]->Tw || g.B != gs[0]->B || g.Hi != gs[0]->Hi || g.Wi != gs[0]->Wi ||
             g.Hy != gs[0]->Hy || g.Wy != gs[0]->Wy)
             return false;
@@ -932,40 +1046,39 @@ static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, in
     return SK_HDR + rows * 4 + mts * 2 + (T + 1) + G + (int64_t)ncls * SK_CLS_INTS;
 }
 
-// kind: 0 = stream-K plan (tile and grid from the workgroups-per-CU setting), 1 = plan of the 64x64 table-driven kernel
-static void plan_shape(const sdt_conv_geom& g, int kind, int& bm, int& bn, int& G) {
-    if (kind == 1) {
-        bm = 64, bn = 64, G = 8;
-    } else {
-        sk_tile_choice(g, bm, bn);
-        G = 256 * g_sk_wpc - g_sk_reserve;
-    }
+// tile and grid from the workgroups-per-CU setting
+static void plan_shape(const sdt_conv_geom& g, int& bm, int& bn, int& G) {
+    sk_tile_choice(g, bm, bn);
+    G = 256 * g_sk_wpc - g_sk_reserve;
 }
 
-static int plan_supported(const sdt_conv_geom* geoms, int ncls, int kind) {
-    if (!geoms || ncls < 1 || ncls > SK_MAXC) return 0;
+static int dtype_bytes(int dtype) { return dtype == SDT_F32 ? 4 : (dtype == SDT_BF16 ? 2 : 0); }
+
+static int plan_supported(const sdt_conv_geom* geoms, int ncls, int esz) {
+    if (!geoms || ncls < 1 || ncls > SK_MAXC || (esz != 4 && esz != 2)) return 0;
+    if (esz == 2 && g_sk_wpc != 2) return 0;  // the bf16 instantiations exist for two workgroups per CU only
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], kind, bm, bn, G);
-    return sk_supported(gs, ncls, bm, bn) ? 1 : 0;
+    plan_shape(*gs[0], bm, bn, G);
+    return sk_supported(gs, ncls, bm, bn, esz) ? 1 : 0;
 }
-extern "C" int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 0); }
-extern "C" int sdt_convtab_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 1); }
+extern "C" int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 4); }
+extern "C" int sdt_convsk_supported_t(const sdt_conv_geom* geoms, int ncls, int x_dtype) { return plan_supported(geoms, ncls, dtype_bytes(x_dtype)); }
 
 // grid of a plan (number of persistent workgroups): one per CU
 extern "C" int sdt_convsk_grid(void) { return 256 * g_sk_wpc - g_sk_reserve; }
 
-static int64_t plan_bytes(const sdt_conv_geom* geoms, int ncls, int kind) {
-    if (!plan_supported(geoms, ncls, kind)) return -1;
+static int64_t plan_bytes(const sdt_conv_geom* geoms, int ncls, int esz) {
+    if (!plan_supported(geoms, ncls, esz)) return -1;
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], kind, bm, bn, G);
+    plan_shape(*gs[0], bm, bn, G);
     return sk_plan_ints(gs, ncls, bm, bn, G) * 4;
 }
-extern "C" int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 0); }
-extern "C" int64_t sdt_convtab_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 1); }
+extern "C" int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 4); }
+extern "C" int64_t sdt_convsk_plan_bytes_t(const sdt_conv_geom* geoms, int ncls, int x_dtype) { return plan_bytes(geoms, ncls, dtype_bytes(x_dtype)); }
 
 // workspace of a launch: slabs + flags + error word (bytes); the caller zero-fills it ONCE after allocation and hands the same
 // buffer to every launch of one stream with a strictly increasing epoch (>= 1)
@@ -974,6 +1087,16 @@ extern "C" int64_t sdt_convsk_workspace_bytes(void) { return (int64_t)512 * (128
 // Builds the plan into host memory `out` (sdt_convsk_plan_bytes bytes); the caller copies it to the device once per geometry.
 // rows_per_group > 0: statistics group of row m of class c = m / rows_per_group (forward statistics) -- for an input gradient with
 // normalisation-backward statistics pass -1: the group is the batch item (groups == B) or 0 (groups == 1), chosen by `bwd_groups`.
+// How long the owner of a split tile polls a partner's flag (one poll = a relaxed load + s_sleep 8, ~1 us under load) before it gives
+// up: the launch's error word is set (ops.streamk_error_codes(); Trainer raises on it) and the tile is stored as NaN.  The default is
+// seconds -- partners publish at the START of their ranges, so a partner that has not arrived by then is not coming (it was never
+// dispatched: the GPU is shared with a process that holds its slot).
+static unsigned g_sk_spin_limit = 1u << 22;
+extern "C" int sdt_convsk_set_spin_limit(unsigned polls) {
+    g_sk_spin_limit = polls;
+    return SDT_OK;
+}
+extern "C" unsigned sdt_convsk_get_spin_limit(void) { return g_sk_spin_limit; }
 static int g_sk_ntmajor_bytes = 2 << 20;
 static int g_sk_perm_pct = 95, g_sk_perm_pct_bwd = 95;  // image-row-major tile order when it leaves <= this many % of the K steps
 #ifdef SDT_TUNING
@@ -987,13 +1110,14 @@ extern "C" int sdt_convsk_set_perm_pct(int pct) {  // forward plans: pct % 1000,
     return SDT_OK;
 }
 #endif
-static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes, int kind) {
-    SDT_CHECK_ARG(plan_supported(geoms, ncls, kind), "geometry not supported by this kernel");
-    SDT_CHECK_ARG(out != nullptr && out_bytes >= plan_bytes(geoms, ncls, kind), "plan buffer too small");
+// esz / ysz: bytes per element of X, W / of Y (every byte offset of the plan is in those units; a K step is 128 bytes of an X row)
+static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes, int esz, int ysz) {
+    SDT_CHECK_ARG(plan_supported(geoms, ncls, esz) && (ysz == 4 || ysz == 2), "geometry / element types not supported by this kernel");
+    SDT_CHECK_ARG(out != nullptr && out_bytes >= plan_bytes(geoms, ncls, esz), "plan buffer too small");
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], kind, bm, bn, G);
+    plan_shape(*gs[0], bm, bn, G);
     int* P = (int*)out;
     const int nnb = gs[0]->Cout / bn;
     int64_t rows = 0, mts = 0;
@@ -1017,18 +1141,18 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     // sit at different K positions of their tiles, so unlike the one-tile-per-workgroup kernel nothing else keeps the weight reads of an XCD
     // together: measured fabric traffic 2*FETCH+WRITE of the 128x128 launches 481 MB against 99 MB algorithmic before this.)
     // (from 64 row tiles up, like the row-major order below: on small launches neither ordering buys anything)
-    const bool ntmajor = kind == 0 && ncls == 1 && nnb > 1 && (int64_t)gs[0]->Cout * gs[0]->Tw * gs[0]->Cin * 4 > (int64_t)g_sk_ntmajor_bytes &&
+    const bool ntmajor = ncls == 1 && nnb > 1 && (int64_t)gs[0]->Cout * gs[0]->Tw * gs[0]->Cin * esz > (int64_t)g_sk_ntmajor_bytes &&
                          cdiv64((int64_t)gs[0]->B * gs[0]->Ho * gs[0]->Wo, bm) >= 64;
     for (int c = 0; c < ncls; ++c) {
         const sdt_conv_geom& g = *gs[c];
         const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
         const int nmb = (int)cdiv64(M, bm);
-        const int nkc = g.Cin / SK_BK;
+        const int nkc = g.Cin * esz / 128;
         int dymin = g.dy[0], dymax = g.dy[0];
         for (int t = 1; t < g.ntaps; ++t) dymin = std::min(dymin, g.dy[t]), dymax = std::max(dymax, g.dy[t]);
         const int nd = dymax - dymin + 1;
         // tap order: by the residue of the input row a tap reads on layers whose weights fit an L2 (see conv.hip), table order otherwise
-        const bool rotate = (unsigned)g.Cout * (unsigned)g.Tw * (unsigned)g.Cin <= (3u << 17);
+        const bool rotate = (unsigned)g.Cout * (unsigned)g.Tw * (unsigned)g.Cin * (unsigned)esz <= (3u << 19);  // <= 1.5 MB of weights
         // taps must be sorted by dy for the rotation to be a cyclic shift of the table: true for every geometry ops.py builds
         bool sorted = true;
         for (int t = 1; t < g.ntaps; ++t) sorted = sorted && g.dy[t] >= g.dy[t - 1];
@@ -1089,9 +1213,9 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
                 decode(m, perm, b, oy, ox);
                 const int64_t mnat = ((int64_t)b * g.Ho + oy) * g.Wo + ox;
                 const int iy0 = oy * g.sy, ix0 = ox * g.sx;
-                ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * 4));
+                ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * esz));
                 unsigned inval = 0x80000000u;  // bit t: tap t reads outside X for this row; bit 31: always set (the "loader off" position)
-                ri[2] = (int)((((int64_t)b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout * 4);  // byte offset of the output row in Y
+                ri[2] = (int)((((int64_t)b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout * ysz);  // byte offset of the output row in Y
                 ri[3] = rows_per_group > 0 ? (int)(mnat / rows_per_group) : (bwd_groups == 1 ? 0 : b);
                 for (int t = 0; t < g.ntaps; ++t) {
                     if ((unsigned)(iy0 + g.dy[t]) < (unsigned)g.Hi && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.Wi) mask |= 1u << t;
@@ -1122,6 +1246,9 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
             tileinfo[(mt_begin + mt) * 2] = (int)rmask;
             tileinfo[(mt_begin + mt) * 2 + 1] = rot;
             const int live = __builtin_popcount(mask) * nkc;
+            // a tile without a live K step would never be visited by a range that ends exactly at it, and its outputs (zeros) would
+            // stay unwritten: such packs -- k5 s2 input gradients with unreachable trailing rows -- go to the 64x64 kernel
+            SDT_CHECK_ARG(live > 0, "a tile of this geometry has no live K step");
             if (ntmajor) {
                 tilecum[mt + 1] = live;  // per-m-tile step counts for now: the prefix sums in n-tile-major order follow the loop
             } else {
@@ -1146,15 +1273,18 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
         cp[6] = (int)tile_begin, cp[7] = nmb, cp[8] = (int)row_begin, cp[9] = (int)mt_begin, cp[10] = g.Tw;
         for (int t = 0; t < SDT_MAX_TAPS; ++t) {
             const bool on = t < g.ntaps;
-            cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * 4 : 0;
+            cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * esz : 0;
             cp[11 + SDT_MAX_TAPS + t] = on ? ((g.dy[t] & 0xffff) | (g.dx[t] << 16)) : 0;
-            cp[11 + 2 * SDT_MAX_TAPS + t] = on ? g.wt[t] * g.Cin * 4 : 0;
+            cp[11 + 2 * SDT_MAX_TAPS + t] = on ? g.wt[t] * g.Cin * esz : 0;
         }
         row_begin += (int64_t)nmb * bm;
         mt_begin += nmb;
         tile_begin += (int64_t)nmb * nnb;
     }
-    SDT_CHECK_ARG(S >= 4 * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
+    // every range needs at least one step (an empty range between a tile's owner and its last contributor would be waited for and never
+    // publish); fp32 launches below 4 steps per range go to the 64x64 kernel of conv.hip (faster there, and the B = 4 fixtures keep their
+    // recorded LeakyReLU decisions), bf16 launches have no other kernel and take the persistent one down to one step per range
+    SDT_CHECK_ARG(S >= (esz == 2 ? 1 : 4) * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
     SDT_CHECK_ARG(T < (1ll << 30), "too many tiles");
     // first tile of every range: the tile that contains step floor(r * S / G)
     int64_t tile = 0;
@@ -1163,27 +1293,29 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
         while (tile + 1 < T && tilecum[tile + 1] <= s0) ++tile;
         range_tile[r] = (int)tile;
     }
-    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G | ((kind == 1 ? 0 : g_sk_wpc) << 16), P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
+    // P[3]: grid | workgroups per CU << 16 | (X / W are bf16) << 24 | (Y is bf16) << 25
+    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24) | ((ysz == 2) << 25), P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
     P[10] = (int)o_row, P[11] = (int)o_ti, P[12] = (int)o_cum, P[13] = (int)o_rt, P[14] = (int)o_cls, P[15] = (int)(o_cls + (int64_t)ncls * SK_CLS_INTS);
     return SDT_OK;
 }
 extern "C" int sdt_convsk_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes) {
-    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, 0);
+    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, 4, 4);
 }
-extern "C" int sdt_convtab_plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, void* out, int64_t out_bytes) {
-    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, 1);
+extern "C" int sdt_convsk_plan_build_t(const sdt_conv_geom* geoms, int ncls, int rows_per_group, int bwd_groups, int x_dtype, int y_dtype, void* out,
+                                       int64_t out_bytes) {
+    return plan_build(geoms, ncls, rows_per_group, bwd_groups, out, out_bytes, dtype_bytes(x_dtype), dtype_bytes(y_dtype));
 }
 
-template <int BM, int BN, int EPI, int WPC>
-static void sk_launch(const float* x, const float* w, const float* bias, float* y, const sk_args& A, double* stats, int rpg, const sk_norm_bwd& nb,
+template <typename TX, typename TY, int BM, int BN, int EPI, int WPC>
+static void sk_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, int rpg, const sk_norm_bwd& nb,
                       hipStream_t s) {
     const size_t lds = (size_t)(2 * (BM + BN) * SK_LDP) * 4 + (size_t)BM * 8 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)convsk_kernel<BM, BN, EPI, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)convsk_kernel<TX, TY, BM, BN, EPI, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((convsk_kernel<BM, BN, EPI, WPC>), dim3(A.G), dim3(256), lds, s, x, w, bias, y, A, stats, rpg, nb);
+    hipLaunchKernelGGL((convsk_kernel<TX, TY, BM, BN, EPI, WPC>), dim3(A.G), dim3(256), lds, s, (const TX*)x, (const TX*)w, bias, (TY*)y, A, stats, rpg, nb);
 }
 
 // kernel arguments from a plan blob (host copy: header + class tables; device copy: row / tile tables)
@@ -1214,6 +1346,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
     A.flags = ws ? (unsigned*)(ws + (size_t)512 * (128 * 128) * 4) : nullptr;
     A.err = ws ? A.flags + 512 : nullptr;
     A.epoch = epoch;
+    A.spin_limit = g_sk_spin_limit;
     nb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     if (nbw) {
         SDT_CHECK_ARG(nbw->y && nbw->mean && nbw->rstd && nbw->sums, "null pointer in sdt_norm_bwd");
@@ -1223,14 +1356,17 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
 }
 
 // One launch of the persistent stream-K conv.
-//   plan_host : the blob sdt_convsk_plan_build wrote (host copy: the header and the class tables travel as kernel arguments)
+//   plan_host : the blob sdt_convsk_plan_build(_t) wrote (host copy: the header and the class tables travel as kernel arguments)
 //   plan_dev  : the same blob in device memory (row / tile tables are read from there)
-//   workspace : sdt_convsk_workspace_bytes() bytes, zero-filled once; epoch strictly increasing per workspace, >= 1
+//   workspace : sdt_convsk_workspace_bytes() bytes, zero-filled once.  epoch: any value >= 1 (the flag value of this launch; a flag is lowered
+//               again by the workgroup that consumed it, so every flag is zero between launches and the SAME epoch may be passed every time --
+//               a launch recorded into a hipGraph replays correctly)
 //   stats != NULL: forward statistics as sdt_conv_taps_stats_f32 (plan built with rows_per_group > 0)
 //   nbw   != NULL: normalisation-backward statistics as sdt_conv_taps_multi_f32 (plan built with rows_per_group = -1, bwd_groups)
-extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
-                              void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
-                              int64_t ybytes, void* stream) {
+// Element types of x / w / nbw->y and of y: the ones the plan was built for (sdt_convsk_plan_build: fp32; _t: fp32 or bf16).
+static int sk_go(const void* x, const void* w, const float* bias, void* y, const void* plan_host, const void* plan_dev, void* workspace,
+                 unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream, int want_x,
+                 int want_y) {
     SDT_CHECK_ARG(x && w && y && plan_host && plan_dev && workspace, "null pointer");
     SDT_CHECK_ARG(epoch >= 1, "epoch must be >= 1");
     SDT_CHECK_ARG(!(stats && nbw), "forward and backward statistics are exclusive");
@@ -1243,87 +1379,85 @@ extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias,
     const int bm = P[1], bn = P[2];
     hipStream_t s = (hipStream_t)stream;
     const int epi = stats ? 1 : (nbw ? 2 : 0);
-    const int wpc = P[3] >> 16;  // workgroups per CU the plan was built for (its grid may leave reserved slots free)
+    const int wpc = (P[3] >> 16) & 0xff;  // workgroups per CU the plan was built for (its grid may leave reserved slots free)
+    const int xbf = (P[3] >> 24) & 1, ybf = (P[3] >> 25) & 1;
+    SDT_CHECK_ARG(xbf == want_x && ybf == want_y, "the plan was built for other element types than this entry point's");
     SDT_CHECK_ARG((wpc == 1 || wpc == 2) && A.G > 0 && A.G <= 256 * wpc && A.G % 8 == 0, "plan built for an unknown grid");
-#define SK_GO(BM_, BN_, WPC_)                                                              \
-    do {                                                                                    \
-        if (epi == 0) sk_launch<BM_, BN_, 0, WPC_>(x, w, bias, y, A, stats, 0, nb, s);      \
-        else if (epi == 1) sk_launch<BM_, BN_, 1, WPC_>(x, w, bias, y, A, stats, 0, nb, s); \
-        else sk_launch<BM_, BN_, 2, WPC_>(x, w, bias, y, A, stats, 0, nb, s);               \
+#define SK_GO(TX_, TY_, BM_, BN_, WPC_)                                                              \
+    do {                                                                                              \
+        if (epi == 0) sk_launch<TX_, TY_, BM_, BN_, 0, WPC_>(x, w, bias, y, A, stats, 0, nb, s);      \
+        else if (epi == 1) sk_launch<TX_, TY_, BM_, BN_, 1, WPC_>(x, w, bias, y, A, stats, 0, nb, s); \
+        else sk_launch<TX_, TY_, BM_, BN_, 2, WPC_>(x, w, bias, y, A, stats, 0, nb, s);               \
     } while (0)
-    if (bm == 128 && bn == 128 && wpc == 1) SK_GO(128, 128, 1);
-    else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(128, 128, 2);
-    else if (bm == 256 && bn == 64 && wpc == 1) SK_GO(256, 64, 1);
-    else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(128, 64, 2);
-    else SDT_CHECK_ARG(false, "plan with an unknown tile shape");
+    if (!xbf && !ybf) {
+        if (bm == 128 && bn == 128 && wpc == 1) SK_GO(float, float, 128, 128, 1);
+        else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(float, float, 128, 128, 2);
+        else if (bm == 256 && bn == 64 && wpc == 1) SK_GO(float, float, 256, 64, 1);
+        else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(float, float, 128, 64, 2);
+        else SDT_CHECK_ARG(false, "plan with an unknown tile shape");
+    } else if (xbf && ybf) {
+        if (bm == 128 && bn == 128 && wpc == 2) SK_GO(__bf16, __bf16, 128, 128, 2);
+        else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(__bf16, __bf16, 128, 64, 2);
+        else SDT_CHECK_ARG(false, "plan with a tile shape the bf16 kernels are not built for");
+    } else {
+        SDT_CHECK_ARG(false, "mixed element types (bf16 operands, fp32 output or the reverse) are not built");
+    }
 #undef SK_GO
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
-
-#ifdef SDT_TUNING
-// The 64x64 kernel driven by a plan (sdt_convtab_plan_build): one workgroup per output tile, no workspace.  chunk: 0 = one accumulator over
-// the whole K loop (the summation order of sdt_conv_taps_f32), 8 = accumulation in chunks of 8 K steps (256 products).
-extern "C" int sdt_convtab_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
-                               double* stats, const sdt_norm_bwd* nbw, int chunk, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream) {
-    SDT_CHECK_ARG(x && w && y && plan_host && plan_dev, "null pointer");
-    SDT_CHECK_ARG(!(stats && nbw), "forward and backward statistics are exclusive");
-    SDT_CHECK_ARG(chunk == 0 || chunk == 8, "chunk must be 0 or 8");
-    SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
-    sk_args A;
-    sk_norm_bwd nb;
-    int rc = sk_fill_args(A, nb, plan_host, plan_dev, nullptr, 1, nbw, xbytes, wbytes, ybytes);
-    if (rc) return rc;
-    const int* P = (const int*)plan_host;
-    SDT_CHECK_ARG(P[1] == 64 && P[2] == 64, "not a 64x64 plan");
-    hipStream_t s = (hipStream_t)stream;
-    const int epi = stats ? 1 : (nbw ? 2 : 0);
-    const dim3 grid(A.T), blk(256);
-#define TAB_GO(EPI_)                                                                                                     \
-    do {                                                                                                                  \
-        if (chunk == 0) hipLaunchKernelGGL((conv_tab_kernel<EPI_, 0>), grid, blk, 0, s, x, w, bias, y, A, stats, nb);     \
-        else hipLaunchKernelGGL((conv_tab_kernel<EPI_, 8>), grid, blk, 0, s, x, w, bias, y, A, stats, nb);                \
-    } while (0)
-    if (epi == 0) TAB_GO(0);
-    else if (epi == 1) TAB_GO(1);
-    else TAB_GO(2);
-#undef TAB_GO
-    SDT_LAUNCH_CHECK();
-    return SDT_OK;
+extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias, float* y, const void* plan_host, const void* plan_dev,
+                              void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
+                              int64_t ybytes, void* stream) {
+    return sk_go(x, w, bias, y, plan_host, plan_dev, workspace, epoch, stats, nbw, xbytes, wbytes, ybytes, stream, 0, 0);
 }
-#endif  // SDT_TUNING
+// bf16 tensors (x, w, y, nbw->y), fp32 bias / statistics / accumulation: the bf16-storage path of BASELINE config 4
+extern "C" int sdt_convsk_bf16(const void* x, const void* w, const float* bias, void* y, const void* plan_host, const void* plan_dev,
+                               void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
+                               int64_t ybytes, void* stream) {
+    return sk_go(x, w, bias, y, plan_host, plan_dev, workspace, epoch, stats, nbw, xbytes, wbytes, ybytes, stream, 1, 1);
+}
 
-// ---- weight gradient through the stream-K machinery
-extern "C" int sdt_convsk_dw_supported(const sdt_conv_geom* g) {
-    if (!g) return 0;
+// ---- weight gradient through the stream-K machinery (esz: bytes per element of x / dy: 4 -> convsk_dw_kernel, 32 rows per K step;
+// 2 -> convbf_dw_kernel, 64 rows per K step)
+static int dw_supported(const sdt_conv_geom* g, int esz) {
+    if (!g || (esz != 4 && esz != 2)) return 0;
+    if (esz == 2 && g_sk_wpc != 2) return 0;
     const sdt_conv_geom* gs[1] = {g};
-    if (!sk_supported(gs, 1, 128, 64)) return 0;  // Cin % 32, sizes
+    if (!sk_supported(gs, 1, 128, 64, esz)) return 0;  // Cin, sizes
     if (g->Cout % 64 != 0 || (g->ntaps * g->Cin) % 64 != 0 || g->Cin % 64 != 0 || g->ntaps != g->Tw) return 0;
     if (g->osy != 1 || g->osx != 1 || g->ooy != 0 || g->oox != 0 || g->Hy != g->Ho || g->Wy != g->Wo) return 0;  // dense dY
     for (int t = 0; t < g->ntaps; ++t)
         for (int u = 0; u < t; ++u)
             if (g->wt[t] == g->wt[u]) return 0;
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    const int step = esz == 4 ? 32 : 64;
     const int bm = g->Cout % 128 == 0 ? 128 : 64, bn = (g->ntaps * g->Cin) % 128 == 0 ? 128 : 64;
-    const int64_t K = cdiv64(M, 32), T = (int64_t)(g->Cout / bm) * ((int64_t)g->ntaps * g->Cin / bn);
+    const int64_t K = cdiv64(M, step), T = (int64_t)(g->Cout / bm) * ((int64_t)g->ntaps * g->Cin / bn);
     const int G = 256 * g_sk_wpc - g_sk_reserve;
-    return T <= G && K >= 8 * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 steps each
+    return T <= G && K >= (esz == 4 ? 8 : 4) * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 (4) steps each
 }
-// plan of a weight gradient: header + per-row table of the forward geometry (rows padded to a multiple of 32 + two extra steps)
-extern "C" int64_t sdt_convsk_dw_plan_bytes(const sdt_conv_geom* g) {
-    if (!sdt_convsk_dw_supported(g)) return -1;
+extern "C" int sdt_convsk_dw_supported(const sdt_conv_geom* g) { return dw_supported(g, 4); }
+extern "C" int sdt_convsk_dw_supported_t(const sdt_conv_geom* g, int dtype) { return dw_supported(g, dtype_bytes(dtype)); }
+// plan of a weight gradient: header + per-row table of the forward geometry (rows padded to a multiple of the K step + three extra steps)
+static int64_t dw_plan_bytes(const sdt_conv_geom* g, int esz) {
+    if (!dw_supported(g, esz)) return -1;
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    const int64_t rows = (cdiv64(M, 32) + 3) * 32;
+    const int step = esz == 4 ? 32 : 64;
+    const int64_t rows = (cdiv64(M, step) + 3) * step;
     return (SK_HDR + rows * 4 + SK_CLS_INTS) * 4;
 }
+extern "C" int64_t sdt_convsk_dw_plan_bytes(const sdt_conv_geom* g) { return dw_plan_bytes(g, 4); }
+extern "C" int64_t sdt_convsk_dw_plan_bytes_t(const sdt_conv_geom* g, int dtype) { return dw_plan_bytes(g, dtype_bytes(dtype)); }
 extern "C" int64_t sdt_convsk_dw_workspace_bytes(void) { return (int64_t)512 * 128 * 128 * 4; }
-extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes) {
-    SDT_CHECK_ARG(sdt_convsk_dw_supported(gp), "geometry not supported by the stream-K weight-gradient kernel");
-    SDT_CHECK_ARG(out != nullptr && out_bytes >= sdt_convsk_dw_plan_bytes(gp), "plan buffer too small");
+static int dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes, int esz) {
+    SDT_CHECK_ARG(dw_supported(gp, esz), "geometry not supported by the stream-K weight-gradient kernel");
+    SDT_CHECK_ARG(out != nullptr && out_bytes >= dw_plan_bytes(gp, esz), "plan buffer too small");
     const sdt_conv_geom& g = *gp;
     int* P = (int*)out;
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
-    const int64_t K = cdiv64(M, 32), rows = (K + 3) * 32;
+    const int step = esz == 4 ? 32 : 64;
+    const int64_t K = cdiv64(M, step), rows = (K + 3) * step;
     const int bm = g.Cout % 128 == 0 ? 128 : 64, bn = (g.ntaps * g.Cin) % 128 == 0 ? 128 : 64;
     const int ncol = g.ntaps * g.Cin / bn;
     const int64_t T = (int64_t)(g.Cout / bm) * ncol;
@@ -1341,32 +1475,39 @@ extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int6
         unsigned inval = 0x80000000u;
         for (int t = 0; t < g.ntaps; ++t)
             if (!((unsigned)(iy0 + g.dy[t]) < (unsigned)g.Hi && (unsigned)(ix0 + g.dx[t]) < (unsigned)g.Wi)) inval |= 1u << t;
-        ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * 4));
+        ri[0] = (int)((uint32_t)((((int64_t)b * g.Hi + iy0) * g.Wi + ix0) * g.Cin * esz));
         ri[1] = (int)inval;
-        ri[2] = (int)(m * g.Cout * 4);
+        ri[2] = (int)(m * g.Cout * esz);
         ri[3] = 0;
     }
     int* cp = P + SK_HDR + rows * 4;
-    cp[0] = g.Hi, cp[1] = g.Wi, cp[2] = g.Cin, cp[3] = g.Cout, cp[4] = g.ntaps, cp[5] = g.Cin / SK_BK;
+    cp[0] = g.Hi, cp[1] = g.Wi, cp[2] = g.Cin, cp[3] = g.Cout, cp[4] = g.ntaps, cp[5] = g.Cin * esz / 128;
     cp[6] = 0, cp[7] = 0, cp[8] = 0, cp[9] = 0, cp[10] = g.Tw;
     for (int t = 0; t < SDT_MAX_TAPS; ++t) {
         const bool on = t < g.ntaps;
-        cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * 4 : 0;
+        cp[11 + t] = on ? (g.dy[t] * g.Wi + g.dx[t]) * g.Cin * esz : 0;
         cp[11 + SDT_MAX_TAPS + t] = on ? g.wt[t] : 0;  // the weight-gradient kernels read wt[t] here
         cp[11 + 2 * SDT_MAX_TAPS + t] = 0;
     }
-    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16), P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
+    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24), P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
     P[10] = SK_HDR, P[11] = 0, P[12] = 0, P[13] = 0, P[14] = (int)(SK_HDR + rows * 4), P[15] = (int)(SK_HDR + rows * 4 + SK_CLS_INTS);
     return SDT_OK;
+}
+extern "C" int sdt_convsk_dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes) { return dw_plan_build(gp, out, out_bytes, 4); }
+extern "C" int sdt_convsk_dw_plan_build_t(const sdt_conv_geom* gp, int dtype, void* out, int64_t out_bytes) {
+    return dw_plan_build(gp, out, out_bytes, dtype_bytes(dtype));
 }
 
 // dw (Cout, Tw, Cin) += the weight gradient of the geometry the plan was built for; workspace: sdt_convsk_dw_workspace_bytes() bytes,
 // contents irrelevant (every slab that is read has been written by this launch).  Deterministic: fixed split, fixed summation order.
-extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, const void* plan_host, const void* plan_dev, void* workspace,
-                                 int64_t xbytes, int64_t ybytes, void* stream) {
+static int dw_go(const void* xv, const void* dyv, float* dw, const void* plan_host, const void* plan_dev, void* workspace, int64_t xbytes,
+                 int64_t ybytes, void* stream, int want_bf) {
+    const float* x = (const float*)xv;
+    const float* dy = (const float*)dyv;
     SDT_CHECK_ARG(x && dy && dw && plan_host && plan_dev && workspace, "null pointer");
     const int* P = (const int*)plan_host;
     SDT_CHECK_ARG(P[0] == SK_MAGIC + 1, "not a weight-gradient plan");
+    SDT_CHECK_ARG(((P[3] >> 24) & 1) == want_bf, "the plan was built for another element type than this entry point's");
     SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace | (uintptr_t)plan_dev) % 16) == 0, "operands must be 16-byte aligned");
     SDT_CHECK_ARG(xbytes > 0 && ybytes > 0 && xbytes < (1ll << 31) - 65536 && ybytes < (1ll << 31) - 65536, "tensor sizes out of range");
     sk_args A;
@@ -1395,8 +1536,26 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
         }                                                                                                                      \
         hipLaunchKernelGGL((convsk_dw_kernel<BM_, BN_, WPC_>), dim3(A.G), dim3(256), lds, s, x, dy, A, K, ncol, nchunk, (float*)workspace); \
     } while (0)
-    const int wpc = P[3] >> 16;
-    if (bm == 128 && bn == 128 && wpc == 2) DW_GO(128, 128, 2);
+    const int wpc = (P[3] >> 16) & 0xff;
+    if (want_bf) {
+        const size_t ldsb = (size_t)2 * 64 * (bm + bn) * 2;
+#define DWB_GO(BM_, BN_)                                                                                                       \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)convbf_dw_kernel<BM_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((convbf_dw_kernel<BM_, BN_>), dim3(A.G), dim3(256), ldsb, s, (const __bf16*)xv, (const __bf16*)dyv, A, K, ncol, nchunk, \
+                           (float*)workspace);                                                                                \
+    } while (0)
+        SDT_CHECK_ARG(wpc == 2, "the bf16 weight gradient is built for two workgroups per CU");
+        if (bm == 128 && bn == 128) DWB_GO(128, 128);
+        else if (bm == 128 && bn == 64) DWB_GO(128, 64);
+        else if (bm == 64 && bn == 128) DWB_GO(64, 128);
+        else DWB_GO(64, 64);
+#undef DWB_GO
+    } else if (bm == 128 && bn == 128 && wpc == 2) DW_GO(128, 128, 2);
     else if (bm == 128 && bn == 128) DW_GO(128, 128, 1);
     else if (bm == 128 && bn == 64 && wpc == 2) DW_GO(128, 64, 2);
     else if (bm == 128 && bn == 64) DW_GO(128, 64, 1);
@@ -1408,4 +1567,13 @@ extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, con
     hipLaunchKernelGGL(dw_sk_reduce_kernel, dim3(A.T * (bm * bn / 4 / 256)), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
+}
+extern "C" int sdt_convsk_dw_f32(const float* x, const float* dy, float* dw, const void* plan_host, const void* plan_dev, void* workspace,
+                                 int64_t xbytes, int64_t ybytes, void* stream) {
+    return dw_go(x, dy, dw, plan_host, plan_dev, workspace, xbytes, ybytes, stream, 0);
+}
+// bf16 x / dy, fp32 gradient (ACCUMULATED into dw as above): the bf16-storage path
+extern "C" int sdt_convsk_dw_bf16(const void* x, const void* dy, float* dw, const void* plan_host, const void* plan_dev, void* workspace,
+                                  int64_t xbytes, int64_t ybytes, void* stream) {
+    return dw_go(x, dy, dw, plan_host, plan_dev, workspace, xbytes, ybytes, stream, 1);
 }

@@ -154,18 +154,42 @@ __device__ __forceinline__ f32x4 l0_yhat(const L0Thread& t, const float (&nb)[L0
     return y;
 }
 
+// four consecutive channels as fp32 <-> the tensor's element type (fp32, or bf16 in the bf16-storage path)
+typedef unsigned l0_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 l0_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ f32x4 l0_ld4(const T* __restrict__ p) {
+    if constexpr (sizeof(T) == 4) {
+        return *(const f32x4*)p;
+    } else {
+        const l0_u32x2 w = *(const l0_u32x2*)p;
+        return (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+    }
+}
+template <typename T>
+__device__ __forceinline__ void l0_st4(T* __restrict__ p, const f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        *(f32x4*)p = v;
+    } else {
+        l0_bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+        *(l0_bf16x4*)p = h;
+    }
+}
+
 // grid (H, B): one image row per workgroup; thread = (segment of the row, channel quad): 16 segments x 16 quads
+template <typename TZ>
 __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ mel, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ z, int H, int W, int groups, float slope,
-                                                     __bf16* __restrict__ zp, size_t plane) {
+                                                     TZ* __restrict__ z, int H, int W, int groups, float slope) {
     const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, groups == 1 ? 0 : b, cq);
     const int len = (W + 15) / 16, x0 = seg * len, x1 = min(W, x0 + len);
     if (x0 >= x1) return;
-    float* out = z + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
+    TZ* out = z + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
     L0Window win;
     win.init(mel + (size_t)b * H * W, H, W, y, x0);
     for (int x = x0; x < x1; ++x) {
@@ -174,8 +198,7 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_fwd(yh[e] * t.ga[e] + t.be[e], slope);
-        *(f32x4*)(out + (size_t)x * L0_C) = o;
-        if (zp != nullptr) store_planes4(o, zp + planes_index((size_t)(b * H + y) * W + x, 4 * cq, L0_C));  // exact 3-way bf16 split
+        l0_st4(out + (size_t)x * L0_C, o);
     }
 }
 
@@ -186,7 +209,8 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
 // needs, besides three sums over the gradient, only  sum x_t  and  sum yhat*x_t = rstd*(sum_u w[c][u] R[u][t] - mean*S_t),
 // i.e. the first/second moments of the mel image that the forward pass already computed.
 // sums[g][c][11] doubles (zero on entry).  grid (row chunks, B).
-__global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const float* __restrict__ dz, const float* __restrict__ mel,
+template <typename TZ>
+__global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const TZ* __restrict__ dz, const float* __restrict__ mel,
                                                           const float* __restrict__ w, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, double* __restrict__ sums, int H,
@@ -206,14 +230,14 @@ __global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < L0_NSUM; ++k) acc[e][k] = 0.f;
     for (int y = y_beg; y < y_end && x0 < x1; ++y) {
-        const float* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
+        const TZ* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
         L0Window win;
         win.init(mel + (size_t)b * H * W, H, W, y, x0);
         for (int xb = x0; xb < x1; xb += 4) {  // 4 gradient vectors in flight per thread (HBM latency hiding)
             f32x4 gzv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                gzv[j] = (xb + j < x1) ? *(const f32x4*)(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                gzv[j] = (xb + j < x1) ? l0_ld4(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int x = xb + j;
@@ -303,11 +327,12 @@ __global__ __launch_bounds__(288) void l0_bwd_finalize_kernel(const double* __re
 // ---------------------------------------------------------------------------------------------
 static int l0_ppb(int HW) { return std::max(1024, std::min(4096, cdiv(HW, 8) / 256 * 256)); }  // moments kernel only
 
-extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
-                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                    int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
-                                    float slope, void* z_planes, void* stream) {
+extern "C" int sdt_l0_block_fwd_t(const float* mel, const float* w, void* z, int z_dtype, double* mom, float* mean, float* rstd,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
+                                  float slope, void* stream) {
     SDT_CHECK_ARG(mel && w && z && mom && mean && rstd, "null pointer");
+    SDT_CHECK_ARG(z_dtype == SDT_F32 || z_dtype == SDT_BF16, "unknown element type");
     SDT_CHECK_ARG(B > 0 && H > 0 && W > 0 && (groups == B || groups == 1), "bad dims (groups must be B or 1)");
     SDT_CHECK_ARG((int64_t)B * H * W * L0_C * 4 < (1ll << 40), "tensor too large");
     hipStream_t s = (hipStream_t)stream;
@@ -317,16 +342,26 @@ extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, 
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_finalize_kernel, dim3(cdiv(groups * L0_C, 64)), dim3(64), 0, s, mom, w, mean, rstd, running_mean,
                        running_var, num_batches_tracked, B, groups, n, eps, momentum);
-    hipLaunchKernelGGL(l0_fwd_kernel, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, z, H, W, groups, slope,
-                       (__bf16*)z_planes, (size_t)B * H * W * L0_C);
+    if (z_dtype == SDT_F32)
+        hipLaunchKernelGGL(l0_fwd_kernel<float>, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, (float*)z, H, W, groups, slope);
+    else
+        hipLaunchKernelGGL(l0_fwd_kernel<__bf16>, dim3(H, B), dim3(256), 0, s, mel, w, mean, rstd, gamma, beta, (__bf16*)z, H, W, groups, slope);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
+extern "C" int sdt_l0_block_fwd_f32(const float* mel, const float* w, float* z, double* mom, float* mean, float* rstd,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    int64_t* num_batches_tracked, int B, int H, int W, int groups, float eps, float momentum,
+                                    float slope, void* stream) {
+    return sdt_l0_block_fwd_t(mel, w, z, SDT_F32, mom, mean, rstd, gamma, beta, running_mean, running_var, num_batches_tracked, B, H, W, groups, eps,
+                              momentum, slope, stream);
+}
 
-extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, const double* mom, double* sums, float* dw,
-                                    float* dgamma, float* dbeta, int B, int H, int W, int groups, float slope, void* stream) {
+extern "C" int sdt_l0_block_bwd_t(const void* dz, int dz_dtype, const float* mel, const float* w, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, const double* mom, double* sums, float* dw,
+                                  float* dgamma, float* dbeta, int B, int H, int W, int groups, float slope, void* stream) {
     SDT_CHECK_ARG(dz && mel && w && mean && rstd && mom && sums && dw, "null pointer");
+    SDT_CHECK_ARG(dz_dtype == SDT_F32 || dz_dtype == SDT_BF16, "unknown element type");
     SDT_CHECK_ARG(B > 0 && H > 0 && W > 0 && (groups == B || groups == 1), "bad dims (groups must be B or 1)");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
@@ -334,10 +369,19 @@ extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const flo
     // that push their partial sums through the same global atomics
     const int rpb = std::max(1, (H * B) / 1280);
     dim3 grid(cdiv(H, rpb), B);
-    hipLaunchKernelGGL(l0_bwd_sums_kernel, grid, dim3(256), 0, s, dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
+    if (dz_dtype == SDT_F32)
+        hipLaunchKernelGGL(l0_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
+    else
+        hipLaunchKernelGGL(l0_bwd_sums_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope,
+                           rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_bwd_finalize_kernel, dim3(L0_C), dim3(288), 0, s, sums, mom, w, mean, rstd, gamma, dw, dgamma, dbeta, B,
                        groups, n);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
+}
+extern "C" int sdt_l0_block_bwd_f32(const float* dz, const float* mel, const float* w, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, const double* mom, double* sums, float* dw,
+                                    float* dgamma, float* dbeta, int B, int H, int W, int groups, float slope, void* stream) {
+    return sdt_l0_block_bwd_t(dz, SDT_F32, mel, w, mean, rstd, gamma, beta, mom, sums, dw, dgamma, dbeta, B, H, W, groups, slope, stream);
 }

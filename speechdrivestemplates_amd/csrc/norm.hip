@@ -14,10 +14,35 @@
 #define MAXC 1024
 #define UNR 4  // rows (16-byte vectors) in flight per thread in the streaming passes
 
+// Four consecutive channels of a channels-last tensor as fp32, whatever it is stored as: fp32 (16-byte access) or bf16 (8-byte access; the
+// bf16-storage path keeps the Conv2d chain's activations in HBM as bf16, statistics and arithmetic stay fp32)
+typedef unsigned nm_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 nm_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* __restrict__ p) {
+    if constexpr (sizeof(T) == 4) {
+        return *(const f32x4*)p;
+    } else {
+        const nm_u32x2 w = *(const nm_u32x2*)p;
+        return (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* __restrict__ p, const f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        *(f32x4*)p = v;
+    } else {
+        nm_bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];  // round to nearest even
+        *(nm_bf16x4*)p = h;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-template <bool BWD>
-__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ a,   // fwd: y      bwd: dz
-                                                       const float* __restrict__ y,   // bwd only
+template <bool BWD, typename TA = float, typename TB = float>
+__global__ __launch_bounds__(256) void colstats_kernel(const TA* __restrict__ a,   // fwd: y      bwd: dz
+                                                       const TB* __restrict__ y,   // bwd only
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float slope, double* __restrict__ sums, int64_t R, int C,
@@ -48,8 +73,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
             for (int j = 0; j < UNR; ++j) {
                 const int64_t rj = r + (int64_t)j * rpp;
                 const bool ok = rj < r1;
-                v[j] = ok ? *(const f32x4*)(a + base + (size_t)rj * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (BWD) yv[j] = ok ? *(const f32x4*)(y + base + (size_t)rj * C) : mu;  // masked rows: dz == 0
+                v[j] = ok ? ld4(a + base + (size_t)rj * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (BWD) yv[j] = ok ? ld4(y + base + (size_t)rj * C) : mu;  // masked rows: dz == 0
             }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
@@ -80,14 +105,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __restrict__ y, float* __restrict__ z,
+template <typename TY = float, typename TZ = float>
+__global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const TY* __restrict__ y, TZ* __restrict__ z,
                                                                 const double* __restrict__ sums, float* __restrict__ mean,
                                                                 float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ rmean,
                                                                 float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                                                 int64_t R, int C, int rows_per_block, float eps,
-                                                                float momentum, float slope, __bf16* __restrict__ zp,
-                                                                size_t plane) {
+                                                                float momentum, float slope) {
     const int tid = threadIdx.x, g = blockIdx.y;
     const int tpr = C >> 2, rpp = 256 / tpr;
     const int cv = tid % tpr, rr = tid / tpr;
@@ -128,7 +153,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             const int64_t rj = r + (int64_t)j * rpp;
-            if (rj < r1) v[j] = *(const f32x4*)(y + base + (size_t)rj * C);
+            if (rj < r1) v[j] = ld4(y + base + (size_t)rj * C);
         }
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
@@ -137,8 +162,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const float* __r
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = act_fwd(((v[j][e] - mu[e]) * rs[e]) * ga[e] + be[e], slope);
-                *(f32x4*)(z + base + (size_t)rj * C) = o;
-                if (zp != nullptr) store_planes4(o, zp + planes_index((size_t)g * R + rj, 4 * cv, C));  // exact 3-way bf16 split (presplit.hip)
+                st4(z + base + (size_t)rj * C, o);
             }
         }
     }
@@ -164,13 +188,13 @@ __global__ __launch_bounds__(256) void colnorm_eval_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                                                float* __restrict__ dy, const double* __restrict__ sums,
+template <typename TZ = float, typename TY = float, typename TD = float>
+__global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const TZ* __restrict__ dz, const TY* __restrict__ y,
+                                                                TD* __restrict__ dy, const double* __restrict__ sums,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int64_t R, int C, int rows_per_block, float slope,
-                                                                __bf16* __restrict__ dyp, size_t plane) {
+                                                                int64_t R, int C, int rows_per_block, float slope) {
     const int tid = threadIdx.x, g = blockIdx.y;
     const int tpr = C >> 2, rpp = 256 / tpr;
     const int cv = tid % tpr, rr = tid / tpr;
@@ -199,8 +223,8 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
         for (int j = 0; j < UNR; ++j) {
             const int64_t rj = r + (int64_t)j * rpp;
             if (rj < r1) {
-                gz[j] = *(const f32x4*)(dz + base + (size_t)rj * C);
-                yv[j] = *(const f32x4*)(y + base + (size_t)rj * C);
+                gz[j] = ld4(dz + base + (size_t)rj * C);
+                yv[j] = ld4(y + base + (size_t)rj * C);
             }
         }
 #pragma unroll
@@ -214,8 +238,7 @@ __global__ __launch_bounds__(256) void colnorm_apply_bwd_kernel(const float* __r
                     const float gg = gz[j][e] * act_grad(yh * ga[e] + be[e], slope);
                     o[e] = ga[e] * rs[e] * (gg - mg[e] - yh * mgy[e]);
                 }
-                *(f32x4*)(dy + base + (size_t)rj * C) = o;
-                if (dyp != nullptr) store_planes4(o, dyp + planes_index((size_t)g * R + rj, 4 * cv, C));
+                st4(dy + base + (size_t)rj * C, o);
             }
         }
     }
@@ -327,27 +350,47 @@ static int check_colnorm(int G, int64_t R, int C) {
     return SDT_OK;
 }
 
-extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
-                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                   int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
-                                   float slope, int stats_ready, void* z_planes, void* stream) {
+static bool dtype_ok(int d) { return d == SDT_F32 || d == SDT_BF16; }
+
+// y (y_dtype) -> z (z_dtype); everything else as sdt_colnorm_fwd_f32
+extern "C" int sdt_colnorm_fwd_t(const void* y, int y_dtype, void* z, int z_dtype, double* sums, float* mean, float* rstd,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
+                                 float slope, int stats_ready, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(y && z && sums && mean && rstd, "null pointer");
+    SDT_CHECK_ARG(dtype_ok(y_dtype) && dtype_ok(z_dtype), "unknown element type");
+    SDT_CHECK_ARG(y_dtype == SDT_BF16 || z_dtype == SDT_F32, "fp32 y with a bf16 z is not built");
     hipStream_t s = (hipStream_t)stream;
     if (!stats_ready) {  // otherwise the producing conv's epilogue already accumulated them (sdt_conv_taps_stats_f32)
         const int rps = colnorm_rows_per_block(C, G, R, true);
-        hipLaunchKernelGGL((colstats_kernel<false>), dim3((unsigned)cdiv64(R, rps), G), dim3(256), 0, s, y, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums,
-                           R, C, rps);
+        const dim3 sgrid((unsigned)cdiv64(R, rps), G);
+        if (y_dtype == SDT_F32)
+            hipLaunchKernelGGL((colstats_kernel<false, float, float>), sgrid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rps);
+        else
+            hipLaunchKernelGGL((colstats_kernel<false, __bf16, float>), sgrid, dim3(256), 0, s, (const __bf16*)y, (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, slope, sums, R, C, rps);
     }
     const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    SDT_CHECK_ARG(z_planes == nullptr || ((uintptr_t)z_planes % 8 == 0), "planes must be 8-byte aligned");
-    hipLaunchKernelGGL(colnorm_apply_fwd_kernel, grid, dim3(256), 0, s, y, z, sums, mean, rstd, gamma, beta, running_mean,
-                       running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope, (__bf16*)z_planes, (size_t)G * R * C);
+#define FWD_GO(TY_, TZ_)                                                                                                              \
+    hipLaunchKernelGGL((colnorm_apply_fwd_kernel<TY_, TZ_>), grid, dim3(256), 0, s, (const TY_*)y, (TZ_*)z, sums, mean, rstd, gamma, beta, \
+                       running_mean, running_var, num_batches_tracked, R, C, rpb, eps, momentum, slope)
+    if (y_dtype == SDT_F32) FWD_GO(float, float);
+    else if (z_dtype == SDT_BF16) FWD_GO(__bf16, __bf16);
+    else FWD_GO(__bf16, float);
+#undef FWD_GO
     SDT_LAUNCH_CHECK();
     return SDT_OK;
+}
+extern "C" int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, int G, int64_t R, int C, float eps, float momentum,
+                                   float slope, int stats_ready, void* stream) {
+    return sdt_colnorm_fwd_t(y, SDT_F32, z, SDT_F32, sums, mean, rstd, gamma, beta, running_mean, running_var, num_batches_tracked, G, R, C, eps,
+                             momentum, slope, stats_ready, stream);
 }
 
 extern "C" int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma, const float* beta,
@@ -364,25 +407,44 @@ extern "C" int sdt_colnorm_eval_f32(const float* y, float* z, const float* gamma
     return SDT_OK;
 }
 
-extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
-                                   const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                   int G, int64_t R, int C, float slope, int stats_ready, void* dy_planes, void* stream) {
+// dz (dz_dtype), y (y_dtype) -> dy (dy_dtype); everything else as sdt_colnorm_bwd_f32.  Built: all fp32; y and dy bf16 with dz bf16 or fp32.
+extern "C" int sdt_colnorm_bwd_t(const void* dz, int dz_dtype, const void* y, int y_dtype, void* dy, int dy_dtype, double* sums, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                 int G, int64_t R, int C, float slope, int stats_ready, void* stream) {
     int rc = check_colnorm(G, R, C);
     if (rc) return rc;
     SDT_CHECK_ARG(dz && y && dy && sums && mean && rstd, "null pointer");
     SDT_CHECK_ARG(!(dgamma || dbeta) || G == 1, "affine gradients need G == 1");
+    SDT_CHECK_ARG(dtype_ok(dz_dtype) && dtype_ok(y_dtype) && dtype_ok(dy_dtype), "unknown element type");
+    const bool all32 = dz_dtype == SDT_F32 && y_dtype == SDT_F32 && dy_dtype == SDT_F32;
+    SDT_CHECK_ARG(all32 || (y_dtype == SDT_BF16 && dy_dtype == SDT_BF16), "element type combination not built");
     hipStream_t s = (hipStream_t)stream;
     if (!stats_ready) {
         const int rps = colnorm_rows_per_block(C, G, R, true);
-        hipLaunchKernelGGL((colstats_kernel<true>), dim3((unsigned)cdiv64(R, rps), G), dim3(256), 0, s, dz, y, mean, rstd, gamma,
-                           beta, slope, sums, R, C, rps);
+        const dim3 sgrid((unsigned)cdiv64(R, rps), G);
+#define ST_GO(TA_, TB_) \
+    hipLaunchKernelGGL((colstats_kernel<true, TA_, TB_>), sgrid, dim3(256), 0, s, (const TA_*)dz, (const TB_*)y, mean, rstd, gamma, beta, slope, sums, R, C, rps)
+        if (all32) ST_GO(float, float);
+        else if (dz_dtype == SDT_F32) ST_GO(float, __bf16);
+        else ST_GO(__bf16, __bf16);
+#undef ST_GO
     }
     const int rpb = colnorm_rows_per_block(C, G, R, false);
     dim3 grid((unsigned)cdiv64(R, rpb), G);
-    hipLaunchKernelGGL(colnorm_apply_bwd_kernel, grid, dim3(256), 0, s, dz, y, dy, sums, mean, rstd, gamma, beta, dgamma,
-                       dbeta, R, C, rpb, slope, (__bf16*)dy_planes, (size_t)G * R * C);
+#define BWD_GO(TZ_, TY_, TD_)                                                                                                        \
+    hipLaunchKernelGGL((colnorm_apply_bwd_kernel<TZ_, TY_, TD_>), grid, dim3(256), 0, s, (const TZ_*)dz, (const TY_*)y, (TD_*)dy, sums, mean, rstd, \
+                       gamma, beta, dgamma, dbeta, R, C, rpb, slope)
+    if (all32) BWD_GO(float, float, float);
+    else if (dz_dtype == SDT_F32) BWD_GO(float, __bf16, __bf16);
+    else BWD_GO(__bf16, __bf16, __bf16);
+#undef BWD_GO
     SDT_LAUNCH_CHECK();
     return SDT_OK;
+}
+extern "C" int sdt_colnorm_bwd_f32(const float* dz, const float* y, float* dy, double* sums, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                   int G, int64_t R, int C, float slope, int stats_ready, void* stream) {
+    return sdt_colnorm_bwd_t(dz, SDT_F32, y, SDT_F32, dy, SDT_F32, sums, mean, rstd, gamma, beta, dgamma, dbeta, G, R, C, slope, stats_ready, stream);
 }
 
 template <bool BWD>

@@ -115,11 +115,26 @@ class GradReducer:
             # the exchange's kernels (RCCL: a few dozen workgroups that live for a whole all-reduce) overlap the Conv2d backward, whose
             # persistent stream-K launches would otherwise occupy every workgroup slot of the GPU: leave the collective room (ops.SK_RESERVED_SLOTS)
             from . import ops
+            self._prev_reserve = ops.SK_RESERVED_SLOTS
             ops.SK_RESERVED_SLOTS = RESERVED_SLOTS
         self._pending = []
         # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
         # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide
         self.exposed_events = None
+
+    def close(self):
+        """Give the process-wide plan knob back (a reducer that is torn down must not leave later single-GPU work planning with a reserve)."""
+        prev = getattr(self, "_prev_reserve", None)
+        if prev is not None:
+            from . import ops
+            ops.SK_RESERVED_SLOTS = prev
+            self._prev_reserve = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def exposed_us(self):
         """mean main-stream time per all_reduce() call since ``exposed_events`` was set to a list (None: not recorded)"""

@@ -246,13 +246,12 @@ class NormBwdHolder:
     output, for ONE-consumer chains (the audio encoder): the consumer's input-gradient launch accumulates the statistics the
     normalisation's backward needs in its epilogue (sdt_conv_taps_multi_f32 with sdt_norm_bwd) and leaves them in ``sums``; the
     normalisation's backward then skips its statistics pass over dz and y."""
-    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums", "zp", "dx_id")
+    __slots__ = ("y", "mean", "rstd", "gamma", "beta", "groups", "slope", "sums", "dx_id")
 
     def __init__(self):
         self.y = self.mean = self.rstd = self.gamma = self.beta = self.sums = None
         self.groups, self.slope = 0, 0.0
         self.dx_id = None  # (data_ptr, _version) of the gradient tensor whose launch accumulated ``sums``: see grad_matches()
-        self.zp = None  # bf16 planes [3][numel] of the normalisation's OUTPUT z (pre-split pipeline, presplit.hip)
 
 
 HOLDER_HANDOVERS = {"used": 0, "refused": 0}  # tests: how often a normalisation backward took / refused the fused statistics
@@ -268,20 +267,6 @@ def _holder_grad_matches(h, gz):
     wrote: one consumer, no hook that rescaled / clipped it (a new tensor), no in-place edit (version bump), no autograd accumulation of
     a second consumer's gradient.  Otherwise the statistics pass runs."""
     return h.dx_id is not None and h.dx_id == (gz.data_ptr(), gz._version, tuple(gz.shape))
-
-
-class BlockLink:
-    """Hand-over inside one conv + normalisation block in the pre-split pipeline: the normalisation's backward leaves the bf16
-    planes of dy here for the convolution's backward that autograd runs next."""
-    __slots__ = ("gy_planes",)
-
-    def __init__(self):
-        self.gy_planes = None
-
-
-def planes_like(t):
-    """uninitialised [3][numel] bf16 planes for an fp32 tensor"""
-    return torch.empty((3, t.numel()), device=t.device, dtype=torch.bfloat16)
 
 
 class ConvProfiler:
@@ -365,7 +350,7 @@ def stage_mark(name):
         STAGES.mark(name)
 
 
-def _conv_launch(kind, is2d, g, call, flops=None, name=None):
+def _conv_launch(kind, is2d, g, call, flops=None, name=None, esz=4):
     """``flops``: algorithmic FLOPs of the launch when they are not the geometry's ``2*M*Cout*ntaps*Cin`` (an input-gradient
     class of a valid-correlation layer: the tap table spans input positions no output position reaches; SURVEY.md 8d counts
     dX = forward)."""
@@ -377,8 +362,8 @@ def _conv_launch(kind, is2d, g, call, flops=None, name=None):
     m = g.B * g.Ho * g.Wo
     if flops is None:
         flops = 2.0 * m * g.Cout * g.ntaps * g.Cin
-    # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, fp32
-    nbytes = 4.0 * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
+    # algorithmic bytes of this GEMM: input tensor + output positions x Cout + weights, each once, at the tensors' element size
+    nbytes = float(esz) * (g.B * g.Hi * g.Wi * g.Cin + m * g.Cout + g.Cout * g.ntaps * g.Cin)
     e0, e1 = PROFILER.event(), PROFILER.event()
     e0.record()
     check(call())
@@ -388,7 +373,7 @@ def _conv_launch(kind, is2d, g, call, flops=None, name=None):
     PROFILER.records.append((name or ConvProfiler.kernel_name(kind, var), kind, is2d, flops, nbytes, e0, e1))
 
 
-def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=None, name=None):
+def _conv_launch_multi(kind, is2d, gs, call, extra_bytes=0.0, flops=None, name=None, esz=4):
     """as _conv_launch for a launch that covers several geometries (the parity classes of one input gradient); ``extra_bytes``:
     what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics);
     ``flops``: the algorithmic FLOPs (input gradients pass the FORWARD layer's count, SURVEY.md 8d -- the classes' tap tables
@@ -401,16 +386,16 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=N
     if flops is None:
         flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for g in gs)
     g0 = gs[0]
-    nbytes = 4.0 * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin) + extra_bytes
+    nbytes = float(esz) * (g0.B * g0.Hi * g0.Wi * g0.Cin + g0.B * g0.Hy * g0.Wy * g0.Cout + g0.Cout * g0.Tw * g0.Cin) + extra_bytes
     e0, e1 = PROFILER.event(), PROFILER.event()
     e0.record()
     check(call())
     e1.record()
-    if name is None and not pre and not is2d and _CONV_MATH_NOW[0] == 0:
+    if name is None and not is2d and _CONV_MATH_NOW[0] == 0:
         arr = (ConvGeom * len(gs))(*gs)
         if lib.sdt_conv1d_small_used(arr, len(gs), max(_splitk_hint(lib, g) for g in gs)) == 1:
             name = "conv1d_small_kernel<8>"
-    name = name or ("conv_taps_pre_kernel (bf16x6 products, pre-split operands)" if pre else ConvProfiler.kernel_name(kind, var))
+    name = name or ConvProfiler.kernel_name(kind, var)
     PROFILER.records.append((name, kind, is2d, flops, nbytes, e0, e1))
 
 
@@ -418,29 +403,63 @@ def _conv_launch_multi(kind, is2d, gs, call, pre=False, extra_bytes=0.0, flops=N
 # --------------------------------------------------------------------------------------------
 # persistent stream-K conv (csrc/convsk.hip): plans and workspaces
 # --------------------------------------------------------------------------------------------
-STAGE1D = None        # experiment hook: experimental.stage1d.enable() puts its module here (generator.py asks it)
 USE_STREAMK = True   # the Conv2d forward / input-gradient launches of the audio encoder go through sdt_convsk_f32 (exact fp32 math)
-_SK_PLANS = {}       # (id of the cached geometry object(s), rows_per_group, bwd_groups, device index) -> _SKPlan | None
-_SK_WS = {}          # (device index, raw stream) -> [workspace tensor, epoch]
+_SK_PLANS = {}       # (geometry bytes, rows_per_group, bwd_groups, device index, forward, reserve, dtype, routing knobs) -> _SKPlan | None
+_SK_WS = {}          # (device index, raw stream) -> workspace tensor
+
+# Storage of the Conv2d chain's activations (and of the conv operands' weight copies) in HBM: 'f32' (default: the reference's arithmetic, what
+# the metric is quoted on) or 'bf16' (BASELINE config 4): the first block writes a bf16 tensor and every kernel up to the resize reads / writes
+# bf16 -- products on v_mfma_f32_32x32x16_bf16, fp32 accumulation / statistics / master weights / gradients.  The 1-D stage stays exact fp32.
+STORAGE = "f32"
+
+
+def set_storage(mode):
+    """'f32' | 'bf16'; returns the previous mode.  Takes effect for the next forward pass."""
+    global STORAGE
+    assert mode in ("f32", "bf16"), mode
+    prev, STORAGE = STORAGE, mode
+    return prev
+
+
+def _dt(t):
+    """enum sdt_dtype of a tensor"""
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    raise RuntimeError("unsupported element type %s" % t.dtype)
+
+
+def _geom_key(garr):
+    """The bytes of a geometry (pack): plan caches are keyed on CONTENT, not on the identity of a cached object (VERDICT r3 #14)"""
+    k = getattr(garr, "_key", None)
+    if k is None:
+        k = bytes(garr)
+        try:
+            garr._key = k
+        except AttributeError:
+            pass
+    return k
 
 
 class _SKPlan:
-    """Host + device copy of a stream-K plan (built once per geometry pack; geometries are cached objects, see fwd_geom / dx_pack)."""
-    __slots__ = ("host", "dev", "keep", "kind")
+    """Host + device copy of a stream-K plan (built once per geometry pack and element type)."""
+    __slots__ = ("host", "dev", "kind", "dtype")
 
-    def __init__(self, garr, n, rpg, bwd_groups, dev, kind="sk", reserve=0):
+    def __init__(self, garr, n, rpg, bwd_groups, dev, dtype=0, reserve=0):
         import ctypes as C
         lib = _lib.load()
-        self.kind = kind
-        check(lib.sdt_convsk_set_reserved_slots(int(reserve) if kind == "sk" else 0))  # process-wide knob of the plan builder: set, build, reset
+        self.kind, self.dtype = "sk", dtype
+        check(lib.sdt_convsk_set_reserved_slots(int(reserve)))  # process-wide knob of the plan builder: set, build, reset
         try:
-            nbytes = (lib.sdt_convsk_plan_bytes if kind == "sk" else lib.sdt_convtab_plan_bytes)(garr, n)
+            nbytes = lib.sdt_convsk_plan_bytes_t(garr, n, dtype)
+            if nbytes <= 0:
+                raise RuntimeError("geometry not supported by the stream-K kernel")
             self.host = (C.c_int32 * (nbytes // 4))()
-            check((lib.sdt_convsk_plan_build if kind == "sk" else lib.sdt_convtab_plan_build)(garr, n, int(rpg), int(bwd_groups), C.addressof(self.host), nbytes))
+            check(lib.sdt_convsk_plan_build_t(garr, n, int(rpg), int(bwd_groups), dtype, dtype, C.addressof(self.host), nbytes))
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
-        self.keep = garr  # the key holds id(garr): keep it alive
 
 
 # Which launches take the stream-K kernel (measured per layer on one MI355X, profiles/r03_streamk_ab.txt): it wins where a tile's K loop
@@ -448,6 +467,7 @@ class _SKPlan:
 # tile) and loses on the 64-wide outputs and on the 2x2-tap parity classes of strided input gradients, which stay with the 64x64 kernel.
 # FORWARD launches all take it (where it loses, L4: -3 %, L1 / L2: par): its chunked accumulation is what puts the forward error of
 # every Conv2d layer level with the reference's blocked sums (tests/test_fullsize_gpu.py::test_b32_forward_stage_error_table).
+# bf16 tensors: every launch (there is no other bf16-storage conv kernel).
 # Workgroup slots that the plans of BACKWARD launches (input gradients, weight gradients) leave free.  0 on one GPU.  dp.GradReducer sets it in
 # data-parallel runs: a persistent launch that fills every slot cannot share the GPU with the long-lived workgroups of a collective -- they wait
 # for slots, or take them and strand the conv workgroups that find none (tools/debug/comm_emulation.py) -- and the gradient exchange overlaps backward
@@ -463,32 +483,30 @@ def _sk_wanted(g0, forward=False):
     return g0.Cout % STREAMK_MIN_COUT == 0 and g0.ntaps * (g0.Cin // 32) >= STREAMK_MIN_STEPS
 
 
-USE_TAB = False      # experiment (tuning library only): 2-D launches that do not take the stream-K kernel run the 64x64 kernel with a plan
-TAB_CHUNK = 8        # K steps per accumulation chunk of that kernel (0: one accumulator over the whole K loop)
+def clear_plans():
+    """Drop every cached plan (the caches are keyed on the routing knobs as well, so flipping one never serves a stale plan; this frees memory)"""
+    _SK_PLANS.clear()
+    _SK_DW_PLANS.clear()
 
 
-def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False):
-    """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the plan (stream-K where that kernel is wanted, else the
-    64x64 table-driven kernel's) or None when the pack qualifies for neither."""
-    if torch.cuda.is_current_stream_capturing():
-        return None  # a stream-K launch carries an epoch that must grow from launch to launch: a captured graph would replay one value
+def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0):
+    """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the stream-K plan or None when the pack does not qualify / is not
+    wanted on that kernel (fp32 launches then take the 64x64 kernel of conv.hip)."""
     reserve = 0 if forward else int(SK_RESERVED_SLOTS)
-    key = (id(garr), int(rpg), int(bwd_groups), dev.index, bool(forward), reserve)
+    key = (_geom_key(garr), n, int(rpg), int(bwd_groups), dev.index, bool(forward), reserve, dtype,
+           USE_STREAMK, STREAMK_MIN_STEPS, STREAMK_MIN_COUT, STREAMK_ALL_FORWARD)
     plan = _SK_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
         plan = None
         g0 = garr if isinstance(garr, ConvGeom) else garr[0]
-        kind = "sk" if (USE_STREAMK and lib.sdt_convsk_supported(garr, n) and _sk_wanted(g0, forward)) else (
-            "tab" if (USE_TAB and g0.Hi > 1 and lib.sdt_convtab_supported(garr, n)) else None)
-        if kind is not None:
+        want = lib.sdt_convsk_supported_t(garr, n, dtype) and (dtype == _lib.BF16 or (USE_STREAMK and _sk_wanted(g0, forward)))
+        if want:
             try:
-                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, kind, reserve)
-            except RuntimeError:  # e.g. too few K steps for a 256-way split (the 1-D stage): the 64x64 kernel takes it
+                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, dtype, reserve)
+            except RuntimeError:  # e.g. too few K steps for a 256-way split (the 1-D stage), a tile without a live K step
                 plan = None
         _SK_PLANS[key] = plan
-        if plan is None:
-            _SK_PLANS[("keep", id(garr))] = garr
     return plan
 
 
@@ -497,30 +515,41 @@ def _sk_workspace(dev, st):
     ws = _SK_WS.get(key)
     if ws is None:
         nbytes = _lib.load().sdt_convsk_workspace_bytes()
-        # zero-filled ONCE (flags carry the epoch of the launch that set them); allocated on the launching stream
-        ws = _SK_WS[key] = [torch.zeros(nbytes // 4, device=dev, dtype=torch.int32), 0]
-    ws[1] += 1
-    return ws[0], ws[1]
+        # zero-filled ONCE: every flag a launch raises is lowered again by the workgroup that consumes it
+        ws = _SK_WS[key] = torch.zeros(nbytes // 4, device=dev, dtype=torch.int32)
+    return ws
+
+
+_SK_ERR_WORD = 512 * 128 * 128 + 512
 
 
 def streamk_error_codes():
-    """Non-zero entries: a stream-K launch gave up waiting for a partial tile (tests / bench check this after synchronising)."""
+    """Non-zero entries: the owner of a split tile gave up waiting for a partner's partial sums (the partner was never dispatched -- the GPU is shared
+    with something that holds its slot); that tile was stored as NaN.  Synchronises.  Trainer / bench / tests call this; see check_streamk()."""
     out = {}
-    for key, (ws, _epoch) in _SK_WS.items():
-        code = int(ws[512 * 128 * 128 + 512].item())
+    for key, ws in _SK_WS.items():
+        code = int(ws[_SK_ERR_WORD].item())
         if code:
             out[key] = code
     return out
 
 
+def check_streamk():
+    """Raise if any stream-K launch of this process reported a lost partner (Trainer calls this on log steps and before every checkpoint)."""
+    codes = streamk_error_codes()
+    if codes:
+        raise RuntimeError("a persistent stream-K convolution launch gave up waiting for a partner workgroup (error words %r: range id + 1 per "
+                           "(device, stream)); its output tile was poisoned with NaN.  The GPU is probably shared with another process or a "
+                           "kernel that holds workgroup slots (see ops.SK_RESERVED_SLOTS); results since the last check are invalid" % (codes,))
+
+
 def _sk_launch(plan, x4, ws_w, bias, y, stats, nb, st):
     lib = _lib.load()
-    if plan.kind == "tab":
-        return lib.sdt_convtab_f32(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(stats), nb, TAB_CHUNK,
-                                   x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
-    wsb, epoch = _sk_workspace(y.device, st)
-    return lib.sdt_convsk_f32(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(wsb), epoch, _p(stats), nb,
-                              x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
+    wsb = _sk_workspace(y.device, st)
+    fn = lib.sdt_convsk_bf16 if plan.dtype == _lib.BF16 else lib.sdt_convsk_f32
+    esz = 2 if plan.dtype == _lib.BF16 else 4
+    return fn(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(wsb), 1, _p(stats), nb,
+              x4.numel() * esz, ws_w.numel() * esz, y.numel() * esz, st)
 
 
 _SK_DW_PLANS = {}
@@ -529,37 +558,35 @@ USE_STREAMK_DW = True  # weight gradients of the 2-D layers with Cout % 128 == 0
 
 
 class _SKDwPlan:
-    __slots__ = ("host", "dev", "keep")
+    __slots__ = ("host", "dev", "dtype")
 
-    def __init__(self, g, dev, reserve=0):
+    def __init__(self, g, dev, dtype=0, reserve=0):
         import ctypes as C
         lib = _lib.load()
+        self.dtype = dtype
         check(lib.sdt_convsk_set_reserved_slots(int(reserve)))
         try:
-            nbytes = lib.sdt_convsk_dw_plan_bytes(g)
+            nbytes = lib.sdt_convsk_dw_plan_bytes_t(g, dtype)
             self.host = (C.c_int32 * (nbytes // 4))()
-            check(lib.sdt_convsk_dw_plan_build(g, C.addressof(self.host), nbytes))
+            check(lib.sdt_convsk_dw_plan_build_t(g, dtype, C.addressof(self.host), nbytes))
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
-        self.keep = g
 
 
-def _sk_dw_plan(g, dev):
+def _sk_dw_plan(g, dev, dtype=0):
     reserve = int(SK_RESERVED_SLOTS)
-    key = (id(g), dev.index, reserve)
+    key = (_geom_key(g), dev.index, reserve, dtype)
     plan = _SK_DW_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
         check(lib.sdt_convsk_set_reserved_slots(reserve))  # "supported" depends on the grid (K steps per chunk)
         try:
-            ok = lib.sdt_convsk_dw_supported(g)
+            ok = lib.sdt_convsk_dw_supported_t(g, dtype)
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
-        plan = _SKDwPlan(g, dev, reserve) if ok else None
+        plan = _SKDwPlan(g, dev, dtype, reserve) if ok else None
         _SK_DW_PLANS[key] = plan
-        if plan is None:
-            _SK_DW_PLANS[("keep", id(g))] = g
     return plan
 
 
@@ -572,7 +599,7 @@ def _sk_dw_workspace(dev, st):
 
 
 def _sk_name(plan):
-    return ("convsk_kernel<%d, %d>" if plan.kind == "sk" else "conv_tab_kernel<%d, %d>") % (plan.host[1], plan.host[2])
+    return "convsk_kernel<%d, %d>" % (plan.host[1], plan.host[2])
 
 def _splitk_hint(lib, g):
     k = getattr(g, "_splitk", None)  # geometries are cached objects: ask the library once per geometry
@@ -590,7 +617,7 @@ def conv_forward(x_cl, w, bias, stride, pad):
     ws = weight_storage(w)
     y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
     st = _stream()
-    if (USE_STREAMK or USE_TAB) and w.dim() == 4 and _CONV_MATH_NOW[0] == 0:
+    if USE_STREAMK and w.dim() == 4 and _CONV_MATH_NOW[0] == 0:
         plan = _sk_plan(g, 1, 0, 1, x_cl.device, forward=True)
         if plan is not None:
             _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x4, ws, bias, y, None, None, st), name=_sk_name(plan))
@@ -606,15 +633,6 @@ def conv_forward(x_cl, w, bias, stride, pad):
 
 
 CONV_MATH = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
-# In 'bf16x6' mode the 2-D chain can run on PRE-SPLIT bf16 planes (sdt_conv_taps_pre_f32) that the producing kernels emit.  OFF by
-# default: measured end to end it is SLOWER than splitting inside the conv kernels (4060 vs 4445 clips/s on one box, f32 4000):
-# the pre kernel reaches 120 TFLOP/s in the step against 125 for the split-in-kernel variant, and every normalisation pass writes
-# 1.5x more bytes.  ops.PRESPLIT = True with the tuning library enables it (tests/test_fullsize_gpu.py covers both forms).
-PRESPLIT = False  # experiment (speechdrivestemplates_amd/experimental): needs the -DSDT_TUNING library; no environment switch
-
-
-def presplit_on():
-    return PRESPLIT and _CONV_MATH_NOW[0] == 6 and _lib.has_experimental()
 _CONV_MATH_NOW = [0]  # mirror of the library's process-wide setting (only set_conv_math changes it)
 
 
@@ -639,10 +657,7 @@ class WeightMirrors:
     dirty = True
 
     def __init__(self, params):
-        import ctypes as C
-        self.entries, descs, tiles = [], [], 0
-        pdescs, ptiles = [], 0
-        self.planes_dirty = True
+        self.entries, tiles = [], 0
         for p in params:
             if p.dim() not in (3, 4):
                 continue
@@ -651,27 +666,36 @@ class WeightMirrors:
                 continue  # not in the kernel layout: conv_input_grad transposes it per call
             cout, taps, cin = ws.shape
             wt = torch.empty((cin, taps, cout), device=p.device, dtype=torch.float32)
-            descs.append(_lib.WtDesc(ws.data_ptr(), wt.data_ptr(), cout, taps, cin, tiles))
-            planes = None
-            if PRESPLIT and p.dim() == 4 and cin % 32 == 0 and cout % 32 == 0:  # experiment only: 2-D layers the pre-split conv kernel can take
-                planes = (torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16),
-                          torch.empty((3, cout * taps * cin), device=p.device, dtype=torch.bfloat16))
-                pdescs.append(_lib.WpDesc(ws.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), cout, taps, cin, ptiles))
-                ptiles += ((cin + 31) // 32) * ((cout + 31) // 32) * taps
+            # [parameter, fp32 mirror, version at the last refresh, bf16 copy of W, bf16 copy of the mirror, first tile]
+            self.entries.append([p, wt, -1, None, None, tiles])
             tiles += ((cin + 31) // 32) * ((cout + 31) // 32) * taps
-            self.entries.append([p, wt, -1, planes])
-        self.total_tiles, self.total_ptiles, self.n_planes = tiles, ptiles, len(pdescs)
-        if pdescs:
-            parr = (_lib.WpDesc * len(pdescs))(*pdescs)
-            self.ptable = torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.entries[0][0].device)
-        if descs:
-            arr = (_lib.WtDesc * len(descs))(*descs)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.table = raw.to(self.entries[0][0].device)
+        self.total_tiles = tiles
+        self.table = None
+        if self.entries:
+            if STORAGE == "bf16":
+                self._alloc16()
+            self._build_table()
             import weakref
             me = weakref.ref(self)
             for i, e in enumerate(self.entries):
                 WeightMirrors._by_ptr[e[0].data_ptr()] = (me, i)  # weak: a dead optimiser's mirrors are dropped
+
+    def _alloc16(self):
+        """bf16 copies of the Conv2d weights and of their mirrors (the operands of the bf16-storage path's kernels)"""
+        for e in self.entries:
+            p = e[0]
+            if p.dim() == 4 and e[3] is None:
+                cout, taps, cin = weight_storage(p.data).shape
+                e[3] = torch.empty((cout, taps, cin), device=p.device, dtype=torch.bfloat16)
+                e[4] = torch.empty((cin, taps, cout), device=p.device, dtype=torch.bfloat16)
+
+    def _build_table(self):
+        descs = []
+        for p, wt, _v, w16, wt16, tile0 in self.entries:
+            cout, taps, cin = weight_storage(p.data).shape
+            descs.append(_lib.WtDesc(p.data_ptr(), wt.data_ptr(), _p(w16), _p(wt16), cout, taps, cin, tile0))
+        arr = (_lib.WtDesc * len(descs))(*descs)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.entries[0][0].device)
 
     def refresh(self):
         if not self.entries:
@@ -683,53 +707,53 @@ class WeightMirrors:
 
     def mark_dirty(self):
         self.dirty = True
-        self.planes_dirty = True
-
-    def refresh_planes(self):
-        """bf16 planes of every 2-D weight and of its mirror (pre-split pipeline): one launch per optimiser step, on first use"""
-        if self.n_planes:
-            check(_lib.load().sdt_weight_planes_batched(_p(self.ptable), self.n_planes, self.total_ptiles, _stream()))
-        self.planes_version = [e[0]._version for e in self.entries]
-        self.planes_dirty = False
 
     @staticmethod
-    def lookup_planes(w):
-        """(planes of W, planes of the (Cin,taps,Cout) mirror) or None"""
+    def _entry(w):
         hit = WeightMirrors._by_ptr.get(w.data_ptr())
         if hit is None:
-            return None
-        owner = hit[0]()
-        if owner is None:
-            return None
-        e = owner.entries[hit[1]]
-        if e[3] is None or e[0].data_ptr() != w.data_ptr() or e[0].shape != w.shape:
-            return None
-        if owner.planes_dirty or owner.planes_version[hit[1]] != e[0]._version:
-            owner.refresh_planes()
-        return e[3]
-
-    @staticmethod
-    def lookup(w):
-        hit = WeightMirrors._by_ptr.get(w.data_ptr())
-        if hit is None:
-            return None
+            return None, None
         owner = hit[0]()
         if owner is None:
             del WeightMirrors._by_ptr[w.data_ptr()]
+            return None, None
+        e = owner.entries[hit[1]]
+        if e[0].data_ptr() != w.data_ptr() or e[0].shape != w.shape:
+            return None, None
+        return owner, e
+
+    @staticmethod
+    def lookup(w):
+        owner, e = WeightMirrors._entry(w)
+        if owner is None:
             return None
-        p, wt, version = owner.entries[hit[1]][:3]
-        if p.data_ptr() != w.data_ptr() or p.shape != w.shape:
-            return None
-        if owner.dirty or version != p._version:
+        if owner.dirty or e[2] != e[0]._version:
             owner.refresh()
-        return wt
+        return e[1]
+
+    @staticmethod
+    def lookup16(w):
+        """(bf16 copy of W (Cout,taps,Cin), bf16 copy of its (Cin,taps,Cout) mirror), refreshed with the fp32 mirror by the same launch;
+        None for a weight no optimiser group registered (the caller converts per call)."""
+        owner, e = WeightMirrors._entry(w)
+        if owner is None or e[0].dim() != 4:
+            return None
+        if e[3] is None:  # the storage mode was switched on after this group was built
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("bf16 weight copies must exist before a hipGraph capture (set ops.STORAGE before setup_optimizer)")
+            owner._alloc16()
+            owner._build_table()
+            owner.dirty = True
+        if owner.dirty or e[2] != e[0]._version:
+            owner.refresh()
+        return e[3], e[4]
 
 
 FUSE_DX_CLASSES = True   # one launch for all output parity classes of a strided layer's input gradient (fp32 math)
 FUSE_BWD_STATS = True    # normalisation-backward statistics in the input-gradient epilogue (fp32 math, 2-D chains)
 
 
-def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=None):
+def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None):
     """dX for y = conv(x, w): tap-conv(s) of gy with the transposed weights -- one geometry per output parity class, all
     classes in ONE launch in fp32 math.  ``norm_holder``: the NormBwdHolder of the normalisation that produced x (see there)."""
     lib = _lib.load()
@@ -741,33 +765,20 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
     st = _stream()
     # algorithmic work of an input gradient = the forward layer's: 2 * B*Ho*Wo * Cout * taps * Cin
     fwd_flops = 2.0 * B * (1 if one_d else out_size(Hi, kh, stride, pad)) * out_size(Wi, kw, stride, pad) * Cout * kh * kw * Cin
+    if gy_cl.dtype == torch.bfloat16:
+        dx = None if one_d else _conv_input_grad_bf16(gy4, w, (B, Hi, Wi, Cin), stride, pad, norm_holder, fwd_flops, st)
+        if dx is not None:
+            return dx
+        gy_cl = gy_cl.float()  # no bf16 kernel for this geometry: the fp32 path takes it (and returns an fp32 gradient)
+        gy4 = _as4(gy_cl)
     wt = WeightMirrors.lookup(w)
     if wt is None:
         ws = weight_storage(w)
         wt = torch.empty((Cin, kh * kw, Cout), device=w.device, dtype=torch.float32)
         check(lib.sdt_weight_transpose_f32(_p(ws), _p(wt), Cout, kh * kw, Cin, st))
     dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.float32)
-    if gy_planes is not None and presplit_on() and not one_d and Cout % 32 == 0:
-        # pre-split pipeline: gy arrives as bf16 planes (written by the normalisation backward), the weights' mirror planes are
-        # refreshed once per optimiser step; all parity classes in one launch, backward statistics in the epilogue
-        wpl = WeightMirrors.lookup_planes(w)
-        pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, False)
-        if wpl is not None and pack is not None:
-            arr, n, gs = pack
-            nb = None
-            h = norm_holder
-            if (h is not None and FUSE_BWD_STATS and h.y is not None and tuple(h.y.shape) == tuple(dx.shape)
-                    and all((g.B * g.Ho * g.Wo if h.groups == 1 else g.Ho * g.Wo) >= 128 for g in gs)):
-                h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
-                nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
-                _holder_filled(h, dx)
-            _conv_launch_multi("dX", True, gs,
-                               lambda: lib.sdt_conv_taps_pre_f32(_p(gy_planes), gy_planes.shape[1], _p(wpl[1]), wpl[1].shape[1], _p(dx),
-                                                                 arr, n, None, 0, nb, st), pre=True,
-                               extra_bytes=4.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops)
-            return dx
     pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, one_d) if (FUSE_DX_CLASSES and _CONV_MATH_NOW[0] == 0) else None
-    if pack is not None and (USE_STREAMK or USE_TAB) and not one_d:
+    if pack is not None and USE_STREAMK and not one_d:
         arr, n, gs = pack
         h = norm_holder
         fuse = (h is not None and FUSE_BWD_STATS and h.y is not None and tuple(h.y.shape) == tuple(dx.shape)
@@ -817,9 +828,63 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None, gy_planes=
     return dx.squeeze(1) if one_d else dx
 
 
+def _bf16_weights(w):
+    """(bf16 (Cout,taps,Cin), bf16 (Cin,taps,Cout)) of a Conv2d weight: the optimiser group's refreshed copies, or -- for a weight no group
+    registered -- converted here"""
+    pair = WeightMirrors.lookup16(w)
+    if pair is None:
+        ws = weight_storage(w.detach())
+        pair = (ws.to(torch.bfloat16), ws.permute(2, 1, 0).contiguous().to(torch.bfloat16))
+    return pair
+
+
+def _conv_input_grad_bf16(gy4, w, x_shape, stride, pad, norm_holder, fwd_flops, st):
+    """bf16-storage input gradient of a Conv2d layer (sdt_convsk_bf16): gy bf16 -> dx bf16, all parity classes in one launch, the
+    normalisation-backward statistics in the epilogue when the block below left a bf16 ``y``.  None: geometry not supported."""
+    B, Hi, Wi, Cin = x_shape
+    Cout = w.shape[0]
+    kh, kw = _ksize(w)
+    pack = dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, False)
+    if pack is None:
+        return None
+    arr, n, gs = pack
+    h = norm_holder
+    fuse = (h is not None and FUSE_BWD_STATS and h.y is not None and h.y.dtype == torch.bfloat16 and tuple(h.y.shape) == (B, Hi, Wi, Cin)
+            and all((g.B * g.Ho * g.Wo if h.groups == 1 else g.Ho * g.Wo) >= 32 for g in gs))
+    plan = _sk_plan(arr, n, -1, h.groups if fuse else 1, w.device, dtype=_lib.BF16)
+    if plan is None:
+        return None
+    wt16 = _bf16_weights(w)[1]
+    dx = torch.empty((B, Hi, Wi, Cin), device=w.device, dtype=torch.bfloat16)
+    nb = None
+    if fuse:
+        h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
+        nb = _lib.NormBwd(_p(h.y), _p(h.mean), _p(h.rstd), _p(h.gamma), _p(h.beta), _p(h.sums), float(h.slope), int(h.groups))
+        _holder_filled(h, dx)
+    _conv_launch_multi("dX", True, gs, lambda: _sk_launch(plan, gy4, wt16, None, dx, None, nb, st),
+                       extra_bytes=2.0 * dx.numel() if nb is not None else 0.0, flops=fwd_flops, name=_sk_name(plan) + " bf16", esz=2)
+    return dx
+
+
 def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
     """Accumulate dW into ``w.grad`` (kernel layout)."""
     lib = _lib.load()
+    if x_cl.dtype == torch.bfloat16 or gy_cl.dtype == torch.bfloat16:
+        if x_cl.dtype == gy_cl.dtype and w.dim() == 4:
+            x4 = x_cl
+            g = conv_geom_for(x4.shape, w, stride, pad)
+            plan = _sk_dw_plan(g, x4.device, _lib.BF16)
+            if plan is not None:
+                gw = grad_buffer(w)
+                gws = weight_storage(gw)
+                if gws.data_ptr() != gw.data_ptr():
+                    raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
+                st = _stream()
+                ws = _sk_dw_workspace(x4.device, st)
+                _conv_launch("dW", True, g, lambda: lib.sdt_convsk_dw_bf16(_p(x4), _p(gy_cl), _p(gws), plan.host, _p(plan.dev), _p(ws),
+                                                                           x4.numel() * 2, gy_cl.numel() * 2, st), name="convbf_dw_kernel", esz=2)
+                return
+        x_cl, gy_cl = x_cl.float(), gy_cl.float()  # no bf16 kernel for this layer: fp32 path
     x4, gy4 = _as4(x_cl), _as4(gy_cl)
     g = conv_geom_for(x4.shape, w, stride, pad)
     gw = grad_buffer(w)
@@ -939,21 +1004,23 @@ def side_stream_if_any():
 # autograd's contract: when backward() returns, every .grad is ready on the stream backward ran on.  Weight gradients launched on the side stream
 # (or deferred) break it unless that stream is joined when the backward pass ends: _conv_backward queues ONE engine callback per pass for that.
 # (The train step joined before its optimiser anyway; a stand-alone `loss.backward(); torch_optimizer.step()` on these modules did not.)
-_JOIN_QUEUED = [False]
+_JOIN_QUEUED = [-1]  # id of the backward pass (autograd graph task) whose end-of-pass join has been queued
 
 
 def _end_of_backward():
-    _JOIN_QUEUED[0] = False
     join_side_stream()
 
 
 def _queue_backward_join():
-    if _JOIN_QUEUED[0]:
-        return
+    """One engine callback per backward PASS.  Keyed on the pass's id, not on a flag the callback clears: the engine runs no final callbacks for a
+    pass that raised, and a latched flag would then silently drop the join of every later pass."""
+    tid = torch._C._current_graph_task_id()
+    if tid < 0 or tid == _JOIN_QUEUED[0]:
+        return  # not inside a backward pass (a direct call of the op: the caller joins), or already queued for this pass
     try:
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        _JOIN_QUEUED[0] = True
-    except RuntimeError:  # not inside a backward pass (a direct call of the op): the caller joins
+        _JOIN_QUEUED[0] = tid
+    except RuntimeError:
         pass
 
 
@@ -984,7 +1051,7 @@ class ConvFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
-def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None, gy_planes=None):
+def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None):
     """Weight / bias gradients accumulated into ``.grad``; returns dX (or None)."""
     if w.requires_grad:
         # only launches long enough to pay for the cross-stream events: on the 1-D stage's 10-20 us kernels the
@@ -1006,47 +1073,34 @@ def _conv_backward(x_cl, w, bias, gy, stride, pad, need_dx, in_holder=None, gy_p
     if bias is not None and bias.requires_grad:
         gb = grad_buffer(bias)
         check(_lib.load().sdt_col_sum_f32(_p(gy), _p(gb), gy.numel() // gy.shape[-1], gy.shape[-1], _stream()))
-    return conv_input_grad(gy, w, x_cl.shape, stride, pad, in_holder, gy_planes) if need_dx else None
-
-
-def presplit_usable(x_cl, w, stride, pad, groups, in_holder):
-    """True when a 2-D conv + column-norm block can run its forward conv on pre-split operands: 'bf16x6' math, the producer of
-    x left its bf16 planes in ``in_holder``, the weight has planes, dense geometry with >= 128 rows per statistics group."""
-    if not presplit_on() or in_holder is None or in_holder.zp is None or x_cl.dim() != 4 or w.dim() != 4:
-        return False
-    if x_cl.shape[-1] % 32 or w.shape[0] % 32 or in_holder.zp.shape[1] != x_cl.numel():
-        return False
-    g = conv_geom_for(x_cl.shape, w, stride, pad)
-    m = g.B * g.Ho * g.Wo
-    return m % groups == 0 and m // groups >= 128 and WeightMirrors.lookup_planes(w) is not None
+    return conv_input_grad(gy, w, x_cl.shape, stride, pad, in_holder) if need_dx else None
 
 
 class ConvStatsFn(torch.autograd.Function):
     """Bias-free forward conv whose epilogue also accumulates the per-(group, channel) sum / sum of squares of its output
-    (sdt_conv_taps_stats_f32, or sdt_conv_taps_pre_f32 on pre-split operands) -- the statistics pass of the InstanceNorm2d /
+    (sdt_conv_taps_stats_f32 / the stream-K kernel's EPI 1) -- the statistics pass of the InstanceNorm2d /
     BatchNorm that follows.  Returns (y, sums); ``sums`` goes to ColNormActFn(..., sums).  Use only when ``conv_stats_fusable``
-    or ``presplit_usable`` says so."""
+    says so."""
 
     @staticmethod
-    def forward(ctx, x_cl, w, stride, pad, groups, in_holder=None, link=None):
+    def forward(ctx, x_cl, w, stride, pad, groups, in_holder=None):
         _req_cuda(x_cl, w)
         lib = _lib.load()
-        pre = presplit_usable(x_cl, w, stride, pad, groups, in_holder)
         x_cl = x_cl.contiguous()
-        ctx.in_holder, ctx.link = in_holder, link
+        ctx.in_holder = in_holder
         g = conv_geom_for(x_cl.shape, w, stride, pad)
-        y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
         sums = _ARENA.take(2 * groups * g.Cout, x_cl.device)
         rpg = g.B * g.Ho * g.Wo // groups
-        ws, st = weight_storage(w), _stream()
-        if pre:
-            wpl, xp = WeightMirrors.lookup_planes(w), in_holder.zp
-            _conv_launch_multi("fwd", True, [g],
-                               lambda: lib.sdt_conv_taps_pre_f32(_p(xp), xp.shape[1], _p(wpl[0]), wpl[0].shape[1], _p(y), g, 1, _p(sums),
-                                                                 rpg, None, st), pre=True)
-            in_holder.zp = None  # x has exactly one consumer in this chain: the planes can go back to the allocator
+        st = _stream()
+        if x_cl.dtype == torch.bfloat16:  # bf16-storage path (conv_stats_fusable has checked that the plan exists)
+            y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.bfloat16)
+            w16 = _bf16_weights(w)[0]
+            plan = _sk_plan(g, 1, rpg, 1, x_cl.device, forward=True, dtype=_lib.BF16)
+            _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x_cl, w16, None, y, sums, None, st), name=_sk_name(plan) + " bf16", esz=2)
         else:
-            plan = _sk_plan(g, 1, rpg, 1, x_cl.device, forward=True) if ((USE_STREAMK or USE_TAB) and _CONV_MATH_NOW[0] == 0 and rpg >= 32) else None
+            y = torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x_cl.device, dtype=torch.float32)
+            ws = weight_storage(w)
+            plan = _sk_plan(g, 1, rpg, 1, x_cl.device, forward=True) if (USE_STREAMK and _CONV_MATH_NOW[0] == 0 and rpg >= 32) else None
             if plan is not None:
                 _conv_launch("fwd", True, g, lambda: _sk_launch(plan, x_cl, ws, None, y, sums, None, st), name=_sk_name(plan))
             else:
@@ -1060,11 +1114,8 @@ class ConvStatsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gsums):
         x_cl, w = ctx.saved_tensors
-        gyp = None
-        if ctx.link is not None:
-            gyp, ctx.link.gy_planes = ctx.link.gy_planes, None
-        return (_conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder, gyp),
-                None, None, None, None, None, None)
+        return (_conv_backward(x_cl, w, None, gy.contiguous(), ctx.stride, ctx.pad, ctx.needs_input_grad[0], ctx.in_holder),
+                None, None, None, None, None)
 
 
 def conv_stats_fusable(x_cl, w, stride, pad, groups):
@@ -1073,6 +1124,9 @@ def conv_stats_fusable(x_cl, w, stride, pad, groups):
     if x_cl.dim() != 4 or w.dim() != 4 or PROFILER_NO_FUSION:
         return False
     g = conv_geom_for(x_cl.shape, w, stride, pad)
+    if x_cl.dtype == torch.bfloat16:  # bf16-storage path: the stream-K kernel is the only one, its plan must exist for this geometry
+        m = g.B * g.Ho * g.Wo
+        return m % groups == 0 and m // groups >= 32 and _sk_plan(g, 1, m // groups, 1, x_cl.device, forward=True, dtype=_lib.BF16) is not None
     key = (groups, _CONV_MATH_NOW[0])  # the library's answer depends on the product arithmetic in force
     ok = getattr(g, "_stats_ok", None)
     if ok is None or ok[0] != key:
@@ -1133,27 +1187,26 @@ class ColNormActFn(torch.autograd.Function):
     """InstanceNorm2d (groups = batch) or training-mode BatchNorm (groups = 1) + LeakyReLU/ReLU."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None, holder=None, link=None):
+    def forward(ctx, y, gamma, beta, rmean, rvar, nbt, groups, slope, sums=None, holder=None, out_f32=False):
+        """``y`` fp32 or bf16 (bf16-storage path); ``z`` has y's element type unless ``out_f32`` (the block that feeds the fp32 1-D stage)."""
         _req_cuda(y)
         lib = _lib.load()
         y = y.contiguous()
         C = y.shape[-1]
         R = y.numel() // C // groups
-        z = torch.empty_like(y)
+        z = torch.empty_like(y, dtype=torch.float32) if out_f32 else torch.empty_like(y)
         ready = sums is not None  # accumulated by the producing conv's epilogue (ConvStatsFn)
         if not ready:
             sums = _ARENA.take(2 * groups * C, y.device)
         mean = torch.empty(groups * C, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        # pre-split pipeline: z is also written as bf16 planes for the next block's conv (dropped there after use)
-        zp = planes_like(z) if (holder is not None and presplit_on() and y.dim() == 4 and C % 32 == 0) else None
-        check(lib.sdt_colnorm_fwd_f32(_p(y), _p(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
-                                      _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _p(zp), _stream()))
+        check(lib.sdt_colnorm_fwd_t(_p(y), _dt(y), _p(z), _dt(z), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                                    _p(nbt), groups, R, C, BN_EPS, BN_MOMENTUM, slope, int(ready), _stream()))
         ctx.save_for_backward(y, mean, rstd, gamma, beta)
-        ctx.groups, ctx.slope, ctx.holder, ctx.link = groups, slope, holder, link
+        ctx.groups, ctx.slope, ctx.holder = groups, slope, holder
         if holder is not None:  # what the consuming conv's input-gradient epilogue needs (NormBwdHolder)
             holder.y, holder.mean, holder.rstd, holder.gamma, holder.beta = y, mean, rstd, gamma, beta
-            holder.groups, holder.slope, holder.sums, holder.zp = groups, slope, None, zp
+            holder.groups, holder.slope, holder.sums = groups, slope, None
         return z
 
     @staticmethod
@@ -1163,7 +1216,9 @@ class ColNormActFn(torch.autograd.Function):
         gz = gz.contiguous()
         C = y.shape[-1]
         R = y.numel() // C // ctx.groups
-        dy = torch.empty_like(y)
+        if y.dtype == torch.float32 and gz.dtype != torch.float32:
+            gz = gz.float()  # (an fp32 block after a bf16 one: not a combination the kernels are built for)
+        dy = torch.empty_like(y)  # the element type of y: the conv below reads it with the same type as its saved input
         h = ctx.holder
         # accumulated by the epilogue of the conv that produced gz -- trusted only if gz IS that launch's output tensor
         ready = h is not None and h.sums is not None and _holder_grad_matches(h, gz)
@@ -1174,11 +1229,8 @@ class ColNormActFn(torch.autograd.Function):
             h.sums = h.dx_id = None
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
-        dyp = planes_like(dy) if (ctx.link is not None and presplit_on() and y.dim() == 4 and C % 32 == 0) else None
-        check(lib.sdt_colnorm_bwd_f32(_p(gz), _p(y), _p(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
-                                      ctx.groups, R, C, ctx.slope, int(ready), _p(dyp), _stream()))
-        if ctx.link is not None:
-            ctx.link.gy_planes = dyp  # picked up by the block's conv backward, which autograd runs next
+        check(lib.sdt_colnorm_bwd_t(_p(gz), _dt(gz), _p(y), _dt(y), _p(dy), _dt(dy), _p(sums), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dg), _p(db),
+                                    ctx.groups, R, C, ctx.slope, int(ready), _stream()))
         return dy, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1193,17 +1245,15 @@ class L0BlockFn(torch.autograd.Function):
         mel = mel.contiguous()
         B, H, W = mel.shape
         ws = weight_storage(w)
-        z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.float32)
+        # the first tensor of the bf16-storage path: written as bf16 when ops.STORAGE says so
+        z = torch.empty((B, H, W, 64), device=mel.device, dtype=torch.bfloat16 if STORAGE == "bf16" else torch.float32)
         # zero on entry; read again by this step's backward (an arena slice is not handed out twice within a step, and
         # the arena is only recycled by the next step's begin_step)
         mom = _ARENA.take(54 * B, mel.device)
         mean = torch.empty(groups * 64, device=mel.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        zp = planes_like(z) if (holder is not None and presplit_on()) else None
-        check(lib.sdt_l0_block_fwd_f32(_p(mel), _p(ws), _p(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
-                                       _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _p(zp), _stream()))
-        if holder is not None:
-            holder.zp = zp  # no backward statistics hand-over for this block (its backward is one fused pass)
+        check(lib.sdt_l0_block_fwd_t(_p(mel), _p(ws), _p(z), _dt(z), _p(mom), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rmean),
+                                     _p(rvar), _p(nbt), B, H, W, groups, BN_EPS, BN_MOMENTUM, slope, _stream()))
         ctx.save_for_backward(mel, w, mean, rstd, gamma, beta, mom)
         ctx.groups, ctx.slope = groups, slope
         return z
@@ -1220,8 +1270,8 @@ class L0BlockFn(torch.autograd.Function):
             raise RuntimeError("weight gradient is not in the (Cout,taps,Cin) kernel layout")
         dg = grad_buffer(gamma) if gamma is not None and gamma.requires_grad else None
         db = grad_buffer(beta) if beta is not None and beta.requires_grad else None
-        check(lib.sdt_l0_block_bwd_f32(_p(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mom), _p(sums),
-                                       _p(gw), _p(dg), _p(db), B, H, W, ctx.groups, ctx.slope, _stream()))
+        check(lib.sdt_l0_block_bwd_t(_p(gz), _dt(gz), _p(mel), _p(weight_storage(w)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mom), _p(sums),
+                                     _p(gw), _p(dg), _p(db), B, H, W, ctx.groups, ctx.slope, _stream()))
         return None, None, None, None, None, None, None, None, None, None
 
 

@@ -11,18 +11,18 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
-    config.addinivalue_line("markers", "experimental: covers an experiment that lives in the -DSDT_TUNING library only "
-                                       "(run with SDT_HIP_LIB=speechdrivestemplates_amd/lib/libsdt_hip_tuning.so)")
+    config.addinivalue_line("markers", "tuning: needs the debug / fault-injection hooks of the -DSDT_TUNING library "
+                                       "(python __graft_entry__.py --tuning; SDT_HIP_LIB=speechdrivestemplates_amd/lib/libsdt_hip_tuning.so)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
-        from speechdrivestemplates_amd import experimental
-        if not experimental.available():
-            skip_exp = pytest.mark.skip(reason="experiment: needs the -DSDT_TUNING library (SDT_HIP_LIB=.../libsdt_hip_tuning.so)")
+        from speechdrivestemplates_amd import _lib
+        if not _lib.has_tuning():
+            skip_exp = pytest.mark.skip(reason="needs the -DSDT_TUNING library (SDT_HIP_LIB=.../libsdt_hip_tuning.so)")
             for item in items:
-                if "experimental" in item.keywords:
+                if "tuning" in item.keywords:
                     item.add_marker(skip_exp)
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -1,0 +1,257 @@
+"""The bf16-storage path of BASELINE config 4 (voice2pose_sdt_bp, bf16): activations of the Conv2d chain and the conv operands' weight
+copies live in HBM as bf16, products run on v_mfma_f32_32x32x16_bf16, accumulation / statistics / master weights / gradients are fp32.
+
+The reference has no bf16 mode, so the tolerances are STATED here, per layer of the comparison:
+  * one kernel against float64 on the SAME bf16-rounded operands: the products are exact in fp32, so what remains is the fp32 accumulation
+    (1e-5 of max on the fp32 outputs: weight gradient, statistics) and ONE rounding of the output to bf16 (2^-8 = 3.9e-3 of each element's
+    magnitude -> 5e-3 of max);
+  * the bf16 chain / train step against the fp32 one and against the float64 oracle: the bars of the round-3 operand-rounding mode
+    (prediction 4e-2 of max, losses 2e-2, every gradient tensor within 25 % of its max-norm and cosine >= 0.97), which the storage path
+    has to meet although it rounds the stored activations as well.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sdt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+LAYERS = [  # name, Hi, Wi, Cin, Cout, kh, kw, s, p : the seven Conv2d layers the bf16 kernels serve (generator.py:15-30)
+    ("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1, 1), ("L3", 40, 213, 128, 128, 4, 4, 2, 1),
+    ("L4", 20, 106, 128, 256, 3, 3, 1, 1), ("L5", 20, 106, 256, 256, 4, 4, 2, 1), ("L6", 10, 53, 256, 256, 3, 3, 1, 1),
+    ("L7", 10, 53, 256, 256, 6, 3, 1, 0),
+]
+
+
+@pytest.fixture()
+def ops():
+    from speechdrivestemplates_amd import ops as _ops
+    prev = _ops.STORAGE
+    yield _ops
+    _ops.set_storage(prev)
+    assert not _ops.streamk_error_codes()
+
+
+def relmax(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    assert torch.isfinite(a).all()
+    return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("B", [3, 32])
+@pytest.mark.parametrize("case", LAYERS, ids=[c[0] for c in LAYERS])
+def test_bf16_conv_kernels_vs_float64_on_the_same_operands(ops, case, B):
+    """sdt_convsk_bf16 forward (with the fused forward statistics) and input gradient, sdt_convsk_dw_bf16 (transposing LDS reads) against
+    float64 convolutions of the SAME bf16-rounded tensors."""
+    tag, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    if B == 32 and tag not in ("L1", "L4", "L7"):
+        pytest.skip("full batch on three representative layers (float64 reference time)")
+    g = torch.Generator().manual_seed(77 + Cin + kh + B)
+    x = torch.randn(B, Hi, Wi, Cin, generator=g).to(BF)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(BF).float()  # bf16-representable master weights
+    xd = x.to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w).to(DEV))
+    groups = B
+    assert ops.conv_stats_fusable(xd, wd, s, p, groups), "the bf16 stream-K plan must exist for every encoder layer"
+    yd, sums = ops.ConvStatsFn.apply(xd, wd, s, p, groups, None)
+    assert yd.dtype == BF
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p)
+    e = relmax(yd.float(), yr.permute(0, 2, 3, 1))
+    assert e <= 5e-3, (tag, "forward", e)
+    ref_sums = torch.stack([yr.sum((2, 3)), (yr * yr).sum((2, 3))], -1)  # (B, Cout, 2): taken from the fp32 accumulators, before rounding
+    es = relmax(sums.view(B, Cout, 2), ref_sums)
+    assert es <= 2e-5, (tag, "statistics", es)
+    gy = torch.randn(yd.shape, generator=g).to(BF)
+    gyd = gy.to(DEV)
+    dxd = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
+    assert dxd.dtype == BF
+    ops.conv_weight_grad(xd, gyd, wd, s, p)
+    torch.cuda.synchronize()
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    edx = relmax(dxd.float(), xr.grad.permute(0, 2, 3, 1))
+    edw = relmax(wd.grad, wr.grad)
+    print("  %s B=%d bf16 kernels vs float64 on the same operands: fwd %.2e (stats %.1e)  dX %.2e  dW %.2e" % (tag, B, e, es, edx, edw))
+    assert edx <= 5e-3, (tag, "dX", edx)
+    assert edw <= 2e-5, (tag, "dW", edw)
+
+
+@pytest.mark.parametrize("norm", ["IN", "BN"])
+def test_bf16_input_gradient_with_backward_statistics(ops, norm):
+    """EPI 2 on bf16 tensors: the input-gradient launch of a block also accumulates sum g, sum g*yhat of the normalisation below from the bf16
+    forward output it reads back -- against float64 on the same rounded tensors."""
+    from speechdrivestemplates_amd import _lib
+    B, Hi, Wi, Cin, Cout, k, s, p = 3, 20, 53, 128, 256, 3, 1, 1
+    g = torch.Generator().manual_seed(5)
+    groups = B if norm == "IN" else 1
+    ybelow = torch.randn(B, Hi, Wi, Cin, generator=g).to(BF)      # raw conv output of the block below
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(BF).float()
+    gy = torch.randn(B, Hi, Wi, Cout, generator=g).to(BF)
+    yb = ybelow.double()
+    dims = (1, 2) if norm == "IN" else (0, 1, 2)
+    mean = yb.mean(dims, keepdim=True)
+    rstd = 1.0 / torch.sqrt(yb.var(dims, unbiased=False, keepdim=True) + 1e-5)
+    h = ops.NormBwdHolder()
+    h.y = ybelow.to(DEV)
+    h.mean = mean.reshape(-1).float().to(DEV)
+    h.rstd = rstd.reshape(-1).float().to(DEV)
+    h.groups, h.slope = groups, 0.2
+    wd = torch.nn.Parameter(ops.to_weight_layout(w).to(DEV))
+    dx = ops.conv_input_grad(gy.to(DEV), wd, (B, Hi, Wi, Cin), s, p, h)
+    torch.cuda.synchronize()
+    assert h.sums is not None and dx.dtype == BF
+    dxr = F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), w.double(), None, s, p).permute(0, 2, 3, 1)
+    assert relmax(dx.float(), dxr) <= 5e-3
+    yh = (yb - mean) * rstd
+    gg = dxr * torch.where(yh > 0, 1.0, 0.2)
+    ref = torch.stack([gg.sum(dims), (gg * yh).sum(dims)], -1).reshape(groups, Cin, 2)
+    e = relmax(h.sums.view(groups, Cin, 2), ref)
+    print("  bf16 EPI 2 (%s): sums vs float64 %.2e" % (norm, e))
+    assert e <= 1e-4, e
+    assert _lib.BF16 == 1
+
+
+def test_bf16_norm_and_first_block_io(ops):
+    """sdt_colnorm_{fwd,bwd}_t and sdt_l0_block_{fwd,bwd}_t with bf16 tensors against the fp32 kernels on the same (rounded) inputs:
+    identical arithmetic, the only difference is the final rounding of what is stored (2^-8 relative)."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C = 3, 20, 53, 128
+    y = torch.randn(B, H, W, C, generator=g).to(BF).to(DEV)
+    gz = torch.randn(B, H, W, C, generator=g).to(BF).to(DEV)
+    outs = {}
+    for dt in (torch.float32, BF):
+        yin = y.to(dt).requires_grad_(True)
+        z = ops.ColNormActFn.apply(yin, None, None, None, None, None, B, 0.2, None, None)
+        assert z.dtype == dt
+        z.backward(gz.to(dt))
+        torch.cuda.synchronize()
+        outs[dt] = (z.detach().float(), yin.grad.detach().float())
+    assert relmax(outs[BF][0], outs[torch.float32][0]) <= 5e-3
+    assert relmax(outs[BF][1], outs[torch.float32][1]) <= 5e-3
+    zf = ops.ColNormActFn.apply(y, None, None, None, None, None, B, 0.2, None, None, True)  # bf16 in, fp32 out (the block before the 1-D stage)
+    assert zf.dtype == torch.float32 and relmax(zf, outs[torch.float32][0]) <= 1e-6
+    # first block: fp32 mel -> bf16 z; backward reads a bf16 gradient
+    mel = (torch.rand(B, 80, 427, generator=g) * 3.0).to(DEV)
+    w0 = (torch.randn(64, 1, 3, 3, generator=g) * 0.3)
+    gz0 = torch.randn(B, 80, 427, 64, generator=g).to(BF).to(DEV)
+    res = {}
+    for mode in ("f32", "bf16"):
+        ops.set_storage(mode)
+        wd = torch.nn.Parameter(ops.to_weight_layout(w0).to(DEV))
+        z0 = ops.L0BlockFn.apply(mel, wd, None, None, None, None, None, B, 0.2, None)
+        assert z0.dtype == (BF if mode == "bf16" else torch.float32)
+        z0.backward(gz0.to(z0.dtype))
+        torch.cuda.synchronize()
+        res[mode] = (z0.detach().float(), wd.grad.detach().clone())
+    ops.set_storage("f32")
+    assert relmax(res["bf16"][0], res["f32"][0]) <= 5e-3
+    assert relmax(res["bf16"][1], res["f32"][1]) <= 1e-5  # the same bf16 gradient values went in: the weight gradient is fp32 arithmetic either way
+
+
+def test_bf16_encoder_chain_follows_the_fp32_chain(ops):
+    """The audio encoder (8 blocks) in bf16 storage against the same weights in fp32 storage: output and every weight gradient."""
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.networks.keypoints_generation.generator import AudioEncoder
+    from speechdrivestemplates_amd.optim import FlatAdam
+    cfg = get_cfg_defaults()
+    torch.manual_seed(3)
+    enc = AudioEncoder(cfg).to(DEV).train()
+    opt = FlatAdam(list(enc.parameters()))  # owns the weight mirrors and their bf16 copies
+    g = torch.Generator().manual_seed(4)
+    B = 4
+    mel = (torch.rand(B, 80, 427, generator=g) ** 4 * 20.0).to(DEV)
+    gout = torch.randn(B, 5, 51, 256, generator=g).to(DEV)
+    res = {}
+    for mode in ("f32", "bf16"):
+        ops.set_storage(mode)
+        opt.zero_grad()
+        out = enc.encode_cl(mel)
+        assert out.dtype == torch.float32
+        out.backward(gout)
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in enc.named_parameters()})
+    ops.set_storage("f32")
+    e = relmax(res["bf16"][0], res["f32"][0])
+    rows = []
+    for k, ref in res["f32"][1].items():
+        got = res["bf16"][1][k]
+        cos = F.cosine_similarity(got.double().reshape(1, -1), ref.double().reshape(1, -1)).item()
+        rows.append((k, relmax(got, ref), cos))
+    print("  encoder bf16 vs fp32 storage: output %.2e; gradients worst rel %.2e, worst cosine %.5f"
+          % (e, max(r[1] for r in rows), min(r[2] for r in rows)))
+    assert e <= 4e-2, e
+    assert max(r[1] for r in rows) <= 0.25 and min(r[2] for r in rows) >= 0.97, rows
+
+
+def test_b32_bf16_storage_vs_oracle(ops):
+    """BASELINE config 4 at 32 clips per GPU: one forward + backward in bf16 storage against the float64 oracle (evaluated at the run's own L1
+    sign decisions), at the stated bf16 bars: prediction 4e-2 of max, losses 2e-2, every gradient tensor within 25 % of its max-norm and
+    with cosine similarity >= 0.97 to the float64 gradient."""
+    from test_fullsize_gpu import N_CLIPS, _dump, _oracle_grads
+    from test_model_gpu import _make_pipeline
+    B, cfg_name = 32, "voice2pose_sdt_bp"
+    ocfg = O.cfg_named(cfg_name)
+    state = O.make_voice2pose_state(ocfg, N_CLIPS, seed=0, code_std=0.5)
+    batch = O.make_batch(B, N_CLIPS, step=3, seed=11)
+    ops.set_storage("bf16")
+    try:
+        pipe, _ = _make_pipeline(cfg_name, N_CLIPS, 0.5)
+        losses, results = pipe.forward_backward(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_storage("f32")
+    grads_hip = {k: p.grad.detach().double().cpu() for k, p in pipe.model.named_parameters() if p.grad is not None}
+    s_hip = torch.sign(results["poses_pred_normalized"].detach().cpu() - batch["poses"])
+    l64, p64, g64 = _oracle_grads(cfg_name, state, batch, torch.float64, l1_signs=s_hip)
+    e = relmax(results["poses_pred_normalized"], p64)
+    rows = []
+    for k, ref in g64.items():
+        got = grads_hip[k]
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        cos = (F.cosine_similarity(got.reshape(1, -1), ref.reshape(1, -1)).item()) if ref.numel() > 1 else 1.0
+        rows.append((k, rel, cos))
+    lines = ["voice2pose_sdt_bp B=32 (bf16 STORAGE) vs float64 oracle: prediction rel-max-err %.3e; losses %s" % (
+        e, {k: "%.2e" % abs(float(losses[k].detach()) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
+    lines += ["      %-60s rel-max-err %.3e  cosine %.5f" % r for r in rows]
+    _dump(lines)
+    assert e <= 4e-2, e
+    for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss"):
+        a, b = float(losses[k]), float(l64[k])
+        assert abs(a - b) <= 2e-2 * abs(b), (k, a, b)
+    worst_rel, worst_cos = max(r[1] for r in rows), min(r[2] for r in rows)
+    print("  bf16 storage B=32: worst gradient rel-max-err %.3e, worst cosine %.5f" % (worst_rel, worst_cos))
+    assert worst_rel <= 0.25 and worst_cos >= 0.97, [r for r in rows if r[1] > 0.25 or r[2] < 0.97]
+
+
+def test_bf16_storage_train_steps_track_the_fp32_run(ops):
+    """Three train steps (forward, backward, Adam) in bf16 storage stay within 2 % of the fp32 run's losses, repeat bit-identically, and leave
+    no stream-K error word."""
+    from test_model_gpu import _make_pipeline
+    hist = {}
+    for mode in ("f32", "bf16", "bf16"):
+        ops.set_storage(mode)
+        try:
+            pipe, _ = _make_pipeline("voice2pose_sdt_bp", 64, 0.5)
+            h = []
+            for step in range(3):
+                batch = O.make_batch(8, 64, step=step, seed=1)
+                losses, _ = pipe.forward_backward(batch)
+                pipe.optimizer_updates(losses)
+                torch.cuda.synchronize()
+                h.append((float(losses["G_loss"]), float(losses["G_reg_loss"])))
+            w = pipe.model.netG.audio_encoder.specgram_encoder_2d[2][0].conv.weight.detach().clone()
+        finally:
+            ops.set_storage("f32")
+        hist.setdefault(mode, []).append((h, w))
+    (hf, _), = hist["f32"]
+    (h1, w1), (h2, w2) = hist["bf16"]
+    for (a, b), (c, d) in zip(hf, h1):
+        assert abs(a - c) <= 2e-2 * abs(a) and abs(b - d) <= 2e-2 * abs(b), (hf, h1)
+    assert h1 == h2 and torch.equal(w1, w2), "the bf16-storage path is not run-to-run deterministic"

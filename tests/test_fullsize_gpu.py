@@ -247,20 +247,11 @@ def test_b32_bf16_mode_vs_oracle():
     assert worst_rel <= 0.25 and worst_cos >= 0.97, [r for r in rows if r[1] > 0.25 or r[2] < 0.97]
 
 
-@pytest.mark.parametrize("presplit", [False, pytest.param(True, marks=pytest.mark.experimental)], ids=["split-in-kernel", "pre-split-planes"])
-def test_b32_bf16x6_mode_meets_the_fp32_bar(presplit):
-    """'bf16x6' (operands split exactly into three bf16 pieces, six MFMA products, fp32 accumulation) claims fp32-equivalent
-    products: at B=32 it has to pass the SAME float64-calibrated checks as the exact-fp32 MFMA path -- in both of its forms, the
-    split inside the conv kernels (the faster one end to end, what `--conv-math bf16x6` runs) and the pre-split operand pipeline
-    (ops.PRESPLIT, an experiment carried by the -DSDT_TUNING library only)."""
-    from speechdrivestemplates_amd import ops
-    prev = ops.PRESPLIT
-    ops.PRESPLIT = presplit
-    try:
-        r = _b32_run("voice2pose_sdt_bp", 0.5, conv_math="bf16x6")
-    finally:
-        ops.PRESPLIT = prev
-    _b32_check("voice2pose_sdt_bp B=32 (bf16x6 products, %s) vs float64 oracle" % ("pre-split planes" if presplit else "split in kernel"), r)
+def test_b32_bf16x6_mode_meets_the_fp32_bar():
+    """'bf16x6' (operands split exactly into three bf16 pieces inside the conv kernels, six MFMA products, fp32 accumulation) claims
+    fp32-equivalent products: at B=32 it has to pass the SAME float64-calibrated checks as the exact-fp32 MFMA path."""
+    r = _b32_run("voice2pose_sdt_bp", 0.5, conv_math="bf16x6")
+    _b32_check("voice2pose_sdt_bp B=32 (bf16x6 products, split in kernel) vs float64 oracle", r)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

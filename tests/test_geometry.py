@@ -151,24 +151,17 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
     extra = {"sdt_last_error", "sdt_abi_version", "sdt_get_conv_math", "sdt_conv_dw_workspace_bytes", "sdt_convsk_plan_bytes",
-             "sdt_convsk_workspace_bytes", "sdt_convsk_dw_plan_bytes", "sdt_convsk_dw_workspace_bytes"}
-    declared |= set(re.findall(r"^\s*int64_t\s+(sdt_\w+)\s*\(", hdr, flags=re.M))
+             "sdt_convsk_workspace_bytes", "sdt_convsk_dw_plan_bytes", "sdt_convsk_dw_workspace_bytes", "sdt_convsk_plan_bytes_t",
+             "sdt_convsk_dw_plan_bytes_t", "sdt_convsk_get_spin_limit"}
+    declared |= set(re.findall(r"^\s*(?:int64_t|unsigned)\s+(sdt_\w+)\s*\(", hdr, flags=re.M))
     for name in sorted(declared):
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
     assert declared - extra == set(_lib.SIGNATURES), "ctypes signatures out of sync with the header: %s" % ((declared - extra) ^ set(_lib.SIGNATURES))
-    assert _lib.load().sdt_abi_version() == 1
-    # the experiments' header is matched by the tuning library (when it has been built) and by nothing in the product library
-    ehdr = open(os.path.join(REPO, "include", "sdt_hip_experimental.h")).read()
-    edecl = set(re.findall(r"^\s*int\s+(sdt_\w+)\s*\(", ehdr, flags=re.M))
-    assert edecl == set(_lib.EXPERIMENTAL_SIGNATURES), edecl ^ set(_lib.EXPERIMENTAL_SIGNATURES)
+    assert _lib.load().sdt_abi_version() == _lib.ABI_VERSION == 2
+    # the debug / fault-injection hooks live in the -DSDT_TUNING library only
     product = ctypes.CDLL(os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip.so"))
-    for name in sorted(edecl):
-        assert not hasattr(product, name), "the product library exports the experiment %s" % name
-    tuning = os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
-    if os.path.exists(tuning):
-        tl = ctypes.CDLL(tuning)
-        for name in sorted(edecl | declared):
-            assert hasattr(tl, name), "libsdt_hip_tuning.so does not export %s" % name
+    for name in ("sdt_debug_convsk_mute_range", "sdt_debug_set_timeline_sk", "sdt_debug_spin"):
+        assert not hasattr(product, name), "the product library exports the debug hook %s" % name
 
 
 def test_ops_refuse_cpu_tensors():

@@ -622,7 +622,7 @@ assert err < 3e-6, err
         assert out.returncode == 0, (var, out.stdout[-2000:], out.stderr[-2000:])
     # no experiment switch is compiled into the product library or read by the package
     blob = open(os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip.so"), "rb").read()
-    for needle in (b"SDT_CONV_PRIO", b"SDT_CONV_TILE", b"SDT_STAGE1D", b"SDT_PRESPLIT", b"c1d_kernel", b"conv_taps_pre_kernel", b"conv_tab_kernel"):
+    for needle in (b"SDT_CONV_PRIO", b"SDT_CONV_TILE", b"SDT_STAGE1D", b"SDT_PRESPLIT", b"c1d_kernel", b"conv_taps_pre_kernel", b"conv_tab_kernel", b"sk_dbg_mute"):
         assert needle not in blob, needle
     pkg = os.path.join(REPO, "speechdrivestemplates_amd")
     for root, _dirs, files in os.walk(pkg):
@@ -706,141 +706,6 @@ def test_fused_dx_classes_and_backward_statistics(ops, norm, stride):
     check("chain dX vs float64", res[True][0], xr.grad.permute(0, 2, 3, 1), 2e-4)
     for got, ref in zip(res[True][1:], [p.grad for p in p1 + p2]):
         check("chain parameter gradient vs float64", got, ref, 5e-4)
-
-
-def _planes(ops, t):
-    from speechdrivestemplates_amd import _lib
-    t = t.contiguous()
-    p = ops.planes_like(t)
-    _lib.check(_lib.load().sdt_split_planes_f32(t.data_ptr(), p.data_ptr(), t.numel(), t.shape[-1], torch.cuda.current_stream().cuda_stream))
-    return p
-
-
-@pytest.mark.experimental
-def test_presplit_planes_are_an_exact_split(ops):
-    """x = x1 + x2 + x3 exactly (three bf16 pieces by truncation) for every NORMAL fp32 value whose third piece stays normal
-    (|x| >= 2^-110); below that the residuals underflow -- the kernels run with the hardware's flush of fp32 subnormal results --
-    and the split degrades gracefully to fewer pieces (activations and weights of this network never get there)."""
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(4096, generator=g) * torch.tensor([1e-20, 1e-3, 1.0, 1e6]).repeat_interleave(1024)
-    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -100 * 1.2345678, 65504.0, 1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -23)])
-    x2 = x.reshape(32, 128)  # (rows, C): pieces of element (row, c) sit at row*3C + (c/32)*96 + piece*32 + c%32
-    p = _planes(ops, x2.to(DEV)).float().cpu().reshape(32, 4, 3, 32).permute(2, 0, 1, 3).reshape(3, -1)
-    tot = (p[0].double() + p[1].double() + p[2].double()).float()
-    bad = (tot != x).nonzero().flatten()[:8].tolist()
-    assert not bad, [(i, x[i].item(), p[0][i].item(), p[1][i].item(), p[2][i].item()) for i in bad]
-    assert torch.equal(p[0] + (p[1] + p[2]), x)  # the pieces do not overlap: any fp32 summation order recovers x
-
-
-@pytest.mark.experimental
-@pytest.mark.parametrize("tile", [64064, 128064, 128128, 1281288, 1282568])
-@pytest.mark.parametrize("case", [("k3 s1", 3, 20, 53, 128, 256, 3, 3, 1, 1), ("k4 s2", 2, 21, 40, 64, 128, 4, 4, 2, 1),
-                                  ("k(6,3) p0", 2, 10, 53, 256, 256, 6, 3, 1, 0)], ids=lambda c: c[0])
-def test_presplit_conv_vs_float64(ops, case, tile):
-    """sdt_conv_taps_pre_f32 (bf16 MFMA, six products per fp32 product, operands pre-split into bf16 planes): forward with the
-    fused forward statistics and the multi-class input gradient, against float64 -- at the tolerance of the exact-fp32 kernels."""
-    from speechdrivestemplates_amd import _lib
-    lib = _lib.load()
-    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
-    g = torch.Generator().manual_seed(31 + Cin + kh)
-    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
-    w = torch.randn(Cout, Cin, kh, kw, generator=g, dtype=torch.float64) * (2.0 / (Cin * kh * kw)) ** 0.5
-    xr = x.clone().requires_grad_(True)
-    y = F.conv2d(xr, w, None, s, p)
-    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
-    y.backward(gy)
-    xd = ops.cl(x.float()).to(DEV)
-    ws = ops.weight_storage(ops.to_weight_layout(w.float()).to(DEV))          # (Cout, taps, Cin)
-    wt = ws.permute(2, 1, 0).contiguous()                                     # (Cin, taps, Cout)
-    xp, wp, wtp = _planes(ops, xd), _planes(ops, ws), _planes(ops, wt)
-    st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.sdt_set_pre_tile(tile))
-    try:
-        geo = ops.fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p)
-        yd = torch.empty((B, geo.Ho, geo.Wo, Cout), device=DEV)
-        rows = geo.Ho * geo.Wo
-        stats = torch.zeros(2 * B * Cout, device=DEV, dtype=torch.float64) if rows >= 128 else None
-        _lib.check(lib.sdt_conv_taps_pre_f32(xp.data_ptr(), xp.shape[1], wp.data_ptr(), wp.shape[1], yd.data_ptr(), geo, 1,
-                                             None if stats is None else stats.data_ptr(), rows, None, st))
-        check(tag + " pre fwd", ops.cf_view(yd), y, 3e-6)
-        if stats is not None:
-            ref = torch.stack([y.sum((2, 3)), (y * y).sum((2, 3))], -1)  # (B, Cout, 2)
-            check(tag + " pre fwd statistics", stats.view(B, Cout, 2), ref, 1e-5)
-        gyd = ops.cl(gy.float()).to(DEV)
-        gyp = _planes(ops, gyd)
-        arr, n, gs = ops.dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, s, p, False)
-        dxd = torch.empty((B, Hi, Wi, Cin), device=DEV)
-        _lib.check(lib.sdt_conv_taps_pre_f32(gyp.data_ptr(), gyp.shape[1], wtp.data_ptr(), wtp.shape[1], dxd.data_ptr(), arr, n, None, 0, None, st))
-        check(tag + " pre dX (%d classes, one launch)" % n, ops.cf_view(dxd), xr.grad, 3e-6)
-    finally:
-        _lib.check(lib.sdt_set_pre_tile(0))
-
-
-@pytest.mark.experimental
-@pytest.mark.parametrize("norm", ["IN", "BN"])
-def test_presplit_chain_matches_float64(ops, norm):
-    """Two ConvNormRelu blocks in 'bf16x6' math with the pre-split hand-over (planes of z from the normalisation forward, planes of
-    dy from its backward, weight planes from the optimiser's mirrors): gradients against float64 autograd at fp32 tolerances, and
-    the pre-split kernels really ran."""
-    from speechdrivestemplates_amd import _lib
-    from speechdrivestemplates_amd.core.networks.building_blocks import ConvNormRelu
-    from speechdrivestemplates_amd.optim import FlatAdam
-    torch.manual_seed(4)
-    B, H, W = 3, 22, 51
-    blk1 = ConvNormRelu('2d', 32, 64, downsample=False, norm=norm, leaky=True).to(DEV).train()
-    blk2 = ConvNormRelu('2d', 64, 64, downsample=True, norm=norm, leaky=True).to(DEV).train()
-    blk3 = ConvNormRelu('2d', 64, 32, downsample=False, norm=norm, leaky=True).to(DEV).train()
-    x = torch.randn(B, H, W, 32, device=DEV)
-    calls = []
-    lib = _lib.load()
-    orig = lib.sdt_conv_taps_pre_f32
-
-    class Spy:
-        def __call__(self, *a):
-            calls.append(a[6])
-            return orig(*a)
-    ops.set_conv_math("bf16x6")
-    prev_presplit = ops.PRESPLIT
-    ops.PRESPLIT = True  # experiment (tuning library)
-    opt = None
-    try:
-        opt = FlatAdam([p for b in (blk1, blk2, blk3) for p in b.parameters()])  # owns the weight mirrors and, with PRESPLIT on, their bf16 planes
-        lib.sdt_conv_taps_pre_f32 = Spy()
-        xin = x.clone().requires_grad_(True)
-        h1, h2, h3 = ops.NormBwdHolder(), ops.NormBwdHolder(), ops.NormBwdHolder()
-        z1 = blk1.forward_cl(xin, None, h1)      # no planes of the chain input: in-kernel split fallback
-        z2 = blk2.forward_cl(z1, h1, h2)         # pre-split forward, stride 2
-        z3 = blk3.forward_cl(z2, h2, h3)
-        gout = torch.randn_like(z3)
-        z3.backward(gout)
-        torch.cuda.synchronize()
-    finally:
-        lib.sdt_conv_taps_pre_f32 = orig
-        ops.set_conv_math("f32")
-        ops.PRESPLIT = prev_presplit
-    assert sorted(calls) == [1, 1, 1, 4], calls  # 2 forwards; dX of blk3 (stride 1) and of blk2 (4 parity classes, one launch)
-    got = [xin.grad] + [p.grad for b in (blk1, blk2, blk3) for p in b.parameters()]
-
-    def ref_block(blk, t):
-        w = blk.conv.weight.detach().double().cpu().requires_grad_(True)
-        y = F.conv2d(t, w, None, blk.stride, blk.padding)
-        if norm == "IN":
-            y, extra = F.instance_norm(y, eps=1e-5), []
-        else:
-            ga = blk.norm.weight.detach().double().cpu().requires_grad_(True)
-            be = blk.norm.bias.detach().double().cpu().requires_grad_(True)
-            y, extra = F.batch_norm(y, None, None, ga, be, True, 0.1, 1e-5), [ga, be]
-        return F.leaky_relu(y, 0.2), [w] + extra
-    xr = x.detach().double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
-    t, params = xr, []
-    for b in (blk1, blk2, blk3):
-        t, ps = ref_block(b, t)
-        params += ps
-    t.backward(gout.double().cpu().permute(0, 3, 1, 2))
-    check("pre-split chain dX vs float64", got[0], xr.grad.permute(0, 2, 3, 1), 3e-4)
-    for a, r in zip(got[1:], [p.grad for p in params]):
-        check("pre-split chain parameter gradient vs float64", a, r, 6e-4)
-    del opt
 
 
 @pytest.mark.parametrize("case", [CONV2D[1], CONV2D[5], CONV2D[7], ("1-D 256->256 k4s2", 4, 1, 64, 256, 256, 1, 4, 2, 1),
@@ -1031,13 +896,14 @@ def test_streamk_plans_with_reserved_slots(ops):
         dx = ops.conv_input_grad(gyd, wd, xd.shape, s, p)
         ops.conv_weight_grad(xd, gyd, wd, s, p)
         torch.cuda.synchronize()
-        grids = {(key[4], key[5]): plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if len(key) == 6 and plan is not None and key[5] == 32}
-        dw_grids = [plan.host[3] & 0xffff for key, plan in ops._SK_DW_PLANS.items() if len(key) == 3 and plan is not None and key[2] == 32]
+        # plan cache keys: (geometry bytes, classes, rows per group, backward groups, device, forward, reserve, dtype, routing knobs ...)
+        grids = {(key[5], key[6]): plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if plan is not None and key[6] == 32}
+        dw_grids = [plan.host[3] & 0xffff for key, plan in ops._SK_DW_PLANS.items() if plan is not None and key[2] == 32]
     finally:
         ops.SK_RESERVED_SLOTS = prev
     assert grids and all(v == 480 for v in grids.values()), grids       # backward plans: 512 - 32 workgroups
     assert dw_grids and all(v == 480 for v in dw_grids), dw_grids
-    fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if len(key) == 6 and plan is not None and key[4] and key[5] == 0]
+    fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if plan is not None and key[5] and key[6] == 0]
     assert fwd and all(v == 512 for v in fwd), fwd                       # forward plans keep every slot
     check("reserve fwd", ops.cf_view(yd), y, 3e-6)
     check("reserve dX", ops.cf_view(dx), xr.grad, 3e-6)
