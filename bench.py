@@ -182,6 +182,9 @@ def main(argv=None):
     ap.add_argument("--config", default="voice2pose_sdt_bp")
     ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="product arithmetic of the forward / input-gradient conv kernels (experiments; the metric is quoted on f32)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16"],
+                    help="element type of the Conv2d chain's activations and conv operands in HBM: bf16 = BASELINE config 4's arithmetic "
+                         "(bf16 tensors and MFMA products, fp32 accumulation / statistics / master weights); the metric is quoted on f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the informational 20 steps in bf16x6 conv math after the timed region")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
@@ -262,6 +265,7 @@ def main(argv=None):
         ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
         ops.OVERLAP_AUX = not args.no_overlap_aux
         ops.set_conv_math(args.conv_math)
+        ops.set_storage(args.storage)
         # every rank draws its own initial weights (nothing here seeds torch): setup_optimizer's dp.sync_replicas makes the
         # replicas identical, as DDP's constructor does in the reference
         pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
@@ -365,7 +369,9 @@ def main(argv=None):
             "metric": "training clips/sec (64-frame, 137-kpt) voice2pose_sdt_bp",
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math,
+            "vs_baseline": None, "dtype": ("bf16 (Conv2d chain: bf16 tensors in HBM, bf16 MFMA products, fp32 accumulation / statistics / master weights / gradients; "
+                      "1-D stage fp32)" if args.storage == "bf16" else
+                      ("f32" if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math)),
             "data": "synthetic",
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"

@@ -558,10 +558,50 @@ def test_validate_loop_and_fgd():
     # one training step first so that BN running statistics of the pose encoder are not the init values
     losses, _ = pipe.forward_backward(O.make_batch(4, 16, step=0, seed=1))
     pipe.optimizer_updates(losses)
-    out = pipe.validate(pipe.test_dataloader, 1)
+    # record what every test_step saw (the batch and the randomly drawn code rows, voice2pose.py:119-120) so that the ORACLE can redo the
+    # whole loop: per batch the eval-mode forward + float64 metrics, then the reference's aggregation (trainer.py:407-427: per-key sums of
+    # loss x TEST.BATCH_SIZE over the batches / number of test samples; FGD over the concatenated pose-encoder features)
+    seen = []
+    orig_forward = pipe.model.forward
+
+    def spy(batch, dataset, *a, **k):
+        out_ = orig_forward(batch, dataset, *a, **k)
+        seen.append((batch, out_[1]["condition_code"].detach().cpu().clone()))
+        return out_
+    pipe.model.forward = spy
+    try:
+        out = pipe.validate(pipe.test_dataloader, 1)
+    finally:
+        pipe.model.forward = orig_forward
     for k in ("G_reg_loss", "G_loss", "L2_dist", "lip_sync_error_n", "FGD_mu", "FGD_mu_logvar"):
         assert k in out and np.isfinite(float(out[k])), (k, out.get(k))
     assert not pipe.model.training  # validate() leaves the model in eval mode like the reference (trainer.py:409)
+    assert len(seen) == 2
+    ocfg = O.cfg_named("voice2pose_sdt_bp")
+    st0 = {k: v.detach().cpu().clone() for k, v in pipe.model.state_dict().items()}
+    sums, feats = {}, {k: [] for k in ("mu_pred", "mu_gt", "logvar_pred", "logvar_gt")}
+    for batch, code in seen:
+        B = code.shape[0]
+        ob = {"audio": batch["audio"].cpu(), "poses": batch["poses"].cpu(), "clip_index": torch.arange(B),
+              "num_frames": batch["num_frames"], "speaker_stat": {k: v.cpu() for k, v in batch["speaker_stat"].items()}}
+        st = dict(st0, clips_code=code)  # row b of the table = the code the step drew for clip b
+        with torch.no_grad():
+            ol, ores = O.voice2pose_forward(st, ob, ocfg, training=False)
+        fin_p = O.get_final_results(ores["poses_pred_batch"].double(), ob["speaker_stat"], True)
+        fin_g = O.get_final_results(ob["poses"].double(), ob["speaker_stat"], True)
+        ol.update(O.evaluate_step(fin_p, fin_g))
+        for k, v in ol.items():
+            sums[k] = sums.get(k, 0.0) + float(v) * cfg.TEST.BATCH_SIZE
+        for k in feats:
+            feats[k].append(ores[k].numpy())
+    want = {k: v / pipe.num_test_samples for k, v in sums.items()}
+    feats = {k: np.concatenate(v, 0) for k, v in feats.items()}
+    want["FGD_mu"] = compute_fgd(feats["mu_pred"], feats["mu_gt"])
+    want["FGD_mu_logvar"] = compute_fgd(np.concatenate([feats["mu_pred"], feats["logvar_pred"]], 1), np.concatenate([feats["mu_gt"], feats["logvar_gt"]], 1))
+    for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss", "L2_dist", "lip_sync_error_n"):
+        check("validate() aggregate %s vs oracle loop" % k, torch.as_tensor(float(out[k])).reshape(1), torch.as_tensor(want[k]).reshape(1), 2e-4)
+    for k in ("FGD_mu", "FGD_mu_logvar"):  # Frechet distance of 8 samples of 32 / 64 features: differences of covariance square roots
+        assert abs(float(out[k]) - want[k]) <= 2e-3 * max(abs(want[k]), 1.0), (k, float(out[k]), want[k])
     # eval forward against the oracle in eval mode (running-stat BN, random code rows replaced by fixed ones)
     pipe.model.eval()
     batch = O.make_batch(4, 16, step=5, seed=1)

@@ -1066,3 +1066,68 @@ def test_gradients_are_ready_when_backward_returns(ops):
             ref = w.grad.clone()
             assert float(ref.abs().max()) > 0
         assert torch.equal(got, ref), "repetition %d read an unfinished weight gradient" % rep
+
+
+def _streamk_launch(ops, seed=3):
+    """one persistent stream-K forward launch with split tiles (B=16 of the L4 shape); returns (y, float64 reference)"""
+    g = torch.Generator().manual_seed(seed)
+    B, Hi, Wi, Cin, Cout, k = 16, 20, 106, 128, 256, 3
+    x = torch.randn(B, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) * (2.0 / (Cin * k * k)) ** 0.5
+    xd = ops.cl(x.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    y = ops.conv_forward(xd, wd, None, 1, 1)
+    torch.cuda.synchronize()
+    return y, F.conv2d(x, w, None, 1, 1)
+
+
+def test_streamk_error_word_makes_the_trainer_raise(ops):
+    """The error word of a stream-K workspace (a lost partner, see the next test) is what Trainer.check_kernels -- called on log steps, after
+    validation and before every checkpoint -- turns into an exception: training never logs or saves numbers such a launch produced."""
+    from speechdrivestemplates_amd.core.pipelines.trainer import Trainer
+    y, ref = _streamk_launch(ops)
+    check("stream-K forward before the simulated failure", ops.cf_view(y), ref, 3e-6)
+    assert ops.streamk_error_codes() == {}
+    Trainer.check_kernels()  # clean: no exception
+    key, ws = next(iter(ops._SK_WS.items()))
+    ws[ops._SK_ERR_WORD] = 7  # what the kernel stores when range 6 never raised its flag
+    try:
+        assert ops.streamk_error_codes() == {key: 7}
+        with pytest.raises(RuntimeError, match="gave up waiting for a partner"):
+            Trainer.check_kernels()
+        with pytest.raises(RuntimeError, match="gave up waiting for a partner"):
+            ops.check_streamk()
+    finally:
+        ws[ops._SK_ERR_WORD] = 0
+    Trainer.check_kernels()
+
+
+@pytest.mark.tuning
+def test_streamk_lost_partner_is_loud(ops):
+    """Fault injection (-DSDT_TUNING library): one workgroup of a stream-K launch computes its partial tile but never raises its flag -- a
+    partner that was never dispatched.  The owner gives up after the spin limit, sets the error word and stores the tile as NaN (never a
+    tile with a partial sum missing); the next, healthy launch on the same workspace is correct again."""
+    from speechdrivestemplates_amd import _lib
+    lib = _lib.load()
+    prev = lib.sdt_convsk_get_spin_limit()
+    _lib.check(lib.sdt_convsk_set_spin_limit(20000))
+    _lib.check(lib.sdt_debug_convsk_mute_range(200))
+    try:
+        y, ref = _streamk_launch(ops)
+        codes = ops.streamk_error_codes()
+        assert list(codes.values()) == [201], codes  # range id + 1
+        bad = torch.isnan(y)
+        assert bad.any() and bad.sum().item() <= 128 * 128, "exactly one tile is poisoned"
+        ok = ~bad.cpu()
+        err = ((ops.cf_view(y).double().cpu() - ref).abs()[ops.cf_view(ok)]).max().item() / ref.abs().max().item()
+        assert err < 3e-6, err  # every other tile is right
+        with pytest.raises(RuntimeError, match="gave up waiting for a partner"):
+            ops.check_streamk()
+    finally:
+        _lib.check(lib.sdt_debug_convsk_mute_range(-1))
+        _lib.check(lib.sdt_convsk_set_spin_limit(prev))
+        for ws in ops._SK_WS.values():
+            ws[ops._SK_ERR_WORD] = 0
+    y, ref = _streamk_launch(ops, seed=4)
+    check("stream-K forward after the injected failure", ops.cf_view(y), ref, 3e-6)
+    assert ops.streamk_error_codes() == {}
