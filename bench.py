@@ -54,11 +54,14 @@ EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "6"))
 
 
 def event_steps(steps):
-    """sampled steps of the timed region: one "alone" + one "stages only" below 40 steps (a per-launch-event step costs ~1.5 ms, so
-    short runs carry a single one), a full rotation of three from 40 steps on, two rotations from 60 on"""
+    """sampled steps of the timed region: below 16 steps one "alone" + one "stages only"; from 16 steps on THREE "alone" steps + one
+    "stages only" (one sampled step of 20 was a thin basis for roofline.achieved; an "alone" step costs ~1.2 ms, i.e. the
+    driver's 20-step run pays ~2 % for them); a rotation alone / stages / as-run from 40 steps on, two rotations from 60 on"""
     if steps < 2:
         return steps  # a single timed step still carries the roofline sample
-    return 2 if steps < 40 else min(EVENT_STEPS_MAX, (steps // 30) * 3 if steps >= 60 else 3)
+    if steps < 16:
+        return 2
+    return 4 if steps < 40 else min(EVENT_STEPS_MAX, (steps // 30) * 3 if steps >= 60 else 3)
 
 
 def stage_batches(n_batches, B, rank, dev):
@@ -154,6 +157,21 @@ def cited_traffic(kernel_name):
     return info
 
 
+def cited_trace_fraction(kernel_name):
+    """The rocprofv3 kernel-trace average of the dominant kernel (tools/collect_profiles.sh writes profiles/<round>_trace_fraction.json next
+    to the trace summaries): cited beside the event-based figure while the kernel sources still hash to the digest recorded there."""
+    prof = os.path.join(REPO, "profiles")
+    cands = sorted((f for f in os.listdir(prof) if f.endswith("_trace_fraction.json")), reverse=True) if os.path.isdir(prof) else []
+    for f in cands:
+        tj = json.load(open(os.path.join(prof, f)))
+        if tj.get("kernel") != kernel_name:
+            continue
+        ok = tj.get("kernel_source_digest") == kernel_source_digest()
+        return {"source": "profiles/" + f, "avg_launch_us": tj.get("avg_launch_us") if ok else None, "frac": tj.get("frac") if ok else None,
+                "current": ok, "note": None if ok else "kernel sources changed since that trace (digest now %s): not cited" % kernel_source_digest()}
+    return None
+
+
 class _StubPipeline:
     """SDT_BENCH_STUB=1: the control flow of this script (process group, barriers, timed loop, max over ranks, JSON) with the
     train step replaced by a tiny CPU all-reduce -- tests/test_bench_flow.py runs it under gloo with two ranks so that the
@@ -186,7 +204,7 @@ def main(argv=None):
                     help="element type of the Conv2d chain's activations and conv operands in HBM: bf16 = BASELINE config 4's arithmetic "
                          "(bf16 tensors and MFMA products, fp32 accumulation / statistics / master weights); the metric is quoted on f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-mode", action="store_true", help="skip the informational 20 steps in bf16x6 conv math after the timed region")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the informational bf16-storage leg (BASELINE config 4's arithmetic) after the timed region")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events (roofline leg)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1)")
     ap.add_argument("--graph-streams", action="store_true", help="with --graph: capture the side streams too (experiment)")
@@ -317,7 +335,8 @@ def main(argv=None):
             if i in sampled:
                 # three kinds of sampled step in rotation: per-launch events with the side stream off ("alone"), per-launch events
                 # as run, and stage windows only (a handful of events per step: per-launch events would inflate the windows)
-                if n_alone <= n_ovl:
+                short_run = 16 <= args.steps < 40  # three "alone" steps, then one "stages only"
+                if (short_run and n_alone < 3) or (not short_run and n_alone <= n_ovl):
                     ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
                 elif n_stage < n_alone:
                     ops.STAGES, n_stage = stages, n_stage + 1
@@ -382,6 +401,7 @@ def main(argv=None):
                        # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)
                        "deterministic": bool(not args.atomic_dw and not args.no_streamk_dw and args.conv_math == "f32")},
             "final_G_loss": final_loss,
+            "streamk_errors": 0 if (ops is not None and on_gpu and not stub) else None,  # asserted above: no stream-K launch lost a partner
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included
             "median_ms_per_step": median_ms, "value_at_median": world * B / (median_ms * 1e-3),
@@ -418,6 +438,11 @@ def main(argv=None):
                 r: {"launches_per_step": v[0] / prof_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
                     "frac": v[2] / (v[1] * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS} for r, v in sorted(d["roles"].items())}
             out["roofline"].update(cited_traffic(name))
+            # the whole step against the fp32-MFMA floor of its convolutions: algorithmic conv FLOPs of a step / matrix peak / step time
+            step_gflop = sum(v["flops"] for v in summ.values()) / prof_steps / 1e9
+            out["roofline"]["step_gflop"] = step_gflop
+            out["roofline"]["step_frac"] = step_gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) / (clean_mean_ms * 1e-3)
+            out["roofline"]["trace_based"] = cited_trace_fraction(name)
             if prof_ovl is not None and n_ovl > 0:
                 do = prof_ovl.summary()[name]
                 out["roofline"]["overlapped"] = {
@@ -456,52 +481,77 @@ def main(argv=None):
             hbs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_kernels.txt")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
             if hbs:
                 out["hbm_kernels_table"] = "profiles/%s (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)" % hbs[-1]
-        if world == 1 and not stub and not args.no_alt_mode and args.conv_math == "f32" and not args.graph and on_gpu:
-            # informational, OUTSIDE the timed region and not part of `value`: the same step with the conv products evaluated as
-            # six bf16 MFMA products of exactly split operands (fp32-equivalent: passes the B=32 float64-calibrated parity tests,
-            # tests/test_fullsize_gpu.py::test_b32_bf16x6_mode_meets_the_fp32_bar) -- opt-in via --conv-math
-            ops.set_conv_math("bf16x6")
+        if world == 1 and not stub and not args.no_alt_mode and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
+                and args.config == "voice2pose_sdt_bp":
+            # informational, OUTSIDE the timed region and not part of `value`: BASELINE config 4's arithmetic on this GPU -- the same train step
+            # with the Conv2d chain's tensors stored as bf16 and its products on the bf16 MFMA (fp32 accumulation / statistics / master weights;
+            # tests/test_bf16_gpu.py states and checks its tolerances).  Replayed from a hipGraph: the step needs ~3.5 ms of GPU time, the host
+            # ~5.6 ms to enqueue its launches one by one (tools/host_time.py).
+            from speechdrivestemplates_amd.graph import GraphedStep
+            ops.set_storage("bf16")
             try:
-                for i in range(3):
-                    runner(args.warmup + args.steps + i)
+                base = args.warmup + args.steps
+                for i in range(3):  # eager: allocates the bf16 weight copies and builds the bf16 plans outside any capture
+                    step(base + i)
+                sync()
+                aprof = None
+                if prof is not None:  # its own roofline: three eager steps with per-launch events, weight gradients on the main stream
+                    aprof = ops.ConvProfiler(pool=2 * 200 * 3)
+                    try:
+                        ops.PROFILER, ops.OVERLAP_DW = aprof, False
+                        for i in range(3):
+                            step(base + 3 + i)
+                        sync()
+                    finally:
+                        ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
+                gs = GraphedStep(pipe, warmup=1)
+                for i in range(4):
+                    gs.run(batches[(base + 6 + i) % len(batches)])
                 sync()
                 ta = time.perf_counter()
-                n_alt = 20
+                n_alt = 30
                 for i in range(n_alt):
-                    losses_alt = runner(args.warmup + args.steps + 3 + i)
+                    losses_alt = gs.run(batches[(base + 10 + i) % len(batches)])
                 sync()
                 alt_ms = (time.perf_counter() - ta) * 1e3 / n_alt
+                alt_loss = float(losses_alt["G_loss"].detach())
+                te = time.perf_counter()
+                for i in range(10):
+                    step(base + 40 + i)
+                sync()
+                eager_ms = (time.perf_counter() - te) * 1e3 / 10
+                codes = ops.streamk_error_codes()
+                assert not codes, "stream-K error words (bf16 leg): %r" % codes
             finally:
-                ops.set_conv_math("f32")
-            alt_loss = float(losses_alt["G_loss" if "G_loss" in losses_alt else "loss"].detach())
-            assert alt_loss == alt_loss and alt_loss < 10.0, "bf16x6 leg diverged: G_loss=%r" % alt_loss
-            out["alt_conv_math"] = {"mode": "bf16x6", "dtype": "bf16x6 (3-piece bf16 split of fp32 operands, 6 MFMA products, fp32 accumulate)",
-                                    "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt,
-                                    "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
-                                    "note": "not the headline: 20 further steps of the same run with --conv-math bf16x6 (exact 3-piece bf16 "
-                                            "split of both operands inside the conv kernels, 6 MFMA products, fp32 accumulation), no sampling events"}
-            if prof is not None:
-                # its own roofline: two more steps with per-launch events (side stream off), priced against the dense bf16 MFMA peak / 6
-                ops.set_conv_math("bf16x6")
-                aprof = ops.ConvProfiler(pool=2 * 200 * 2)
-                try:
-                    ops.PROFILER, ops.OVERLAP_DW = aprof, False
-                    for i in range(2):
-                        runner(args.warmup + args.steps + 23 + i)
-                    sync()
-                finally:
-                    ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
-                    ops.set_conv_math("f32")
+                ops.set_storage("f32")
+            assert alt_loss == alt_loss and alt_loss < 10.0, "bf16 leg diverged: G_loss=%r" % alt_loss
+            out["alt_conv_math"] = {"mode": "bf16", "dtype": "bf16 (Conv2d chain: bf16 tensors in HBM + bf16 MFMA products; fp32 accumulation, statistics, "
+                                                             "master weights, gradients; 1-D stage exact fp32)",
+                                    "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt, "graph": True,
+                                    "eager_ms_per_step": eager_ms, "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
+                                    "note": "not the headline (the metric is quoted on the reference's fp32 arithmetic): %d further steps of the same run in "
+                                            "bf16 storage (BASELINE config 4 per GPU), replayed from a hipGraph; eager_ms_per_step = the same steps "
+                                            "enqueued launch by launch (host-bound)" % n_alt}
+            if aprof is not None:
                 asum = aprof.summary()
-                aname, ad = max(asum.items(), key=lambda kv: kv[1]["us"])
-                a_ach = ad["flops"] / (ad["us"] * 1e-6) / 1e12
-                a_all = sum(v["flops"] for v in asum.values()) / (sum(v["us"] for v in asum.values()) * 1e-6) / 1e12
+                two_d = {k: v for k, v in asum.items() if "bf16" in k or k.startswith("convbf")}
+                aname, ad = max(two_d.items(), key=lambda kv: kv[1]["us"])
+                a_us = ad["us"] / ad["launches"]
+                a_bytes, a_flops = ad["bytes"] / ad["launches"], ad["flops"] / ad["launches"]
+                tot_b = sum(v["bytes"] for v in two_d.values())
+                tot_f = sum(v["flops"] for v in two_d.values())
+                tot_us = sum(v["us"] for v in two_d.values())
                 out["alt_conv_math"]["roofline"] = {
-                    "bound": "mfma", "kernel": aname, "achieved": a_ach, "peak": BF16_MATRIX_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s (fp32-equivalent)",
-                    "frac": a_ach / (BF16_MATRIX_PEAK_TFLOPS / 6.0), "avg_launch_us": ad["us"] / ad["launches"], "launches_per_step": ad["launches"] / 2.0,
-                    "all_conv_launches_achieved": a_all, "event_sampled_steps": 2,
-                    "note": "peak = dense bf16 MFMA peak (%.0f TFLOP/s) / 6 products per fp32 product; algorithmic fp32 FLOPs of the layer / event window"
-                            % BF16_MATRIX_PEAK_TFLOPS}
+                    "bound": "hbm", "kernel": aname, "achieved": a_bytes / (a_us * 1e-6) / 1e9, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                    "frac": a_bytes / (a_us * 1e-6) / 1e12 / HBM_PEAK_TBS, "avg_launch_us": a_us, "launches_per_step": ad["launches"] / 3.0,
+                    "algorithmic_mb_per_launch": a_bytes / 1e6, "algorithmic_gflop_per_launch": a_flops / 1e9,
+                    "mfma_achieved_tflops": a_flops / (a_us * 1e-6) / 1e12, "mfma_frac": a_flops / (a_us * 1e-6) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
+                    "all_conv2d_launches": {"ms_per_step": tot_us / 3.0 / 1e3, "gb_s": tot_b / (tot_us * 1e-6) / 1e9,
+                                            "tflops": tot_f / (tot_us * 1e-6) / 1e12, "launches_per_step": sum(v["launches"] for v in two_d.values()) / 3.0},
+                    "event_sampled_steps": 3,
+                    "note": "bf16 tensors: algorithmic bytes = 2 x (|X| + |Y| + |W|) per launch (SURVEY.md 8d's per-layer bytes halved) / HIP-event window, "
+                            "against 8 TB/s; mfma_* = the same launches against the dense bf16 MFMA peak (%.0f TFLOP/s): the kernels are bound by "
+                            "neither -- LDS feeding and the per-tile epilogue of a persistent fp32-shaped tile (DESIGN.md section 2)" % BF16_MATRIX_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(B)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -38,7 +38,11 @@ _DEFAULTS = {
     "DEMO": {"MULTIPLE": 1, "NUM_SAMPLES": 1, "CODE_INDEX": None, "CODE_INDEX_B": None, "CODE_PATH": None},
     "SYS": {"OUTPUT_DIR": "output/", "CANVAS_SIZE": (720, 1280), "VISUALIZATION_SCALING": 0.85,
             "VIDEO_FORMAT": ["mp4", "img"], "ASYNC_VIDEO_SAVING": False, "LOG_INTERVAL": 100, "NUM_WORKERS": 8,
-            "DISTRIBUTED": False, "WORLD_SIZE": 1, "MASTER_ADDR": "localhost", "MASTER_PORT": 21379},
+            "DISTRIBUTED": False, "WORLD_SIZE": 1, "MASTER_ADDR": "localhost", "MASTER_PORT": 21379,
+            # extensions of this engine (absent from the reference's configs/default.py:4-97; defaults = the reference's behaviour):
+            # STORAGE 'bf16' = BASELINE config 4's arithmetic for the Conv2d chain (ops.set_storage), HIP_GRAPH = replay the train step
+            # from a captured hipGraph (graph.GraphedStep, single-GPU runs)
+            "STORAGE": "f32", "HIP_GRAPH": False},
 }
 
 

@@ -178,6 +178,8 @@ class Voice2Pose(Trainer):
         super().__init__(cfg)
 
     def setup_model(self, cfg, state_dict=None, external_codes=None):
+        if getattr(cfg.SYS, 'STORAGE', 'f32') != 'f32':
+            ops.set_storage(cfg.SYS.STORAGE)  # before setup_optimizer: its weight mirrors allocate the bf16 copies
         self.model = Voice2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank(), external_codes).cuda()
         if state_dict is not None:
             sd = OrderedDict((k[len('module.'):] if k.startswith('module.') else k, v) for k, v in state_dict.items())
@@ -295,8 +297,17 @@ class Voice2Pose(Trainer):
         tag = 'TRAIN'
         log_step = t_step % self.cfg.SYS.LOG_INTERVAL == 0
         save_step = t_step % self.result_saving_interval_train == 0 and (self.cfg.TRAIN.SAVE_NPZ or self.cfg.TRAIN.SAVE_VIDEO)
-        losses, results = self.forward_backward(batch, want_final=bool(save_step))
-        self.optimizer_updates(losses)
+        if getattr(self.cfg.SYS, 'HIP_GRAPH', False) and not save_step and not self.cfg.SYS.DISTRIBUTED:
+            # replay the captured step (forward, metrics, backward, Adam): the host copies the batch into the graph's static inputs and
+            # launches ONE graph instead of ~270 kernels (graph.GraphedStep; steps that save results run eagerly: they need the final poses)
+            if getattr(self, '_graphed', None) is None:
+                from ...graph import GraphedStep
+                self._graphed = GraphedStep(self, warmup=2)
+            losses = self._graphed.run(batch)
+            results = self._graphed.results
+        else:
+            losses, results = self.forward_backward(batch, want_final=bool(save_step))
+            self.optimizer_updates(losses)
         self.last_losses = losses
         if log_step:
             if self.cfg.SYS.DISTRIBUTED:

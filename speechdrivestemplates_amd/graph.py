@@ -1,4 +1,6 @@
-"""hipGraph replay of a whole training step.
+"""hipGraph replay of a whole training step (product since round 4: the bf16-storage step needs 3.5 ms of GPU time, the host needs
+5.6 ms to enqueue its ~270 launches one by one -- replayed from a graph the host cost is 0.16 ms per step; the fp32 step is GPU-bound
+and gains nothing).  ``SYS.HIP_GRAPH: True`` makes Voice2Pose.train_step use it (single-GPU runs).
 
 The 1-D stage of the generator is ~100 launches of a few microseconds each; issued one by one from Python they are
 host-bound.  ``GraphedStep`` captures ``forward_backward`` + ``optimizer_updates`` of a Voice2Pose pipeline (every
@@ -22,10 +24,12 @@ class GraphedStep:
         self.graph = None
         self.static = None
         self.losses = None
+        self.results = None  # results dict of the captured step: static tensors that every replay overwrites
 
     def _eager(self, batch):
-        losses, _ = self.pipe.forward_backward(batch)
+        losses, results = self.pipe.forward_backward(batch)
         self.pipe.optimizer_updates(losses)
+        self.results = results
         return losses
 
     @staticmethod

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence, run on the MI355X box: bash tools/collect_profiles.sh r03   (writes gpurun_out/<tag>_final/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_final
@@ -14,8 +14,16 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 # (3) every kernel alone on the GPU
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_noovl" -o b -- $CMD --no-overlap-dw --no-kernel-events > "$OUT/trace_noovl.log" 2>&1
 python tools/trace_summary.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape.txt" 2>&1
+# trace-based fraction of the dominant kernel (bench.py cites it beside its event-based figure): algorithmic GFLOP per launch from the bench line
+GF=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['roofline']['algorithmic_gflop_per_launch'])")
+python tools/trace_fraction.py "$OUT/trace_noovl/b_kernel_trace.csv" "convsk_kernel<float, float, 128, 128" "convsk_kernel<128, 128>" "$GF" 157.3 "$OUT/trace_fraction.json" > "$OUT/trace_fraction.log" 2>&1
 python tools/stream_summary.py "$OUT/trace/b_kernel_trace.csv" 35 14 > "$OUT/streams.txt" 2>&1
 python tools/hbm_kernels.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 > "$OUT/hbm_kernels.txt" 2>&1
+# (3a) the bf16-storage step (BASELINE config 4's arithmetic): every kernel alone, and as run
+BCMD="python bench.py --storage bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-alt-mode --no-kernel-events"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bf16" -o b -- $BCMD --no-overlap-dw > "$OUT/trace_bf16.log" 2>&1
+python tools/trace_summary.py "$OUT/trace_bf16/b_kernel_trace.csv" 25 60 > "$OUT/bf16_trace_by_launch_shape.txt" 2>&1
+cp "$OUT/trace_bf16/b_kernel_stats.csv" "$OUT/bf16_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/trace_bf16"
 # (3b) PMC of the MFMA kernels, one launch set per layer and role (two passes: issue / stall split, instruction mix)
 bash tools/debug/pmc_conv.sh L1,L2,L3,L4,L5,L6,L7 fwd,dX,dW > "$OUT/pmc_conv.txt" 2>&1
 # (4) fabric-side traffic: two PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
