@@ -213,6 +213,7 @@ def main(argv=None):
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     ap.add_argument("--atomic-dw", action="store_true",
                     help="weight gradients with fp32 atomics (the round-2 default) instead of the ordered, bit-reproducible reductions")
+    ap.add_argument("--bwd-wpc", default=None, help="experiment: persistent workgroups per CU of the backward stream-K plans, 'DX,DW' (e.g. 1,1 or 2,1)")
     ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
     ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
@@ -275,6 +276,8 @@ def main(argv=None):
             from speechdrivestemplates_amd import _lib
             _lib.check(_lib.load().sdt_debug_set_small1d(ctypes.c_int(0)))
             ops.STREAMK_MIN_COUT = 64
+        if args.bwd_wpc:
+            ops.SK_WPC_DX, ops.SK_WPC_DW = (int(v) for v in args.bwd_wpc.split(","))
         ops.DEFER_SMALL_DW = not args.no_defer_dw
         ops.DETERMINISTIC_DW = not args.atomic_dw
         if args.atomic_dw:

@@ -87,8 +87,15 @@ class Pose2Pose(Trainer):
         opt.step()
 
     def train_step(self, batch, t_step, global_step, epoch):
-        losses, _ = self.forward_backward(batch)
-        self.optimizer_updates(losses)
+        if getattr(self.cfg.SYS, 'HIP_GRAPH', False) and not self.cfg.SYS.DISTRIBUTED:
+            # ~150 launches of a few microseconds: enqueued one by one the step is bound by the host (3 ms); replayed from a hipGraph it is not
+            if getattr(self, '_graphed', None) is None:
+                from ...graph import GraphedStep
+                self._graphed = GraphedStep(self, warmup=2)
+            losses = self._graphed.run(batch)
+        else:
+            losses, _ = self.forward_backward(batch)
+            self.optimizer_updates(losses)
         self.last_losses = losses
         if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
             if self.cfg.SYS.DISTRIBUTED:

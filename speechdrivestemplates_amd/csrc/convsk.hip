@@ -264,8 +264,9 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
 // just stored; every MFMA of k-group 2 by its share of k-group 3's reads.
 template <int G2, int Q, int NM, int NF, int NL>
 __device__ __forceinline__ void sk_bf_interleave() {
-    constexpr int HL = (NL + 1) / 2;
-    constexpr int lo = G2 * HL, hi = G2 < 2 ? ((G2 + 1) * HL < NL ? (G2 + 1) * HL : NL) : lo;
+    // the LDS stores of step s+1 and the global loads of step s+3 go with the FIRST k-group: the loads are issued as early in the step as
+    // their registers are free (a load lands two steps before it is staged: the L2 latency under load is about one bf16 step)
+    constexpr int lo = 0, hi = G2 == 0 ? NL : 0;
     constexpr int nr = (NF + NM - 1 - Q) / NM, nw = (hi - lo + NM - 1 - Q) / NM;
     SK_SGB(0x8, 1);
     if constexpr (nr > 0) SK_SGB(0x100, nr);
@@ -480,6 +481,95 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
                     }
         };
         SK_TL(1, wall_clock64());
+        const int nsteps = b - a;
+        if constexpr (BF) {
+            // ---- bf16: a K step is 16 MFMAs of 32 cycles per wave, about the L2 latency under load.  TWO register sets: the loads of step s + 3 are
+            // issued at the top of step s into the set that was just staged, i.e. two steps before they are written to LDS (with one set
+            // the wave sat in vmcnt(0) at the top of every step: 2500 cycles per step against 512 of MFMA, tools/debug/sk_timeline.py
+            // --dtype bf16).  The loop is unrolled by two so that register set and LDS buffer are compile-time.  One accumulator over
+            // the whole K loop: the products of bf16 operands are exact in fp32 and the operands carry 2^-9 already.
+            f32x4 ra2[2][RA], rb2[2][RB];
+            auto load2 = [&](auto SI) {
+                constexpr int S_ = decltype(SI)::value;
+                const bool on = left > 0 && rmask != 0u;
+                int t = (rmask != 0u ? __builtin_ctz(rmask) : 0) + rot;
+                t = t >= ntaps ? t - ntaps : t;
+                t = on ? t : 0;
+                const int ash = __builtin_amdgcn_readlane(v_ash, t), bsh = __builtin_amdgcn_readlane(v_bsh, t);
+                const int cs = kc * (SK_BK * 4);
+                const int sh = on ? 31 - t : 0;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const unsigned o = ((abase[i] + (unsigned)ash) & 0x7fffffffu) | ((inval[i] << sh) & 0x80000000u);
+                    ra2[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, cs, 0));
+                }
+                const unsigned bsh_eff = (unsigned)bsh + (on ? 0u : SK_OOB);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) rb2[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i] + bsh_eff), cs, 0));
+                --left;
+                const bool wrap = kc + 1 == nkc;
+                kc = wrap ? 0 : kc + 1;
+                rmask = wrap ? (rmask & (rmask - 1u)) : rmask;
+            };
+            auto stage2 = [&](auto SI, const int buf) {
+                constexpr int S_ = decltype(SI)::value;
+                float* wA = sA + buf * BM * SK_LDP + wofs;
+                float* wB = sB + buf * BN * SK_LDP + wofs;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) *(f32x4*)&wA[32 * i * SK_LDP] = ra2[S_][i];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) *(f32x4*)&wB[32 * i * SK_LDP] = rb2[S_][i];
+            };
+            auto step2 = [&](auto CUR) {
+                constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
+                constexpr int SET = 0;
+                const float* pa = sA + cur * BM * SK_LDP + fa;
+                const float* pb = sB + cur * BN * SK_LDP + fb;
+                SK_READ(a1, b1, pa, pb, 1);
+                stage2(std::integral_constant<int, nx>{}, nx);  // step s + 1: registers -> LDS[next]
+                load2(std::integral_constant<int, nx>{});       // step s + 3 -> the registers just staged
+                SK_MFMA(SET, a0, b0);
+                SK_READ(a0, b0, pa, pb, 2);
+                SK_MFMA(SET, a1, b1);
+                SK_READ(a1, b1, pa, pb, 3);
+                SK_MFMA(SET, a0, b0);
+                sk_bf_interleave<0, 0, NM, TM + TN, RA + RB>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                SK_READ(a0, b0, sA + nx * BM * SK_LDP + fa, sB + nx * BN * SK_LDP + fb, 0);
+                SK_MFMA(SET, a1, b1);
+#pragma unroll
+                for (int q = 0; q < (NM < TM + TN ? NM : TM + TN); ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
+                if constexpr (NM > TM + TN) SK_SGB(0x8, NM - (TM + TN));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load2(std::integral_constant<int, 0>{});
+            stage2(std::integral_constant<int, 0>{}, 0);
+            load2(std::integral_constant<int, 1>{});
+            load2(std::integral_constant<int, 0>{});
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[0][i][j][q] = 0.f;
+            SK_READ(a0, b0, sA + fa, sB + fb, 0);
+            SK_TL(2, wall_clock64());
+            SK_TL(5, (unsigned long long)nsteps);
+            int s = 0;
+            for (; s + 1 < nsteps; s += 2) {
+                step2(std::integral_constant<int, 0>{});
+                step2(std::integral_constant<int, 1>{});
+            }
+            if (s < nsteps) step2(std::integral_constant<int, 0>{});
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) tot[i][j] = acc[0][i][j];
+        } else {
         load();
         stage(0);
         load();
@@ -493,7 +583,6 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
         SK_READ(a0, b0, sA + fa, sB + fb, 0);
         // K loop.  Chunks are aligned to the tile's own step index (a + s): the summation structure of a segment does not depend on
         // where the workgroup's range starts
-        const int nsteps = b - a;
         SK_TL(2, wall_clock64());
         SK_TL(5, (unsigned long long)nsteps);
         for (int s = 0; s < nsteps; ++s) {
@@ -501,6 +590,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
             step(s & 1);
         }
         flush();
+        }
 
         // ------------------------------------------------------------------ end of the segment
         const bool owner = a == 0, whole = owner && b == tend - tbeg;
@@ -871,7 +961,7 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
     const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
     int ya[LA];
     int2 xb[LB];
-    f32x4 ra[LA], rb[LB];
+    f32x4 ra[2][LA], rb[2][LB];  // two register sets: a load is issued two steps before its data is written to LDS (see convsk_kernel's bf16 loop)
     int mrow = a * 64;  // first row of the next table read
     auto load_rows = [&]() {
 #pragma unroll
@@ -881,25 +971,27 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
         mrow += 64;
     };
     int left = b - a;
-    auto load = [&]() {
+    auto load = [&](auto SI) {
+        constexpr int S_ = decltype(SI)::value;
         const unsigned off_mask = left > 0 ? 0u : SK_OOB;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const unsigned oa = ((unsigned)ya[i] + acol) | off_mask;  // rows past M carry SK_OOB already
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
+            ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask;
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
+            rb[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
         }
         --left;
     };
-    auto stage = [&](const int buf) {
+    auto stage = [&](auto SI, const int buf) {
+        constexpr int S_ = decltype(SI)::value;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *(f32x4*)&sA[buf * 64 * BM + bfdw_off<BM>(rra + RPA * i, cqa * 8)] = ra[i];
+        for (int i = 0; i < LA; ++i) *(f32x4*)&sA[buf * 64 * BM + bfdw_off<BM>(rra + RPA * i, cqa * 8)] = ra[S_][i];
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *(f32x4*)&sB[buf * 64 * BN + bfdw_off<BN>(rrb + RPB * i, cqb * 8)] = rb[i];
+        for (int i = 0; i < LB; ++i) *(f32x4*)&sB[buf * 64 * BN + bfdw_off<BN>(rrb + RPB * i, cqb * 8)] = rb[S_][i];
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -912,21 +1004,25 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
     // 16 (g & 1) + 4 (p & 3) of its 32-column sub-tile
     const int g4 = lane >> 4, p4 = lane & 15;
     const int frow = 8 * (g4 >> 1) + (p4 >> 2), fcol = 16 * (g4 & 1) + 4 * (p4 & 3);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
     load_rows();
-    load();
+    load(I0{});     // step 0 -> set 0
     load_rows();
-    stage(0);
-    load();
+    stage(I0{}, 0);
+    load(I1{});     // step 1 -> set 1
     load_rows();
+    load(I0{});     // step 2 -> set 0
+    load_rows();    // tables of step 3
     __syncthreads();
     const int nsteps = b - a;
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
+    auto step = [&](auto CUR) {
+        constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
         const short* pa = sA + cur * 64 * BM;
         const short* pb = sB + cur * 64 * BN;
-        stage(cur ^ 1);  // the registers hold step s + 1
-        load();          // step s + 2
-        load_rows();     // tables of step s + 3
+        stage(std::integral_constant<int, nx>{}, nx);  // step s + 1: registers (loaded two steps ago) -> LDS[next]
+        load(std::integral_constant<int, nx>{});       // step s + 3 -> the registers just staged
+        load_rows();                                   // tables of step s + 4
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {  // k16 blocks of the step
             sk_s16x8 fa[TM], fb[TN];
@@ -951,8 +1047,18 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, fa[tm]), __builtin_bit_cast(sk_bf16x8, fb[tn]),
                                                                           acc[tm][tn], 0, 0, 0);
         }
-        __syncthreads();  // everybody has read LDS[cur] and written LDS[cur ^ 1]
+        // everybody has read LDS[cur] and written LDS[cur ^ 1]; the global loads stay in flight across the barrier (no vmcnt drain)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        step(I0{});
+        step(I1{});
     }
+    if (s < nsteps) step(I0{});
     // partial tile -> slab of this unit (natural [n][j] layout: the reduce kernel reads it coalesced)
     float* slab = slabs + (size_t)u * (BM * BN);
 #pragma unroll
@@ -1444,7 +1550,7 @@ static int64_t dw_plan_bytes(const sdt_conv_geom* g, int esz) {
     if (!dw_supported(g, esz)) return -1;
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
     const int step = esz == 4 ? 32 : 64;
-    const int64_t rows = (cdiv64(M, step) + 3) * step;
+    const int64_t rows = (cdiv64(M, step) + (esz == 4 ? 3 : 4)) * step;  // the bf16 kernel reads its row tables one step further ahead
     return (SK_HDR + rows * 4 + SK_CLS_INTS) * 4;
 }
 extern "C" int64_t sdt_convsk_dw_plan_bytes(const sdt_conv_geom* g) { return dw_plan_bytes(g, 4); }
@@ -1457,7 +1563,7 @@ static int dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes, 
     int* P = (int*)out;
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
     const int step = esz == 4 ? 32 : 64;
-    const int64_t K = cdiv64(M, step), rows = (K + 3) * step;
+    const int64_t K = cdiv64(M, step), rows = (K + (esz == 4 ? 3 : 4)) * step;
     const int bm = g.Cout % 128 == 0 ? 128 : 64, bn = (g.ntaps * g.Cin) % 128 == 0 ? 128 : 64;
     const int ncol = g.ntaps * g.Cin / bn;
     const int64_t T = (int64_t)(g.Cout / bm) * ncol;

@@ -446,11 +446,12 @@ class _SKPlan:
     """Host + device copy of a stream-K plan (built once per geometry pack and element type)."""
     __slots__ = ("host", "dev", "kind", "dtype")
 
-    def __init__(self, garr, n, rpg, bwd_groups, dev, dtype=0, reserve=0):
+    def __init__(self, garr, n, rpg, bwd_groups, dev, dtype=0, reserve=0, wpc=2):
         import ctypes as C
         lib = _lib.load()
         self.kind, self.dtype = "sk", dtype
-        check(lib.sdt_convsk_set_reserved_slots(int(reserve)))  # process-wide knob of the plan builder: set, build, reset
+        check(lib.sdt_convsk_set_reserved_slots(int(reserve)))  # process-wide knobs of the plan builder: set, build, reset
+        check(lib.sdt_convsk_set_wg_per_cu(int(wpc)))
         try:
             nbytes = lib.sdt_convsk_plan_bytes_t(garr, n, dtype)
             if nbytes <= 0:
@@ -459,6 +460,7 @@ class _SKPlan:
             check(lib.sdt_convsk_plan_build_t(garr, n, int(rpg), int(bwd_groups), dtype, dtype, C.addressof(self.host), nbytes))
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
+            check(lib.sdt_convsk_set_wg_per_cu(2))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
 
 
@@ -472,6 +474,11 @@ class _SKPlan:
 # data-parallel runs: a persistent launch that fills every slot cannot share the GPU with the long-lived workgroups of a collective -- they wait
 # for slots, or take them and strand the conv workgroups that find none (tools/debug/comm_emulation.py) -- and the gradient exchange overlaps backward
 SK_RESERVED_SLOTS = 0
+# Persistent workgroups per CU of the BACKWARD plans (fp32; experiment, bench.py --bwd-wpc): with ONE workgroup per CU (one wave per SIMD, half
+# of the register file) a weight-gradient launch on the side stream leaves room for the main stream's HBM-bound passes to run BESIDE it
+# instead of behind it.  Forward plans keep two.
+SK_WPC_DX = 2
+SK_WPC_DW = 2
 STREAMK_MIN_STEPS = 48   # input gradients: K steps (of 32) per output tile, nominal: taps * Cin / 32
 STREAMK_MIN_COUT = 128
 STREAMK_ALL_FORWARD = True
@@ -493,8 +500,9 @@ def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the stream-K plan or None when the pack does not qualify / is not
     wanted on that kernel (fp32 launches then take the 64x64 kernel of conv.hip)."""
     reserve = 0 if forward else int(SK_RESERVED_SLOTS)
+    wpc = 2 if (forward or dtype != _lib.F32) else int(SK_WPC_DX)
     key = (_geom_key(garr), n, int(rpg), int(bwd_groups), dev.index, bool(forward), reserve, dtype,
-           USE_STREAMK, STREAMK_MIN_STEPS, STREAMK_MIN_COUT, STREAMK_ALL_FORWARD)
+           USE_STREAMK, STREAMK_MIN_STEPS, STREAMK_MIN_COUT, STREAMK_ALL_FORWARD, wpc)
     plan = _SK_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
@@ -503,7 +511,7 @@ def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0):
         want = lib.sdt_convsk_supported_t(garr, n, dtype) and (dtype == _lib.BF16 or (USE_STREAMK and _sk_wanted(g0, forward)))
         if want:
             try:
-                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, dtype, reserve)
+                plan = _SKPlan(garr, n, rpg, bwd_groups, dev, dtype, reserve, wpc)
             except RuntimeError:  # e.g. too few K steps for a 256-way split (the 1-D stage), a tile without a live K step
                 plan = None
         _SK_PLANS[key] = plan
@@ -560,32 +568,37 @@ USE_STREAMK_DW = True  # weight gradients of the 2-D layers with Cout % 128 == 0
 class _SKDwPlan:
     __slots__ = ("host", "dev", "dtype")
 
-    def __init__(self, g, dev, dtype=0, reserve=0):
+    def __init__(self, g, dev, dtype=0, reserve=0, wpc=2):
         import ctypes as C
         lib = _lib.load()
         self.dtype = dtype
         check(lib.sdt_convsk_set_reserved_slots(int(reserve)))
+        check(lib.sdt_convsk_set_wg_per_cu(int(wpc)))
         try:
             nbytes = lib.sdt_convsk_dw_plan_bytes_t(g, dtype)
             self.host = (C.c_int32 * (nbytes // 4))()
             check(lib.sdt_convsk_dw_plan_build_t(g, dtype, C.addressof(self.host), nbytes))
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
+            check(lib.sdt_convsk_set_wg_per_cu(2))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
 
 
 def _sk_dw_plan(g, dev, dtype=0):
     reserve = int(SK_RESERVED_SLOTS)
-    key = (_geom_key(g), dev.index, reserve, dtype)
+    wpc = 2 if dtype != _lib.F32 else int(SK_WPC_DW)
+    key = (_geom_key(g), dev.index, reserve, dtype, wpc)
     plan = _SK_DW_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
         check(lib.sdt_convsk_set_reserved_slots(reserve))  # "supported" depends on the grid (K steps per chunk)
+        check(lib.sdt_convsk_set_wg_per_cu(wpc))
         try:
             ok = lib.sdt_convsk_dw_supported_t(g, dtype)
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
-        plan = _SKDwPlan(g, dev, dtype, reserve) if ok else None
+            check(lib.sdt_convsk_set_wg_per_cu(2))
+        plan = _SKDwPlan(g, dev, dtype, reserve, wpc) if ok else None
         _SK_DW_PLANS[key] = plan
     return plan
 
@@ -1583,7 +1596,14 @@ def mel_spectrogram(audio, basis, fb, bins=None):
     g = _geom(B=B, Hi=1, Wi=nh, Cin=HOP, Ho=1, Wo=F, Hy=1, Wy=F, Cout=2 * N_FREQ, sy=1, sx=1, osy=1, osx=1, ooy=0, oox=0,
               Tw=3, taps=[(0, 0, 0), (0, 1, 1), (0, 2, 2)])
     spec = torch.empty((B, F, 2 * N_FREQ), device=audio.device, dtype=torch.float32)
-    check(lib.sdt_conv_taps_f32(_p(hops), _p(basis), None, _p(spec), g, st))
+    math = _CONV_MATH_NOW[0]
+    if math != 0:  # the STFT keeps exact fp32 products whatever arithmetic the convolutions run in: the power mel spans 5 decades
+        check(lib.sdt_set_conv_math(0))
+    try:
+        check(lib.sdt_conv_taps_f32(_p(hops), _p(basis), None, _p(spec), g, st))
+    finally:
+        if math != 0:
+            check(lib.sdt_set_conv_math(math))
     nmel = fb.shape[1]
     mel = torch.empty((B, nmel, F), device=audio.device, dtype=torch.float32)
     check(lib.sdt_mel_fb_f32(_p(spec), _p(fb.contiguous()), _p(lo), _p(hi), _p(mel), B, F, N_FREQ, nmel, st))

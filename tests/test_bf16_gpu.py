@@ -192,7 +192,8 @@ def test_bf16_encoder_chain_follows_the_fp32_chain(ops):
     assert max(r[1] for r in rows) <= 0.25 and min(r[2] for r in rows) >= 0.97, rows
 
 
-def test_b32_bf16_storage_vs_oracle(ops):
+@pytest.mark.parametrize("math1d", ["f32", "bf16"])
+def test_b32_bf16_storage_vs_oracle(ops, math1d):
     """BASELINE config 4 at 32 clips per GPU: one forward + backward in bf16 storage against the float64 oracle (evaluated at the run's own L1
     sign decisions), at the stated bf16 bars: prediction 4e-2 of max, losses 2e-2, every gradient tensor within 40 % of its max-norm and
     with cosine similarity >= 0.97 to the float64 gradient (module docstring)."""
@@ -203,12 +204,14 @@ def test_b32_bf16_storage_vs_oracle(ops):
     state = O.make_voice2pose_state(ocfg, N_CLIPS, seed=0, code_std=0.5)
     batch = O.make_batch(B, N_CLIPS, step=3, seed=11)
     ops.set_storage("bf16")
+    ops.set_conv_math(math1d)  # 'bf16': the 1-D stage's conv products from bf16-rounded operands as well (fp32 tensors, fp32 accumulation)
     try:
         pipe, _ = _make_pipeline(cfg_name, N_CLIPS, 0.5)
         losses, results = pipe.forward_backward(batch)
         torch.cuda.synchronize()
     finally:
         ops.set_storage("f32")
+        ops.set_conv_math("f32")
     grads_hip = {k: p.grad.detach().double().cpu() for k, p in pipe.model.named_parameters() if p.grad is not None}
     s_hip = torch.sign(results["poses_pred_normalized"].detach().cpu() - batch["poses"])
     l64, p64, g64 = _oracle_grads(cfg_name, state, batch, torch.float64, l1_signs=s_hip)
@@ -219,8 +222,8 @@ def test_b32_bf16_storage_vs_oracle(ops):
         rel = ((got - ref).abs().max() / ref.abs().max()).item()
         cos = (F.cosine_similarity(got.reshape(1, -1), ref.reshape(1, -1)).item()) if ref.numel() > 1 else 1.0
         rows.append((k, rel, cos))
-    lines = ["voice2pose_sdt_bp B=32 (bf16 STORAGE) vs float64 oracle: prediction rel-max-err %.3e; losses %s" % (
-        e, {k: "%.2e" % abs(float(losses[k].detach()) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
+    lines = ["voice2pose_sdt_bp B=32 (bf16 STORAGE, 1-D stage products %s) vs float64 oracle: prediction rel-max-err %.3e; losses %s" % (
+        math1d, e, {k: "%.2e" % abs(float(losses[k].detach()) / float(l64[k]) - 1.0) for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss")})]
     lines += ["      %-60s rel-max-err %.3e  cosine %.5f" % r for r in rows]
     _dump(lines)
     assert e <= 4e-2, e

@@ -145,3 +145,25 @@ def test_differently_seeded_ranks_are_synchronised_at_construction():
             assert np.array_equal(sd0[k], sd1[k]), (cfg_name, k)
         if cfg_name == "voice2pose_s2g":  # per-rank batch statistics: the buffers do differ
             assert any(not np.array_equal(sd0[k], sd1[k]) for k in sd0 if "running_mean" in k)
+
+
+def test_emulated_collective_costs_at_most_three_percent():
+    """the one thing a single-GPU box can say about persistent conv kernels sharing the GPU with a collective.  32 spinning
+    workgroups that need a CU slot (64 KB of LDS each) for 600 us per step -- what RCCL's all-reduce kernels look like to the stream-K launches,
+    tools/debug/comm_emulation.py -- with the backward plans leaving 32 slots free (what dp.GradReducer sets): the step must not get more than
+    3 % slower, and no stream-K launch may lose a partner.  Needs the -DSDT_TUNING library (sdt_debug_spin); skipped where it was not built."""
+    import re
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(repo, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")):
+        pytest.skip("tuning library not built (python __graft_entry__.py --tuning)")
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "debug", "comm_emulation.py"), "--reserve", "32", "--us", "600", "--steps", "25"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    ms = {"on": [], "off": []}
+    for m in re.finditer(r"emulated collective (on|off)\s.*?: ([0-9.]+) ms/step", out.stdout):
+        ms[m.group(1)].append(float(m.group(2)))
+    assert len(ms["on"]) == 2 and len(ms["off"]) == 2, out.stdout
+    on, off = min(ms["on"]), min(ms["off"])
+    print("  emulated collective (32 workgroups x 600 us, reserve 32): %.3f ms/step against %.3f plain (%+.1f %%)" % (on, off, 100 * (on / off - 1)))
+    assert on <= 1.03 * off, (ms, out.stdout)

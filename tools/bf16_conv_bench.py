@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Per-layer timing of the bf16-storage conv kernels (forward with statistics, input gradient with backward statistics, weight gradient) at
+B = 32, each launch alone on the GPU: HIP events over REP back-to-back launches.  python tools/bf16_conv_bench.py [--layers L1,L5] [--rep 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from speechdrivestemplates_amd import ops  # noqa: E402
+
+LAYERS = [("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1, 1), ("L3", 40, 213, 128, 128, 4, 4, 2, 1),
+          ("L4", 20, 106, 128, 256, 3, 3, 1, 1), ("L5", 20, 106, 256, 256, 4, 4, 2, 1), ("L6", 10, 53, 256, 256, 3, 3, 1, 1),
+          ("L7", 10, 53, 256, 256, 6, 3, 1, 0)]
+
+
+def timed(fn, rep):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rep):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / rep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", default=",".join(c[0] for c in LAYERS))
+    ap.add_argument("--rep", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    a = ap.parse_args()
+    B, dev = a.batch, "cuda"
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    tot = {"fwd": 0.0, "dX": 0.0, "dW": 0.0}
+    print("%-4s %10s | %8s %8s | %8s %8s | %8s %8s   (us, TFLOP/s; %s tensors, B=%d)" % ("", "GFLOP", "fwd", "", "dX", "", "dW", "", a.dtype, B))
+    for tag, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
+        if tag not in a.layers.split(","):
+            continue
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B, Hi, Wi, Cin, generator=g).to(dt).to(dev)
+        w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev))
+        y, sums = ops.ConvStatsFn.apply(x, w, s, p, B, None)
+        gy = torch.randn(y.shape, generator=g).to(dt).to(dev)
+        geo = ops.conv_geom_for(x.shape, w, s, p)
+        gflop = 2.0 * B * geo.Ho * geo.Wo * Cout * kh * kw * Cin / 1e9
+        # the block below: a holder with the statistics of a tensor of x's shape (what the input-gradient epilogue reads back)
+        h = ops.NormBwdHolder()
+        h.y, h.mean, h.rstd = x, torch.zeros(B * Cin, device=dev), torch.ones(B * Cin, device=dev)
+        h.groups, h.slope = B, 0.2
+
+        def f_fwd():
+            ops._ARENA.begin_step(torch.device(dev, 0))
+            ops.ConvStatsFn.apply(x, w, s, p, B, None)
+
+        def f_dx():
+            ops._ARENA.begin_step(torch.device(dev, 0))
+            ops.conv_input_grad(gy, w, x.shape, s, p, h if tag != "L1" else None)
+
+        def f_dw():
+            ops.conv_weight_grad(x, gy, w, s, p)
+        t = {"fwd": timed(f_fwd, a.rep), "dX": timed(f_dx, a.rep), "dW": timed(f_dw, a.rep)}
+        for k in tot:
+            tot[k] += t[k]
+        print("%-4s %10.2f | %8.1f %8.1f | %8.1f %8.1f | %8.1f %8.1f" % (tag, gflop, t["fwd"], gflop / t["fwd"] * 1e3, t["dX"], gflop / t["dX"] * 1e3,
+                                                                  t["dW"], gflop / t["dW"] * 1e3))
+    print("sum  fwd %.0f us  dX %.0f us  dW %.0f us  = %.3f ms" % (tot["fwd"], tot["dX"], tot["dW"], sum(tot.values()) / 1e3))
+    assert not ops.streamk_error_codes()
+
+
+if __name__ == "__main__":
+    main()

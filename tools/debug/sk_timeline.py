@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--only", default="L1,L2,L4,L5")
     ap.add_argument("--roles", default="fwd,dX")
     ap.add_argument("--wpc", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16-storage kernels (forward with statistics, dX)")
     a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     lib = _lib.load()
     lib.sdt_debug_set_timeline_sk.argtypes = [ctypes.c_void_p]
     _lib.check(lib.sdt_convsk_set_wg_per_cu(a.wpc))
@@ -31,11 +33,21 @@ def main():
     for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
         if name not in a.only.split(",") or Hi == 1:
             continue
-        x = torch.randn((B, Hi, Wi, Cin), device="cuda")
+        x = torch.randn((B, Hi, Wi, Cin), device="cuda").to(dt)
         w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kh, kw), device="cuda") * 0.05))
-        y = ops.conv_forward(x, w, None, s, p)
+        if a.dtype == "bf16":
+            y = ops.ConvStatsFn.apply(x, w, s, p, B, None)[0]
+
+            def fwd():
+                ops._ARENA.begin_step(torch.device("cuda", 0))
+                return ops.ConvStatsFn.apply(x, w, s, p, B, None)
+        else:
+            y = ops.conv_forward(x, w, None, s, p)
+
+            def fwd():
+                return ops.conv_forward(x, w, None, s, p)
         gy = torch.randn_like(y)
-        fns = {"fwd": lambda: ops.conv_forward(x, w, None, s, p), "dX": lambda: ops.conv_input_grad(gy, w, x.shape, s, p)}
+        fns = {"fwd": fwd, "dX": lambda: ops.conv_input_grad(gy, w, x.shape, s, p)}
         for role in a.roles.split(","):
             for _ in range(3):
                 fns[role]()
@@ -61,7 +73,7 @@ def main():
             for k, v in ph.items():
                 print("    %-36s median %6.2f us  p90 %6.2f  max %6.2f   sum per workgroup %.1f us" % (k, np.median(v), np.percentile(v, 90), v.max(), v.sum() / (nseg > 0).sum()))
             per_step = ph["K loop"] / np.maximum(steps, 1)
-            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (4096 MFMA cycles)" % (np.median(per_step), np.median(per_step) * 2380))
+            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles)" % (np.median(per_step), np.median(per_step) * 2380, 512 if a.dtype == "bf16" else 4096))
             for kk, nm in ((0, "whole"), (1, "owner"), (2, "publish")):
                 sel = kind == kk
                 if sel.any():
