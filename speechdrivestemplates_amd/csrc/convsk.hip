@@ -86,6 +86,11 @@ template <> struct sk_is_bf16<__bf16> { static constexpr bool value = true; };
 __device__ __forceinline__ float sk_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 #define SK_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#if defined(SK_BF_ABL) && (SK_BF_ABL & 4)  // ablation (wrong results): no MFMAs in the bf16 K loop (the fragments stay live)
+#define SK_BF_MFMA(C, A, B) asm volatile("" : "+v"(C) : "v"(A), "v"(B))
+#else
+#define SK_BF_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, A), __builtin_bit_cast(sk_bf16x8, B), C, 0, 0, 0)
+#endif
 
 #ifdef SDT_TUNING
 // tools/debug/sk_timeline.py: lane 0 of every workgroup stamps the 100 MHz real-time counter at five points of each of its first 16
@@ -406,8 +411,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
 #define SK_MFMA(SET, A, B)                                                                                              \
     if constexpr (BF) {                                                                                                 \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)             \
-            acc[SET][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, A[tm]),            \
-                                                                       __builtin_bit_cast(sk_bf16x8, B[tn]), acc[SET][tm][tn], 0, 0, 0); \
+            SK_BF_MFMA(acc[SET][tm][tn], A[tm], B[tn]);                                                                 \
     } else {                                                                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                 \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                           \
@@ -501,11 +505,20 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
                     const unsigned o = ((abase[i] + (unsigned)ash) & 0x7fffffffu) | ((inval[i] << sh) & 0x80000000u);
+#if defined(SK_BF_ABL) && (SK_BF_ABL & 1)  // ablation (wrong results): no global loads in the K loop
+                    ra2[S_][i][0] = __uint_as_float(o + (unsigned)cs);
+#else
                     ra2[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, cs, 0));
+#endif
                 }
                 const unsigned bsh_eff = (unsigned)bsh + (on ? 0u : SK_OOB);
 #pragma unroll
-                for (int i = 0; i < RB; ++i) rb2[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i] + bsh_eff), cs, 0));
+                for (int i = 0; i < RB; ++i)
+#if defined(SK_BF_ABL) && (SK_BF_ABL & 1)
+                    rb2[S_][i][0] = __uint_as_float(bbase[i] + bsh_eff + (unsigned)cs);
+#else
+                    rb2[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i] + bsh_eff), cs, 0));
+#endif
                 --left;
                 const bool wrap = kc + 1 == nkc;
                 kc = wrap ? 0 : kc + 1;
@@ -515,10 +528,19 @@ __global__ __launch_bounds__(256, WPC) void convsk_kernel(const TX* __restrict__
                 constexpr int S_ = decltype(SI)::value;
                 float* wA = sA + buf * BM * SK_LDP + wofs;
                 float* wB = sB + buf * BN * SK_LDP + wofs;
+#if defined(SK_BF_ABL) && (SK_BF_ABL & 2)  // ablation (wrong results): no LDS stores in the K loop (the registers stay live through an asm use)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) asm volatile("" ::"v"(ra2[S_][i]));
+#pragma unroll
+                for (int i = 0; i < RB; ++i) asm volatile("" ::"v"(rb2[S_][i]));
+                (void)wA;
+                (void)wB;
+#else
 #pragma unroll
                 for (int i = 0; i < RA; ++i) *(f32x4*)&wA[32 * i * SK_LDP] = ra2[S_][i];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) *(f32x4*)&wB[32 * i * SK_LDP] = rb2[S_][i];
+#endif
             };
             auto step2 = [&](auto CUR) {
                 constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;

@@ -347,3 +347,63 @@ def test_streamk_weight_gradient_plan(case):
     assert np.array_equal(ri[:M, 1].astype(np.int64) & 0xffffffff, inval & 0xffffffff)
     assert np.array_equal(ri[:M, 2].astype(np.int64), np.arange(M, dtype=np.int64) * g.Cout * 4)
     assert np.all(ri[M:, 2] == -(1 << 31)) and np.all(ri[M:, 1] == -1)  # rows past M: every tap invalid, dY offset out of range
+
+
+def test_streamk_plan_rejects_tiles_without_live_steps():
+    """a k5 / stride-2 input gradient over a size that leaves trailing input rows no output position reaches puts whole tiles of a
+    parity class at ZERO live K steps (in the image-row-major order); a range that ends exactly at such a tile would never visit it and its
+    outputs -- zeros -- would stay unwritten.  The plan builder refuses such packs (ops._sk_plan then routes the launch to the 64x64 kernel of
+    conv.hip, which writes every position; tests/test_ops_gpu.py::test_input_gradient_with_unreachable_rows checks the result)."""
+    from speechdrivestemplates_amd import ops
+    lib = _lib.load()
+    arr, n, gs = ops.dx_pack(32, 10, 65, 128, 128, 5, 5, 2, 0, False)
+    assert lib.sdt_convsk_supported(arr, n) == 1
+    nbytes = lib.sdt_convsk_plan_bytes(arr, n)
+    blob = (ctypes.c_int32 * (nbytes // 4))()
+    assert lib.sdt_convsk_plan_build(arr, n, -1, 1, ctypes.addressof(blob), nbytes) != 0
+    assert b"no live K step" in lib.sdt_last_error()
+    import torch
+    assert ops._sk_plan(arr, n, -1, 1, torch.device("cuda", 0)) is None  # the host-side cache records "no plan": no GPU is touched for that
+
+
+@pytest.mark.parametrize("case", [("bf16 3x3 pad 1, 20-row images", 32, 20, 106, 128, 256, 3, 3, 1, 1, "fwd"),
+                                  ("bf16 4x4 stride 2: input gradient, 4 parity classes", 8, 40, 213, 128, 128, 4, 4, 2, 1, "dx")], ids=lambda c: c[0])
+def test_streamk_plan_in_bf16_units(case):
+    """sdt_convsk_plan_build_t(.., SDT_BF16, SDT_BF16, ..): the same plan with every byte offset in 2-byte elements and a K step of 64 channels
+    (128 bytes of an input row): row offsets, output offsets and the per-tile step counts against the brute-force statement."""
+    from speechdrivestemplates_amd import ops
+    lib = _lib.load()
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p, role = case
+    if role == "fwd":
+        g = ops.fwd_geom(B, Hi, Wi, Cin, Cout, kh, kw, s, p)
+        garr, n, gs, rpg = g, 1, [g], g.Ho * g.Wo
+    else:
+        garr, n, gs = ops.dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, s, p, False)
+        rpg = -1
+    assert lib.sdt_convsk_supported_t(garr, n, _lib.BF16) == 1
+    nbytes = lib.sdt_convsk_plan_bytes_t(garr, n, _lib.BF16)
+    blob = (ctypes.c_int32 * (nbytes // 4))()
+    assert lib.sdt_convsk_plan_build_t(garr, n, rpg, B if role == "dx" else 1, _lib.BF16, _lib.BF16, ctypes.addressof(blob), nbytes) == 0, lib.sdt_last_error()
+    P = np.frombuffer(blob, dtype=np.int32).copy()
+    assert (P[3] >> 24) & 3 == 3 and (P[3] >> 16) & 0xff == 2  # bf16 operands, bf16 output, two workgroups per CU
+    bm, rows, T = int(P[1]), int(P[8]), int(P[6])
+    rowinfo = P[P[10]:P[10] + 4 * rows].reshape(-1, 4)
+    tilecum = P[P[12]:P[12] + T + 1]
+    SK_OOB = -(1 << 31)
+    row0 = 0
+    for g in gs:
+        M = g.B * g.Ho * g.Wo
+        nmb = -(-M // bm)
+        ri = rowinfo[row0:row0 + nmb * bm]
+        real = ri[ri[:, 2] != SK_OOB]
+        assert len(real) == M
+        b, oy, ox = np.meshgrid(np.arange(g.B), np.arange(g.Ho), np.arange(g.Wo), indexing="ij")
+        yoff = (((b * g.Hy + oy * g.osy + g.ooy) * g.Wy + ox * g.osx + g.oox) * g.Cout * 2).ravel().astype(np.int64)
+        xoff = (((b * g.Hi + oy * g.sy) * g.Wi + ox * g.sx) * g.Cin * 2).ravel().astype(np.int64)
+        order = np.argsort(yoff)
+        got = real[np.argsort(real[:, 2].astype(np.int64))]
+        assert np.array_equal(got[:, 2].astype(np.int64), yoff[order]) and np.array_equal(got[:, 0].astype(np.int64) & 0xffffffff, xoff[order] & 0xffffffff)
+        row0 += nmb * bm
+    assert np.all(np.diff(tilecum) > 0) and np.all(np.diff(tilecum) % (gs[0].Cin // 64) == 0)  # live taps x (Cin / 64) steps per tile
+    cls = P[P[14]:P[14] + 11 + 3 * 20]
+    assert cls[5] == gs[0].Cin // 64 and cls[11 + 1] == (gs[0].dy[1] * gs[0].Wi + gs[0].dx[1]) * gs[0].Cin * 2  # K steps per tap, tap shift in bytes

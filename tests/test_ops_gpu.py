@@ -1131,3 +1131,29 @@ def test_streamk_lost_partner_is_loud(ops):
     y, ref = _streamk_launch(ops, seed=4)
     check("stream-K forward after the injected failure", ops.cf_view(y), ref, 3e-6)
     assert ops.streamk_error_codes() == {}
+
+
+def test_input_gradient_with_unreachable_rows(ops):
+    """k5 / stride 2 / no padding over 10 x 65 inputs: the last input row of every image is reached by no output position, whole tiles of a parity
+    class have no live K step, the stream-K plan builder refuses the pack (tests/test_geometry.py) and the 64x64 kernel computes the gradient --
+    zeros included -- against float64."""
+    B, Hi, Wi, Cin, Cout, k, s, p = 32, 10, 65, 128, 128, 5, 2, 0
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(2, Cin, Hi, Wi, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) * 0.02
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w, None, s, p)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    gyd = torch.zeros((B,) + tuple(y.shape[2:]) + (Cout,), device=DEV)
+    gyd[:2] = ops.cl(gy.float()).to(DEV)
+    wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
+    arr, n, _gs = ops.dx_pack(B, Hi, Wi, Cin, Cout, k, k, s, p, False)
+    assert ops._sk_plan(arr, n, -1, 1, gyd.device) is None
+    dx = torch.full((B, Hi, Wi, Cin), float("nan"), device=DEV)  # poison: torch.empty inside the op could hide an unwritten row behind stale zeros
+    del dx
+    dx = ops.conv_input_grad(gyd, wd, (B, Hi, Wi, Cin), s, p)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all()
+    check("k5 s2 dX (items 0, 1)", ops.cf_view(dx[:2]), xr.grad, 3e-6)
+    assert float(dx[2:].abs().max()) == 0.0 and float(dx[:, Hi - 1].abs().max()) <= float(xr.grad[:, :, Hi - 1].abs().max()) + 1e-6

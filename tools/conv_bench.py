@@ -31,22 +31,17 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--roles", default="fwd,dX,dW")
     ap.add_argument("--math", default="f32", help="f32 | bf16 | bf16x3 | bf16x6 (forward / input-gradient kernels)")
-    ap.add_argument("--tab", type=int, default=-1, help="-1: off; 0 / 8: the plan-driven 64x64 kernel for every 2-D launch, accumulation chunk 0 / 8 K steps")
     ap.add_argument("--oob", action="store_true", help="experiment: the stream-K kernel's A / B loads all out of range (zeros, no memory traffic): the loop's issue-bound rate")
     ap.add_argument("--streamk", type=int, default=2, help="0: the 64x64 kernel of conv.hip; 1 / 2: the persistent stream-K kernel with 1 / 2 workgroups per CU")
     a = ap.parse_args()
     ops.USE_STREAMK = a.streamk > 0
     ops.USE_STREAMK_DW = a.streamk > 0
-    ops.USE_TAB = a.tab >= 0
     if os.environ.get("SDT_SK_ALL") == "1":  # every 2-D layer through the stream-K kernel (tool-only switch)
         ops.STREAMK_MIN_STEPS, ops.STREAMK_MIN_COUT = 1, 64
-    if a.tab >= 0:
-        ops.TAB_CHUNK = a.tab
-        ops.USE_STREAMK = False
     if a.oob:
         def _oob_launch(plan, x4, ws_w, bias, y, stats, nb, st):
             lib = ops._lib.load()
-            wsb, epoch = ops._sk_workspace(y.device, st)
+            wsb, epoch = ops._sk_workspace(y.device, st), 1
             return lib.sdt_convsk_f32(ops._p(x4), ops._p(ws_w), ops._p(bias), ops._p(y), plan.host, ops._p(plan.dev), ops._p(wsb), epoch, ops._p(stats), nb,
                                       16, 16, y.numel() * 4, st)
         ops._sk_launch = _oob_launch

@@ -35,7 +35,6 @@ def main():
         x = torch.randn((B, Hi, Wi, Cin), device="cuda")
         w = torch.nn.Parameter(ops.to_weight_layout(torch.randn((Cout, Cin, kh, kw), device="cuda") * 0.05))
         ops.USE_STREAMK = False
-        ops.USE_TAB = False
         y_old = ops.conv_forward(x, w, None, s, p)
         gy = torch.randn_like(y_old)
         dx_old = ops.conv_input_grad(gy, w, x.shape, s, p)
@@ -45,7 +44,6 @@ def main():
         dw_old = w.grad.clone()
         ops.USE_STREAMK_DW = True
         ops.USE_STREAMK = MODE == 'sk'
-        ops.USE_TAB = MODE == 'tab'
         y1 = ops.conv_forward(x, w, None, s, p)
         y2 = ops.conv_forward(x, w, None, s, p)
         dx1 = ops.conv_input_grad(gy, w, x.shape, s, p)

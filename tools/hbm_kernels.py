@@ -29,7 +29,7 @@ def algorithmic_bytes(name, rows_elems):
         return 2 * 4 * n            # read y, write z
     if name.startswith("colnorm_apply_bwd"):
         return 3 * 4 * n            # read dz, y; write dy
-    if name.startswith("colstats_kernel<true>") or name.startswith("colstats_kernel<1"):
+    if name.startswith("colstats_kernel<true") or name.startswith("colstats_kernel<1"):
         return 2 * 4 * n            # read dz, y
     if name.startswith("colstats_kernel"):
         return 4 * n                # read y

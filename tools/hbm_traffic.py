@@ -30,7 +30,9 @@ def per_kernel(path, counter):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         # the three epilogue instantiations (EPI = plain / + forward statistics / + backward statistics) are one kernel for bench.py
         name = re.sub(r"^(conv_taps_kernel<\d+, \d+, \w+, \d+), \d+>", r"\1>", name)
-        name = re.sub(r"^(convsk_kernel<\d+, \d+), \d+, \d+>", r"\1>", name)  # <BM, BN, EPI, workgroups per CU> -> bench.py's name
+        # <TX, TY, BM, BN, EPI, workgroups per CU> -> bench.py's name (the bf16 instantiations stay mangled: the demangler does not know DF16b)
+        name = re.sub(r"^convsk_kernel<float, float, (\d+, \d+), \d+, \d+>", r"convsk_kernel<\1>", name)
+        name = re.sub(r"^_Z13convsk_kernelIDF16bDF16bLi(\d+)ELi(\d+)E.*", r"convsk_kernel<\1, \2> bf16", name)
         tot[name] += float(r["Counter_Value"]) * 1024.0
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
