@@ -294,6 +294,36 @@ int sdt_resize_concat_bwd_f32(const float* dout, const int64_t* idx, float* dx, 
 int sdt_upsample_add_fwd_f32(const float* prev, const float* skip, float* out, int B, int Ti, int To, int C, void* stream);
 int sdt_upsample_add_bwd_f32(const float* dout, float* dprev, int B, int Ti, int To, int C, void* stream);
 
+/* ---- The generator's Conv1d stage as one persistent launch per direction (csrc/chain1d.hip) ------------------------------------------
+ * A CHAIN of ConvNormRelu('1d', norm='IN') blocks (building_blocks.py:31-51: Conv1d without bias -> normalisation of every (clip, frame) over
+ * the channels -> LeakyReLU) with the wiring of UNet_1D + the decoder stack (generator.py:53-85,96-103): a block's input is the external
+ * tensor (block 0), the activated output of an earlier block, or F.interpolate(earlier block, Ti, 'linear') + the activated output of another
+ * one (generator.py:79-83).  Every block has 256 output channels; <= 64 frames per clip; Cin a multiple of 32 (<= 320, block 0 only: the
+ * others read 256-channel block outputs).  Only the RAW conv outputs y travel between blocks; normalisation and activation are applied by
+ * the consumer on load.  8 workgroups own a clip (see the file header); the launch needs 64 * ceil(B / 8) co-resident workgroups.           */
+enum { SDT_CHAIN_PLAIN = 0, SDT_CHAIN_NORM = 1, SDT_CHAIN_UPADD = 2 };
+typedef struct sdt_chain1d_layer {
+    int32_t Ti, To, Cin, k, stride, pad;
+    int32_t in_mode;        /* SDT_CHAIN_PLAIN: x0 | _NORM: act(norm(y[src_a])) | _UPADD: upsample(act(norm(y[src_a])), Ti) + act(norm(y[src_b])) */
+    int32_t src_a, src_b;   /* indices of earlier blocks (-1: unused) */
+    int32_t reserved;
+    const float* w;         /* (256, k, Cin) weights */
+    const float* wt;        /* (Cin, k, 256) mirror (backward only) */
+    float* y;               /* (B, To, 256) raw conv output: written by forward, read by backward */
+    float* x;               /* (B, Ti, 256) the conv's input as consumed, for the weight-gradient launch (NULL: not wanted; unused for block 0) */
+    float* dy;              /* (B, To, 256) backward: gradient of y (the weight gradient's other operand) */
+    float* dx;              /* (B, Ti, Cin) backward: gradient of the conv's input */
+} sdt_chain1d_layer;
+/* 1 when the current device can hold the launch (every cluster co-resident), else 0. */
+int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B);
+/* zout (B, To_last, 256) = act(norm(y[nlayers-1])).  counters: >= B zero-initialised uint32 (zero again when the launch ends); err: one uint32
+ * that a launch sets non-zero when a workgroup gave up waiting for its cluster (sdt_convsk_set_spin_limit) -- results are then invalid. */
+int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* x0, float* zout, int B, float slope, float eps,
+                        void* counters, void* err, void* stream);
+/* gz (B, To_last, 256): gradient of zout.  Writes dy of every block and dx of every block (block 0 only when need_dx0). */
+int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* gz, int B, float slope, float eps, int need_dx0,
+                        void* counters, void* err, void* stream);
+
 /* nn.L1Loss(reduction='none')(pred,gt)*lambda .mean() (voice2pose.py:141-142). partial: >=256 doubles. */
 int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n, float lambda, double* partial, float* loss, void* stream);
 int sdt_l1_loss_bwd_f32(const float* pred, const float* gt, const float* gout, int64_t n, float lambda, float* dpred, void* stream);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDT_HIP_LIB: developer tools only (tools/conv_bench.py points it at the -DSDT_TUNING build); the package itself never sets it
 LIB_PATH = os.environ.get("SDT_HIP_LIB") or os.path.join(_HERE, "lib", "libsdt_hip.so")
 MAX_TAPS = 20
-ABI_VERSION = 2  # sdt_abi_version() of the library this binding was written against
+ABI_VERSION = 3  # sdt_abi_version() of the library this binding was written against
 
 
 class ConvGeom(C.Structure):
@@ -33,6 +33,14 @@ class WtDesc(C.Structure):
                 ("cin", C.c_int32), ("tile_begin", C.c_int32)]
 
 
+class ChainLayer(C.Structure):
+    """Mirror of ``sdt_chain1d_layer`` (include/sdt_hip.h)."""
+    _fields_ = [("Ti", C.c_int32), ("To", C.c_int32), ("Cin", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("in_mode", C.c_int32), ("src_a", C.c_int32), ("src_b", C.c_int32), ("reserved", C.c_int32),
+                ("w", C.c_void_p), ("wt", C.c_void_p), ("y", C.c_void_p), ("x", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p)]
+
+
+CHAIN_PLAIN, CHAIN_NORM, CHAIN_UPADD = 0, 1, 2
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _G = C.POINTER(ConvGeom)
 
@@ -69,6 +77,9 @@ SIGNATURES = {
     "sdt_resize_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_resize_concat_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_upsample_add_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sdt_chain1d_supported": [C.POINTER(ChainLayer), _i, _i],
+    "sdt_chain1d_fwd_f32": [C.POINTER(ChainLayer), _i, _p, _p, _i, _f, _f, _p, _p, _p],
+    "sdt_chain1d_bwd_f32": [C.POINTER(ChainLayer), _i, _p, _i, _f, _f, _i, _p, _p, _p],
     "sdt_upsample_add_bwd_f32": [_p, _p, _i, _i, _i, _i, _p],
     "sdt_l1_loss_fwd_f32": [_p, _p, _i64, _f, _p, _p, _p],
     "sdt_l1_loss_bwd_f32": [_p, _p, _p, _i64, _f, _p, _p],

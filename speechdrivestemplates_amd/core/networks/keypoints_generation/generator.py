@@ -86,6 +86,19 @@ class SequenceGeneratorCNN(nn.Module):
             *[ConvNormRelu('1d', 256, 256, downsample=False, norm=norm, leaky=leaky) for _ in range(4)],
             make_head(256, cfg.DATASET.NUM_LANDMARKS * 2, 1))
 
+    def _chain(self):
+        """(spec, weights, slope) of the sixteen Conv1d blocks as ops.Chain1dFn takes them -- e0..e6, d5..d1 (generator.py:70-85), the four
+        decoder blocks -- or None when a block is not ConvNormRelu('1d', norm='IN') (BatchNorm chains keep the per-block kernels)."""
+        from .... import _lib
+        blocks = [getattr(self.unet, 'e%d' % i) for i in range(7)] + [getattr(self.unet, 'd%d' % i) for i in (5, 4, 3, 2, 1)] + list(self.decoder)[:4]
+        if any(b.conv_type != '1d' or b.norm_type != 'IN' or b.slope != blocks[0].slope for b in blocks):
+            return None
+        wiring = [(_lib.CHAIN_PLAIN, -1, -1)] + [(_lib.CHAIN_NORM, i - 1, -1) for i in range(1, 7)]
+        wiring += [(_lib.CHAIN_UPADD, 6 + j, 5 - j) for j in range(5)]  # d5 = upsample(e6) + e5, d4 = upsample(d5) + e4, ...
+        wiring += [(_lib.CHAIN_NORM, 11 + j, -1) for j in range(4)]
+        spec = tuple((b.conv.kernel_size[0], b.stride, b.padding) + w for b, w in zip(blocks, wiring))
+        return spec, [b.conv.weight for b in blocks], blocks[0].slope
+
     def forward(self, x, num_frames, code=None):
         """mel (B,80,F), code (B,D)|None -> poses (B,num_frames,2,K), generator.py:106-117."""
         num_frames = int(num_frames)
@@ -105,9 +118,14 @@ class SequenceGeneratorCNN(nn.Module):
         use_code = self.cfg.VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION is not None
         ops.stage_mark("g1d_fwd:begin")
         h = ops.ResizeConcatFn.apply(feat, code if use_code else None, num_frames)  # (B,T,256[+D])
-        h = self.unet.forward_cl(h)
-        for block in list(self.decoder)[:4]:
-            h = block.forward_cl(h)
+        chain = self._chain()
+        if chain is not None and ops.chain1d_usable(h, chain[0], chain[1]):
+            # U-Net + decoder blocks in one persistent launch per direction (csrc/chain1d.hip)
+            h = ops.Chain1dFn.apply(h, chain[0], chain[2], *chain[1])
+        else:
+            h = self.unet.forward_cl(h)
+            for block in list(self.decoder)[:4]:
+                h = block.forward_cl(h)
         h = conv_head(h, self.decoder[4])  # (B,T,2K): channel c = xy*K + k, i.e. already the (B,T,2,K) memory layout
         ops.stage_mark("g1d_fwd:end")
         if ops.STAGES is not None and h.requires_grad:

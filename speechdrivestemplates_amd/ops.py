@@ -539,6 +539,10 @@ def streamk_error_codes():
         code = int(ws[_SK_ERR_WORD].item())
         if code:
             out[key] = code
+    for dev, ws in _CHAIN_WS.items():  # the Conv1d chain launches: 0x40000000 + block (+ 64: backward) whose cluster never completed
+        code = int(ws[_CHAIN_ERR].item())
+        if code:
+            out[(dev, "chain1d")] = code
     return out
 
 
@@ -1391,6 +1395,151 @@ class UpsampleAddFn(torch.autograd.Function):
         dprev = torch.empty((B, Ti, C), device=g.device, dtype=torch.float32)
         check(_lib.load().sdt_upsample_add_bwd_f32(_p(g), _p(dprev), B, Ti, To, C, _stream()))
         return dprev, (g if ctx.needs_input_grad[1] else None), None
+
+
+# ---------------------------------------------------------------------------------------------
+# The generator's Conv1d stage as ONE persistent launch per direction (csrc/chain1d.hip): 8 workgroups per clip, raw conv outputs handed from
+# block to block inside the launch, normalisation + activation (+ upsampling + skip) applied by the consumer on load.
+CHAIN1D = True
+_CHAIN_WS = {}  # device index -> int32 [64 cluster counters | error word]
+_CHAIN_ERR = 64
+
+
+def _chain_ws(dev):
+    ws = _CHAIN_WS.get(dev.index)
+    if ws is None:
+        ws = _CHAIN_WS[dev.index] = torch.zeros(_CHAIN_ERR + 64, device=dev, dtype=torch.int32)  # zero-filled once: a launch leaves its counters at zero
+    return ws
+
+
+def chain_blocks(spec, T0, Cin0):
+    """[(Ti, To, Cin, k, stride, pad, in_mode, src_a, src_b)] of a chain whose blocks are ``spec`` = ((k, stride, pad, in_mode, src_a, src_b), ...)
+    fed with (B, T0, Cin0); raises ValueError when the wiring is inconsistent."""
+    out = []
+    for l, (k, stride, pad, mode, sa, sb) in enumerate(spec):
+        if mode == _lib.CHAIN_PLAIN:
+            Ti, Cin = T0, Cin0
+        elif mode == _lib.CHAIN_NORM:
+            Ti, Cin = out[sa][1], 256
+        else:
+            Ti, Cin = out[sb][1], 256
+        To = out_size(Ti, k, stride, pad)
+        if To < 1:
+            raise ValueError("block %d of the chain has no output frames" % l)
+        out.append((Ti, To, Cin, k, stride, pad, mode, sa, sb))
+    return out
+
+
+def chain1d_usable(h, spec, weights):
+    """The launch exists for this chain on this device: fp32 (B, T <= 64, Cin % 32 == 0) input, every block 256 wide with its weight in the kernel
+    layout, every 8-workgroup cluster co-resident (B <= 32 on MI355X)."""
+    if not (CHAIN1D and h.is_cuda and h.dtype == torch.float32 and h.dim() == 3 and _CONV_MATH_NOW[0] == 0):
+        return False
+    B, T0, Cin0 = h.shape
+    if T0 > 64 or Cin0 % 32 or Cin0 > 320 or len(spec) > 20 or len(spec) != len(weights):
+        return False
+    try:
+        blocks = chain_blocks(spec, T0, Cin0)
+    except (ValueError, IndexError):
+        return False
+    for (Ti, To, Cin, k, stride, pad, mode, sa, sb), w in zip(blocks, weights):
+        if w.dim() != 3 or tuple(w.shape) != (256, Cin, k) or weight_storage(w).data_ptr() != w.data_ptr() or w.dtype != torch.float32:
+            return False
+    tab = (_lib.ChainLayer * len(blocks))(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, 1, 0, 1, 0, 0, 0)
+                                            for (Ti, To, Cin, k, stride, pad, mode, sa, sb) in blocks])
+    return bool(_lib.load().sdt_chain1d_supported(tab, len(blocks), B))
+
+
+def _chain_launch(name, kind, flops, nbytes, call):
+    if PROFILER is None:
+        check(call())
+        return
+    e0, e1 = PROFILER.event(), PROFILER.event()
+    e0.record()
+    check(call())
+    e1.record()
+    PROFILER.records.append((name, kind, False, flops, nbytes, e0, e1))
+
+
+class Chain1dFn(torch.autograd.Function):
+    """A chain of ConvNormRelu('1d', norm='IN') blocks -- UNet_1D + the decoder stack, generator.py:53-85,96-103 -- in one launch per direction.
+    ``spec``: ((k, stride, pad, in_mode, src_a, src_b), ...) per block (include/sdt_hip.h sdt_chain1d_layer); ``h`` (B, T, Cin) feeds block 0;
+    returns the activated output of the last block (B, T_last, 256).  Weight gradients are accumulated into ``.grad`` by the usual launches
+    (deferred to the side stream inside a train step), from the conv inputs / raw-output gradients the two launches leave in HBM."""
+
+    @staticmethod
+    def forward(ctx, h, spec, slope, *weights):
+        _req_cuda(h, *weights)
+        lib = _lib.load()
+        h = h.contiguous()
+        B, T0, Cin0 = h.shape
+        blocks = chain_blocks(spec, T0, Cin0)
+        n = len(blocks)
+        dev = h.device
+        want_grad = any(ctx.needs_input_grad)  # (grad mode is off inside forward(): needs_input_grad is what says a backward may follow)
+        ybuf = torch.empty(B * 256 * sum(b[1] for b in blocks), device=dev, dtype=torch.float32)
+        xbuf = torch.empty(B * 256 * sum(b[0] for b in blocks[1:]), device=dev, dtype=torch.float32) if want_grad else None
+        ys, xs, yo, xo = [], [None], 0, 0
+        for l, b in enumerate(blocks):
+            ys.append(ybuf[yo:yo + B * b[1] * 256].view(B, b[1], 256))
+            yo += B * b[1] * 256
+            if l:
+                xs.append(xbuf[xo:xo + B * b[0] * 256].view(B, b[0], 256) if want_grad else None)
+                xo += B * b[0] * 256
+        zout = torch.empty((B, blocks[-1][1], 256), device=dev, dtype=torch.float32)
+        tab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(weight_storage(w)), None, _p(ys[l]),
+                                                      _p(xs[l]) if l else None, None, None)
+                                      for l, ((Ti, To, Cin, k, stride, pad, mode, sa, sb), w) in enumerate(zip(blocks, weights))])
+        ws = _chain_ws(dev)
+        flops = sum(2.0 * B * To * 256 * k * Cin for (Ti, To, Cin, k, *_r) in blocks)
+        nbytes = 4.0 * (h.numel() + zout.numel() + sum(w.numel() for w in weights))
+        st = _stream()
+        _chain_launch("chain1d_fwd_kernel", "fwd", flops, nbytes,
+                      lambda: lib.sdt_chain1d_fwd_f32(tab, n, _p(h), _p(zout), B, float(slope), BN_EPS, ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
+        ctx.blocks, ctx.slope, ctx.ys, ctx.xs = blocks, float(slope), ys, xs
+        ctx.save_for_backward(h, ybuf, xbuf, *weights)
+        return zout
+
+    @staticmethod
+    def backward(ctx, gz):
+        h, ybuf, xbuf = ctx.saved_tensors[:3]
+        weights = ctx.saved_tensors[3:]
+        lib = _lib.load()
+        blocks, ys, xs = ctx.blocks, ctx.ys, ctx.xs
+        n = len(blocks)
+        B = h.shape[0]
+        dev = h.device
+        gz = gz.contiguous()
+        st = _stream()
+        need_dx0 = bool(ctx.needs_input_grad[0])
+        dybuf = torch.empty_like(ybuf)
+        dxbuf = torch.empty(B * sum(b[0] * b[2] for b in blocks), device=dev, dtype=torch.float32)
+        dys, dxs, yo, xo, wts = [], [], 0, 0, []
+        for l, (b, w) in enumerate(zip(blocks, weights)):
+            Ti, To, Cin, k = b[0], b[1], b[2], b[3]
+            dys.append(dybuf[yo:yo + B * To * 256].view(B, To, 256))
+            yo += B * To * 256
+            dxs.append(dxbuf[xo:xo + B * Ti * Cin].view(B, Ti, Cin))
+            xo += B * Ti * Cin
+            wt = None
+            if l or need_dx0:
+                wt = WeightMirrors.lookup(w)
+                if wt is None:
+                    wt = torch.empty((Cin, k, 256), device=dev, dtype=torch.float32)
+                    check(lib.sdt_weight_transpose_f32(_p(weight_storage(w)), _p(wt), 256, k, Cin, st))
+            wts.append(wt)
+        tab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(weight_storage(w)), _p(wts[l]), _p(ys[l]),
+                                                      _p(xs[l]) if l else None, _p(dys[l]), _p(dxs[l]))
+                                      for l, ((Ti, To, Cin, k, stride, pad, mode, sa, sb), w) in enumerate(zip(blocks, weights))])
+        ws = _chain_ws(dev)
+        flops = sum(2.0 * B * To * 256 * k * Cin for l, (Ti, To, Cin, k, *_r) in enumerate(blocks) if l or need_dx0)
+        nbytes = 4.0 * (gz.numel() + ybuf.numel() + dybuf.numel() + sum(w.numel() for w in weights))
+        _chain_launch("chain1d_bwd_kernel", "dX", flops, nbytes,
+                      lambda: lib.sdt_chain1d_bwd_f32(tab, n, _p(gz), B, ctx.slope, BN_EPS, int(need_dx0), ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
+        for l, (b, w) in enumerate(zip(blocks, weights)):  # weight gradients: the per-block launches, deferred to the side stream inside a train step
+            if w.requires_grad:
+                _conv_backward(h if l == 0 else xs[l], w, None, dys[l], b[4], b[5], False)
+        return (dxs[0] if need_dx0 else None, None, None) + (None,) * n
 
 
 class L1LossFn(torch.autograd.Function):

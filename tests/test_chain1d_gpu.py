@@ -1,0 +1,126 @@
+"""The generator's Conv1d stage as one persistent launch per direction (csrc/chain1d.hip, ops.Chain1dFn) against the per-block kernels it
+replaces (ops.ConvRowNormFn + ops.UpsampleAddFn: conv -> split-K reduction + normalisation -> LeakyReLU per block), which are themselves held to
+the oracle by tests/test_ops_gpu.py and the trajectory tests.  Same seeded inputs, forward output, input gradient and all sixteen weight
+gradients; fp32 both sides, only the summation order differs (K split over 2 or 4 waves here, over 4 workgroups + slabs there)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SLOPE = 0.2
+TOL = 2e-5  # relative to the tensor's largest magnitude; measured 1e-6 .. 4e-6 (see the calibrated margins)
+
+
+def _wiring():
+    from speechdrivestemplates_amd import _lib
+    w = [(_lib.CHAIN_PLAIN, -1, -1)] + [(_lib.CHAIN_NORM, i - 1, -1) for i in range(1, 7)]
+    w += [(_lib.CHAIN_UPADD, 6 + j, 5 - j) for j in range(5)]
+    w += [(_lib.CHAIN_NORM, 11 + j, -1) for j in range(4)]
+    down = [False, False, True, True, True, True, True] + [False] * 9
+    return tuple(((4, 2, 1) if d else (3, 1, 1)) + x for d, x in zip(down, w))
+
+
+def _weights(cin0, seed):
+    from speechdrivestemplates_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    ws = []
+    for l, (k, s, p, mode, sa, sb) in enumerate(_wiring()):
+        cin = cin0 if l == 0 else 256
+        w = torch.randn((256, cin, k), generator=g) * (2.0 / (cin * k)) ** 0.5
+        ws.append(torch.nn.Parameter(ops.to_weight_layout(w.cuda())))
+    return ws
+
+
+def _per_block(h, ws, slope=SLOPE):
+    """generator.py:70-85 + the decoder blocks through the per-block autograd functions"""
+    from speechdrivestemplates_amd import ops
+    spec = _wiring()
+    x, skips = h, []
+    for i in range(7):
+        x = ops.ConvRowNormFn.apply(x, ws[i], spec[i][1], spec[i][2], slope)
+        skips.append(x)
+    for j, i in enumerate((5, 4, 3, 2, 1)):
+        x = ops.ConvRowNormFn.apply(ops.UpsampleAddFn.apply(x, skips[i], skips[i].shape[1]), ws[7 + j], 1, 1, slope)
+    for j in range(4):
+        x = ops.ConvRowNormFn.apply(x, ws[12 + j], 1, 1, slope)
+    return x
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _run_both(B, T, cin0, slope):
+    from speechdrivestemplates_amd import ops
+    torch.manual_seed(B * 1000 + T)
+    ws_a, ws_b = _weights(cin0, 7), _weights(cin0, 7)
+    h_a = torch.randn((B, T, cin0), device="cuda", requires_grad=True)
+    h_b = h_a.detach().clone().requires_grad_(True)
+    gz = torch.randn((B, T, 256), device="cuda")
+    assert ops.chain1d_usable(h_a, _wiring(), ws_a)
+    ops.begin_step(torch.device("cuda", 0))
+    z_a = ops.Chain1dFn.apply(h_a, _wiring(), slope, *ws_a)
+    z_a.backward(gz)
+    ops.join_side_stream()
+    z_b = _per_block(h_b, ws_b, slope)
+    z_b.backward(gz)
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert not ops.streamk_error_codes()
+    return z_a.detach(), z_b.detach(), h_a.grad, h_b.grad, ws_a, ws_b
+
+
+# LeakyReLU'(u) jumps at u = 0: an element whose normalised value is within rounding of zero takes slope 1 in one implementation and 0.2 in the
+# other, and that clip's gradients then differ by ~1e-2 of their scale although both are correct to fp32 (about 2 such elements are expected among
+# the 8.4 M activations of B = 32; which clips is a deterministic function of the seed).  So the tight comparison of ALL gradients at B = 32 uses
+# slope 1 (no kink: exercises every GEMM, the normalisation backward, the gather of the output gradients), the slope-0.2 cases run at the sizes
+# whose seeded data has no such element, and the B = 32 slope-0.2 case compares clip by clip and lets at most 3 clips differ by a kink's worth.
+@pytest.mark.parametrize("B,T,cin0,slope", [(3, 64, 288, SLOPE), (32, 64, 288, 1.0), (8, 64, 256, SLOPE), (5, 32, 288, SLOPE)])
+def test_chain_matches_the_per_block_kernels(B, T, cin0, slope):
+    from conftest import calibrated_bound
+    from speechdrivestemplates_amd import ops
+    z_a, z_b, dh_a, dh_b, ws_a, ws_b = _run_both(B, T, cin0, slope)
+
+    def check(name, got, ref, tol=TOL):
+        err = _rel(got, ref)
+        assert err <= calibrated_bound(name, err, tol), "%s: %.3e" % (name, err)
+
+    check("z", z_a, z_b)
+    check("dh", dh_a, dh_b)
+    for l, (wa, wb) in enumerate(zip(ws_a, ws_b)):
+        check("dW[%d]" % l, ops.weight_storage(wa.grad), ops.weight_storage(wb.grad))
+
+
+def test_chain_full_batch_with_the_leaky_slope():
+    z_a, z_b, dh_a, dh_b, _wa, _wb = _run_both(32, 64, 288, SLOPE)
+    assert _rel(z_a, z_b) <= TOL
+    scale = dh_b.abs().max()
+    per_clip = (dh_a - dh_b).abs().amax(dim=(1, 2)) / scale
+    kinked = per_clip > TOL
+    assert int(kinked.sum()) <= 3, "clips whose input gradient differs: %s" % per_clip.tolist()
+    assert float(per_clip.max()) <= 0.1, "more than an activation kink's worth: %s" % per_clip.tolist()
+
+
+def test_chain_leaves_its_counters_at_zero_and_replays():
+    """two launches back to back on the same counters (what a hipGraph replay does): the second sees them lowered"""
+    from speechdrivestemplates_amd import ops
+    ws = _weights(288, 3)
+    h = torch.randn((32, 64, 288), device="cuda")
+    with torch.no_grad():
+        z1 = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+        z2 = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2)
+    assert int(ops._chain_ws(h.device).abs().sum().item()) == 0
+
+
+def test_chain_without_an_input_gradient():
+    from speechdrivestemplates_amd import ops
+    ws = _weights(288, 5)
+    h = torch.randn((4, 64, 288), device="cuda")
+    ops.begin_step(torch.device("cuda", 0))
+    z = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+    z.sum().backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in ws)
