@@ -128,11 +128,16 @@ __device__ __forceinline__ void ch_arrive(gu32* cnt, unsigned total) {
     }
 }
 
+
 // ---- weight streaming -----------------------------------------------------------------------
 // A workgroup's 32 weight columns are streamed in chunks of KC floats per column.  The stream does not depend on the chain, so the first CH_D
 // chunks of a block are requested BEFORE the workgroup waits for its cluster and stages its input (the wait and the staging hide the latency),
 // and CH_D chunks stay in flight in registers throughout (measured with one chunk in flight: 2.2 us per chunk whatever the MFMA count).
+// Every access of the stream is unconditional (a thread without a vector of the chunk re-reads the column's first floats and parks them in a
+// dummy LDS slot; requests past the last chunk re-read the last one): the K loop's chunks are single basic blocks, which is what lets
+// sched_group_barrier spread the feeding instructions between the MFMAs.
 #define CH_D 4
+#define CH_DUMMY (2 * CH_WBUF)  // [256][4] floats behind the two ring slots
 struct ch_wstream {
     const float* Wcol;
     int K, KC, nch;
@@ -149,17 +154,21 @@ __device__ __forceinline__ void ch_w_setup(ch_wstream& S, const float* Wcol, int
         const int idx = tid + 256 * p;
         S.ok[p] = idx < nvec;
         const int col = idx / kv, v = idx - col * kv;
-        S.goff[p] = col * K + 4 * v;
+        S.goff[p] = S.ok[p] ? col * K + 4 * v : 0;
         S.loff[p] = col * WS + 4 * v;
     }
 }
 template <int SLOT>
 __device__ __forceinline__ void ch_w_issue(ch_wstream& S, int c) {
-    if (c < S.nch) {
+    const int cidx = min(c, S.nch - 1) * S.KC;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (S.ok[p]) S.rg[SLOT][p] = *(const f32x4*)(S.Wcol + S.goff[p] + c * S.KC);
-    }
+    for (int p = 0; p < 4; ++p) S.rg[SLOT][p] = *(const f32x4*)(S.Wcol + S.goff[p] + (S.ok[p] ? cidx : 0));
+}
+template <int SLOT>
+__device__ __forceinline__ void ch_w_to_lds(ch_wstream& S, float* wb, int buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(f32x4*)(wb + (S.ok[p] ? buf * CH_WBUF + S.loff[p] : CH_DUMMY + 4 * tid)) = S.rg[SLOT][p];
 }
 __device__ __forceinline__ void ch_w_prefetch(ch_wstream& S) {
     ch_w_issue<0>(S, 0);
@@ -168,52 +177,124 @@ __device__ __forceinline__ void ch_w_prefetch(ch_wstream& S) {
     ch_w_issue<3>(S, 3);
 }
 
+#define CH_SGB(mask) __builtin_amdgcn_sched_group_barrier(mask, 1, 0)
+// tools/debug/r04_chain_ablation.sh (wrong results by design, never in the product library): what the K loop costs without 1 its MFMAs,
+// 2 the weight loads of later chunks, 4 the LDS stores of the next chunk
+#if defined(CH_ABL) && (CH_ABL & 1)
+#define CH_MFMA(C, A, B) asm volatile("" : "+v"(C) : "v"(A), "v"(B))
+#else
+#define CH_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
+#endif
+#if defined(CH_ABL) && (CH_ABL & 2)
+#define CH_ABL_LOAD(x)
+#else
+#define CH_ABL_LOAD(x) x
+#endif
+#if defined(CH_ABL) && (CH_ABL & 4)
+#define CH_ABL_STORE(x)
+#else
+#define CH_ABL_STORE(x) x
+#endif
+
+__device__ __forceinline__ void ch_barrier() {  // LDS traffic of this wave done, then the workgroup barrier (no vmcnt wait: the weight stream stays in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Chunk C of a K loop that is FULLY unrolled (NCH chunks): a loop's back edge made the compiler wait for vmcnt(0) in front of every LDS store of
+// the stream -- for the chunk requested one iteration ago instead of CH_D ago (tools/debug/r04_chain_ablation.sh: 0.27 us per chunk).  In
+// straight-line code it counts the requests exactly.  Program order = the issue order asked of the scheduler: the chunk's first fragment reads,
+// then per group of four MFMAs two fragment reads of a later group and two feeding instructions (LDS stores of chunk C + 1 into the other ring
+// slot, then the requests for chunk C + 1 + CH_D into the registers just stored) -- tools/mfma_peak.hip: at one wave per SIMD the matrix pipe
+// idles through every feeding instruction that is not issued under an MFMA.
+template <int NJ, int NCH, int C, typename RowFn>
+__device__ __forceinline__ void ch_chunk(ch_wstream& S, f32x16& acc, const float* xs, int RS, float* wb, int CK, int m, RowFn rowfn, int koff, int lane) {
+    constexpr int NS = (C + 1) % CH_D;
+    constexpr int NW = (C + 1 < NCH) ? 4 : 0, NV = (C + 1 + CH_D < NCH) ? 4 : 0, NF = NW + NV;
+    constexpr int LEAD = NJ > 1 ? 2 : 1;
+    constexpr int PER = (NF + NJ - 1) / NJ > 2 ? (NF + NJ - 1) / NJ : 2;
+    const int KC = S.KC, WS = KC + 4, tid = threadIdx.x;
+    const int tap = (C * KC) / CK, ci0 = C * KC - tap * CK;
+    const float* ap = xs + rowfn(m, tap) * RS + ci0 + koff;
+    const float* bp = wb + (C & 1) * CH_WBUF + (lane & 31) * WS + koff;
+    const int nb = ((C + 1) & 1) * CH_WBUF;
+    const int cnext = (C + 1 + CH_D) * KC;
+    f32x4 a[NJ], b[NJ];
+#pragma unroll
+    for (int j = 0; j < LEAD; ++j) {
+        a[j] = *(const f32x4*)(ap + 8 * j);
+        b[j] = *(const f32x4*)(bp + 8 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j + LEAD < NJ) {
+            a[j + LEAD] = *(const f32x4*)(ap + 8 * (j + LEAD));
+            b[j + LEAD] = *(const f32x4*)(bp + 8 * (j + LEAD));
+        }
+#pragma unroll
+        for (int f = (j * PER < NF ? j * PER : NF); f < ((j + 1) * PER < NF ? (j + 1) * PER : NF); ++f) {
+            if (f < NW) {
+                CH_ABL_STORE(*(f32x4*)(wb + (S.ok[f] ? nb + S.loff[f] : CH_DUMMY + 4 * tid)) = S.rg[NS][f]);
+            } else {
+                CH_ABL_LOAD(S.rg[NS][f - NW] = *(const f32x4*)(S.Wcol + S.goff[f - NW] + (S.ok[f - NW] ? cnext : 0)));
+            }
+        }
+        CH_MFMA(acc, a[j][0], b[j][0]);
+        CH_MFMA(acc, a[j][1], b[j][1]);
+        CH_MFMA(acc, a[j][2], b[j][2]);
+        CH_MFMA(acc, a[j][3], b[j][3]);
+    }
+    // the same order for the scheduler
+#pragma unroll
+    for (int j = 0; j < 2 * LEAD; ++j) CH_SGB(0x100);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f0 = j * PER < NF ? j * PER : NF, f1 = (j + 1) * PER < NF ? (j + 1) * PER : NF;
+        CH_SGB(0x008);
+        if (j + LEAD < NJ) CH_SGB(0x100);
+        CH_SGB(0x008);
+        if (j + LEAD < NJ) CH_SGB(0x100);
+        CH_SGB(0x008);
+        if (f0 < f1) {
+            if (f0 < NW) CH_SGB(0x200);
+            else CH_SGB(0x020);
+        }
+        CH_SGB(0x008);
+#pragma unroll
+        for (int f = f0 + 1; f < f1; ++f) {
+            if (f < NW) CH_SGB(0x200);
+            else CH_SGB(0x020);
+        }
+    }
+    ch_barrier();
+    if constexpr (C + 1 < NCH) ch_chunk<NJ, NCH, C + 1>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
+}
+
 // acc (one 32 x 32 tile per wave) = A (rows from LDS through rowfn) x W[n0 .. n0+32)^T over the stream S (K = ntap * CK floats per column); then
 // the K splits are reduced through LDS and rows [0, M) x 32 columns are published to `out` (row stride ldo floats).
 // rowfn(m, tap) -> LDS row of xs that multiplies tap `tap` for output row m.
-template <typename RowFn>
-__device__ __forceinline__ void ch_gemm_store(ch_wstream& S, const float* xs, int RS, float* wb, int CK, int M, RowFn rowfn,
-                                             const __amdgpu_buffer_rsrc_t rsOut, int ldo, int n0) {
+template <int NJ, int NCH, typename RowFn>
+__device__ __forceinline__ void ch_gemm_store_nj(ch_wstream& S, const float* xs, int RS, float* wb, int CK, int M, RowFn rowfn,
+                                                const __amdgpu_buffer_rsrc_t rsOut, int ldo, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MT = M > 32 ? 2 : 1, KS = 4 / MT;
     const int mt = wave % MT, ks = wave / MT;
-    const int KC = S.KC, nch = S.nch, kper = KC / KS, WS = KC + 4;
+    const int kper = S.KC / KS;
     int m = mt * 32 + (lane & 31);
     if (m >= M) m = M - 1;  // rows past the end compute a copy of the last row: never stored
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int koff = ks * kper + (lane >> 5) * 4;
-    const int nj = kper >> 3;
-    // chunk c: its registers -> LDS ring slot c & 1, request chunk c + CH_D into the freed registers, barrier, MFMAs.  The slot written here was
-    // last read by the MFMAs of chunk c - 2, which every wave finished before it passed the barrier of chunk c - 1.
-#define CH_CHUNK(SLOT)                                                                                                  \
-    if (c + SLOT < nch) {                                                                                               \
-        const int cc = c + SLOT;                                                                                        \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) if (S.ok[p]) *(f32x4*)(wb + (cc & 1) * CH_WBUF + S.loff[p]) = S.rg[SLOT][p]; \
-        ch_w_issue<SLOT>(S, cc + CH_D);                                                                                 \
-        __syncthreads();                                                                                                \
-        const int tap = (cc * KC) / CK, ci0 = cc * KC - tap * CK;                                                       \
-        const float* ap = xs + rowfn(m, tap) * RS + ci0 + koff;                                                         \
-        const float* bp = wb + (cc & 1) * CH_WBUF + (lane & 31) * WS + koff;                                            \
-        for (int j = 0; j < nj; ++j) {                                                                                  \
-            const f32x4 a = *(const f32x4*)(ap + 8 * j);                                                                \
-            const f32x4 b = *(const f32x4*)(bp + 8 * j);                                                                \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);                                       \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);                                       \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);                                       \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);                                       \
-        }                                                                                                               \
-    }
-    for (int c = 0; c < nch; c += CH_D) {
-        CH_CHUNK(0)
-        CH_CHUNK(1)
-        CH_CHUNK(2)
-        CH_CHUNK(3)
-    }
-#undef CH_CHUNK
-    __syncthreads();
-    // K splits -> LDS (the weight ring is free), summed in split order, published
+    // chunk 0 -> ring slot 0.  Chunk c then reads slot c & 1 while chunk c + 1 is written to the other slot (last read by chunk c - 1, which every
+    // wave finished before the barrier that closed it) and chunk c + 1 + CH_D is requested into the registers that held chunk c + 1.
+    ch_w_to_lds<0>(S, wb, 0);
+    if constexpr (CH_D < NCH) ch_w_issue<0>(S, CH_D);
+    ch_barrier();
+    ch_chunk<NJ, NCH, 0>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
+    // K splits -> LDS (the weight ring is free: the loop ended on a barrier), summed in split order, published
     float* red = wb;
 #pragma unroll
     for (int v = 0; v < 16; ++v) red[wave * (32 * CH_RED) + (8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * CH_RED + (lane & 31)] = acc[v];
@@ -229,6 +310,23 @@ __device__ __forceinline__ void ch_gemm_store(ch_wstream& S, const float* xs, in
         }
     }
     __syncthreads();  // red is the weight ring of the next GEMM
+}
+
+// (MFMA groups per chunk, chunks) of the blocks this kernel is built for: 64-frame k3 blocks (8, 6), the 288-channel first block (6, 9), blocks of
+// <= 32 frames with k3 (4, 6; 3, 9 with 288 channels) / k4 (4, 8), the input gradient of the first strided block (64 frames, k4: 8, 8); chain_check() admits nothing else.
+template <typename RowFn>
+__device__ __forceinline__ void ch_gemm_store(ch_wstream& S, const float* xs, int RS, float* wb, int CK, int M, RowFn rowfn,
+                                             const __amdgpu_buffer_rsrc_t rsOut, int ldo, int n0) {
+    const int nj = (S.KC / (M > 32 ? 2 : 4)) >> 3;
+    const int key = nj * 16 + S.nch;
+    switch (key) {
+        case 8 * 16 + 6: ch_gemm_store_nj<8, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 8 * 16 + 8: ch_gemm_store_nj<8, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 6 * 16 + 9: ch_gemm_store_nj<6, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 4 * 16 + 6: ch_gemm_store_nj<4, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 3 * 16 + 9: ch_gemm_store_nj<3, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        default: ch_gemm_store_nj<4, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+    }
 }
 
 // ---- frames on load ---------------------------------------------------------------------------
@@ -336,7 +434,8 @@ __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
             const __amdgpu_buffer_rsrc_t rsA = ch_rsrc(LA.y + (size_t)clip * LA.To * CH_C, LA.To * CH_C * 4);
             float* xout = L.x ? L.x + (size_t)clip * L.Ti * CH_C : nullptr;
             if (L.mode == 1) {
-                for (int t0 = wave * 16; t0 < L.Ti; t0 += 64) {
+                const int t0 = wave * 16;  // <= 64 frames: one batch per wave
+                if (t0 < L.Ti) {
                     ch_row a[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) a[p] = ch_ld_row(rsA, t0 + 4 * p + fq, li);
@@ -418,22 +517,24 @@ struct ch_bwd_src {
 };
 
 // gradient of the raw output of frames t0 + fq (one pass of a wave): gather the output gradient, normalisation backward (norm.hip rownorm_kernel<BWD>)
-template <bool UP>
+template <bool UP, bool TWO>
 __device__ __forceinline__ void ch_bwd_frames(const ch_args& A, const ch_layer& L, const ch_bwd_src& G, const float* ysrc, float* dyo, float* ds, int RS,
                                               int t0, int fq, int li, int r) {
-    constexpr int NP = UP ? 1 : 2;
+    constexpr int NP = UP ? 1 : 4;  // frames in flight per lane group: a 64-frame block is one batch of loads per wave
     ch_row g[NP], yv[NP], up[UP ? 6 : 1];
     float uw[UP ? 6 : 1];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int t = t0 + 4 * p + fq;  // past the end: the buffer range returns zeros
         g[p] = ch_ld_row(G.rs0, t, li);  // zero-sized range: zeros
-        const ch_row g1 = ch_ld_row(G.rs1, t, li);
+        if constexpr (TWO) {
+            const ch_row g1 = ch_ld_row(G.rs1, t, li);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            g[p].v[q] += g1.v[q];
-            yv[p].v[q] = t < L.To ? *(const f32x4*)(ysrc + (size_t)t * CH_C + 4 * (li + 16 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q) g[p].v[q] += g1.v[q];
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            yv[p].v[q] = t < L.To ? *(const f32x4*)(ysrc + (size_t)t * CH_C + 4 * (li + 16 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (UP) {
             const int jlo = (int)floorf(((float)t - 0.5f) / G.usc - 0.5f) - 1;
 #pragma unroll
@@ -536,9 +637,10 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
         G.TiU = GU.Ti;
         G.usc = G.up ? (float)L.To / (float)GU.Ti : 1.f;  // upsampling source index scale: in / out
         if (G.up) {
-            for (int t0 = wave * 4; t0 < L.To; t0 += 16) ch_bwd_frames<true>(A, L, G, ysrc, dyo, ds, RS, t0, fq, li, r);
-        } else {
-            for (int t0 = wave * 8; t0 < L.To; t0 += 32) ch_bwd_frames<false>(A, L, G, ysrc, dyo, ds, RS, t0, fq, li, r);
+            for (int t0 = wave * 4; t0 < L.To; t0 += 16) ch_bwd_frames<true, true>(A, L, G, ysrc, dyo, ds, RS, t0, fq, li, r);
+        } else if (wave * 16 < L.To) {  // <= 64 frames: one batch per wave
+            if (L.g_id1 >= 0) ch_bwd_frames<false, true>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r);
+            else ch_bwd_frames<false, false>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r);
         }
         __syncthreads();
         CH_TL(s, 1);
@@ -566,7 +668,11 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-static int chain_check(const sdt_chain1d_layer* Ls, int n, int B) {
+static bool chain_variant(int nj, int nch) {  // the unrolled K loops ch_gemm_store() dispatches to
+    return (nj == 8 && (nch == 6 || nch == 8)) || (nj == 6 && nch == 9) || (nj == 4 && (nch == 6 || nch == 8)) || (nj == 3 && nch == 9);
+}
+
+static int chain_check(const sdt_chain1d_layer* Ls, int n, int B, bool pointers = true) {
     SDT_CHECK_ARG(Ls != nullptr && n >= 1 && n <= CH_MAXL && B >= 1, "bad chain");
     for (int l = 0; l < n; ++l) {
         const sdt_chain1d_layer& L = Ls[l];
@@ -586,7 +692,10 @@ static int chain_check(const sdt_chain1d_layer* Ls, int n, int B) {
                 SDT_CHECK_ARG(Ls[L.src_a].To <= L.Ti && 2 * Ls[L.src_a].To >= L.Ti, "upsampling ratio must be in [1, 2]");
             }
         }
-        SDT_CHECK_ARG(L.w != nullptr && L.y != nullptr, "NULL weight / output");
+        const int KC = L.Cin % 128 == 0 ? 128 : (L.Cin % 96 == 0 ? 96 : (L.Cin % 64 == 0 ? 64 : 32));
+        SDT_CHECK_ARG(chain_variant((KC / (L.To > 32 ? 2 : 4)) >> 3, L.k * L.Cin / KC) && chain_variant((128 / (L.Ti > 32 ? 2 : 4)) >> 3, 2 * L.k),
+                      "no K loop was built for this block (kernel size 3 or 4; 256 or 288 input channels)");
+        SDT_CHECK_ARG(!pointers || (L.w != nullptr && L.y != nullptr), "NULL weight / output");
     }
     return SDT_OK;
 }
@@ -637,10 +746,10 @@ static int chain_fill(ch_args& A, const sdt_chain1d_layer* Ls, int n, int B, flo
     return SDT_OK;
 }
 
-static const size_t kChainLds = (size_t)(CH_ROWS * (CH_MAXCIN + 4) + 2 * CH_WBUF) * 4;
+static const size_t kChainLds = (size_t)(CH_ROWS * (CH_MAXCIN + 4) + 2 * CH_WBUF + 256 * 4) * 4;
 
 extern "C" int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B) {
-    if (layers == nullptr || nlayers < 1 || nlayers > CH_MAXL || B < 1) return 0;
+    if (chain_check(layers, nlayers, B, false) != SDT_OK) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     // one workgroup per CU (LDS), every cluster co-resident: 8 workgroups per clip, clusters allotted in windows of 64 block ids

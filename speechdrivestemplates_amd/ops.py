@@ -1468,6 +1468,14 @@ class Chain1dFn(torch.autograd.Function):
     (deferred to the side stream inside a train step), from the conv inputs / raw-output gradients the two launches leave in HBM."""
 
     @staticmethod
+    def _slices(buf, sizes, shapes):
+        out, o = [], 0
+        for n, shp in zip(sizes, shapes):
+            out.append(buf[o:o + n].view(shp))
+            o += n
+        return out
+
+    @staticmethod
     def forward(ctx, h, spec, slope, *weights):
         _req_cuda(h, *weights)
         lib = _lib.load()
@@ -1477,64 +1485,70 @@ class Chain1dFn(torch.autograd.Function):
         n = len(blocks)
         dev = h.device
         want_grad = any(ctx.needs_input_grad)  # (grad mode is off inside forward(): needs_input_grad is what says a backward may follow)
-        ybuf = torch.empty(B * 256 * sum(b[1] for b in blocks), device=dev, dtype=torch.float32)
-        xbuf = torch.empty(B * 256 * sum(b[0] for b in blocks[1:]), device=dev, dtype=torch.float32) if want_grad else None
-        ys, xs, yo, xo = [], [None], 0, 0
-        for l, b in enumerate(blocks):
-            ys.append(ybuf[yo:yo + B * b[1] * 256].view(B, b[1], 256))
-            yo += B * b[1] * 256
-            if l:
-                xs.append(xbuf[xo:xo + B * b[0] * 256].view(B, b[0], 256) if want_grad else None)
-                xo += B * b[0] * 256
+        need_dx0 = bool(ctx.needs_input_grad[0])
+        ysz = [B * b[1] * 256 for b in blocks]
+        ys = Chain1dFn._slices(torch.empty(sum(ysz), device=dev, dtype=torch.float32), ysz, [(B, b[1], 256) for b in blocks])
+        xs = [None] * n
+        if want_grad:
+            xsz = [B * b[0] * 256 for b in blocks[1:]]
+            xs = [None] + Chain1dFn._slices(torch.empty(sum(xsz), device=dev, dtype=torch.float32), xsz, [(B, b[0], 256) for b in blocks[1:]])
         zout = torch.empty((B, blocks[-1][1], 256), device=dev, dtype=torch.float32)
-        tab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(weight_storage(w)), None, _p(ys[l]),
-                                                      _p(xs[l]) if l else None, None, None)
-                                      for l, ((Ti, To, Cin, k, stride, pad, mode, sa, sb), w) in enumerate(zip(blocks, weights))])
+        wst = [weight_storage(w) for w in weights]
+        tab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(wst[l]), None, _p(ys[l]), _p(xs[l]), None, None)
+                                      for l, (Ti, To, Cin, k, stride, pad, mode, sa, sb) in enumerate(blocks)])
         ws = _chain_ws(dev)
         flops = sum(2.0 * B * To * 256 * k * Cin for (Ti, To, Cin, k, *_r) in blocks)
         nbytes = 4.0 * (h.numel() + zout.numel() + sum(w.numel() for w in weights))
         st = _stream()
         _chain_launch("chain1d_fwd_kernel", "fwd", flops, nbytes,
                       lambda: lib.sdt_chain1d_fwd_f32(tab, n, _p(h), _p(zout), B, float(slope), BN_EPS, ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
-        ctx.blocks, ctx.slope, ctx.ys, ctx.xs = blocks, float(slope), ys, xs
-        ctx.save_for_backward(h, ybuf, xbuf, *weights)
+        ctx.blocks, ctx.slope, ctx.xs = blocks, float(slope), xs
+        if want_grad:
+            # everything backward() needs besides the gradient itself is prepared HERE: in a train step the host is about a millisecond ahead of
+            # the GPU during the forward pass and level with it when the backward pass reaches this stage (its table-building showed as a gap of
+            # the main stream in front of the launch).  The (Cin,taps,Cout) weight mirrors have stable addresses; backward() only asks for a refresh.
+            dys = Chain1dFn._slices(torch.empty(sum(ysz), device=dev, dtype=torch.float32), ysz, [(B, b[1], 256) for b in blocks])
+            dsz = [B * b[0] * b[2] for b in blocks]
+            dxs = Chain1dFn._slices(torch.empty(sum(dsz), device=dev, dtype=torch.float32), dsz, [(B, b[0], b[2]) for b in blocks])
+            wts = []
+            for l, w in enumerate(weights):
+                wt = None
+                if l or need_dx0:
+                    _owner, e = WeightMirrors._entry(w)
+                    # no optimiser group mirrors this weight: transposed per call in backward()
+                    wt = e[1] if e is not None else torch.empty((blocks[l][2], blocks[l][3], 256), device=dev, dtype=torch.float32)
+                wts.append(wt)
+            ctx.dys, ctx.dxs, ctx.wts = dys, dxs, wts
+            ctx.btab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(wst[l]), _p(wts[l]), _p(ys[l]), _p(xs[l]),
+                                                               _p(dys[l]), _p(dxs[l]))
+                                               for l, (Ti, To, Cin, k, stride, pad, mode, sa, sb) in enumerate(blocks)])
+            ctx.bflops = sum(2.0 * B * To * 256 * k * Cin for l, (Ti, To, Cin, k, *_r) in enumerate(blocks) if l or need_dx0)
+            ctx.bbytes = 4.0 * (zout.numel() + 2 * sum(ysz) + sum(w.numel() for w in weights))
+        ctx.save_for_backward(h, ys[0]._base, *weights)
         return zout
 
     @staticmethod
     def backward(ctx, gz):
-        h, ybuf, xbuf = ctx.saved_tensors[:3]
-        weights = ctx.saved_tensors[3:]
+        h = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[2:]
         lib = _lib.load()
-        blocks, ys, xs = ctx.blocks, ctx.ys, ctx.xs
+        blocks, xs, dys, dxs = ctx.blocks, ctx.xs, ctx.dys, ctx.dxs
         n = len(blocks)
         B = h.shape[0]
-        dev = h.device
         gz = gz.contiguous()
         st = _stream()
         need_dx0 = bool(ctx.needs_input_grad[0])
-        dybuf = torch.empty_like(ybuf)
-        dxbuf = torch.empty(B * sum(b[0] * b[2] for b in blocks), device=dev, dtype=torch.float32)
-        dys, dxs, yo, xo, wts = [], [], 0, 0, []
-        for l, (b, w) in enumerate(zip(blocks, weights)):
-            Ti, To, Cin, k = b[0], b[1], b[2], b[3]
-            dys.append(dybuf[yo:yo + B * To * 256].view(B, To, 256))
-            yo += B * To * 256
-            dxs.append(dxbuf[xo:xo + B * Ti * Cin].view(B, Ti, Cin))
-            xo += B * Ti * Cin
-            wt = None
-            if l or need_dx0:
-                wt = WeightMirrors.lookup(w)
-                if wt is None:
-                    wt = torch.empty((Cin, k, 256), device=dev, dtype=torch.float32)
-                    check(lib.sdt_weight_transpose_f32(_p(weight_storage(w)), _p(wt), 256, k, Cin, st))
-            wts.append(wt)
-        tab = (_lib.ChainLayer * n)(*[_lib.ChainLayer(Ti, To, Cin, k, stride, pad, mode, sa, sb, 0, _p(weight_storage(w)), _p(wts[l]), _p(ys[l]),
-                                                      _p(xs[l]) if l else None, _p(dys[l]), _p(dxs[l]))
-                                      for l, ((Ti, To, Cin, k, stride, pad, mode, sa, sb), w) in enumerate(zip(blocks, weights))])
-        ws = _chain_ws(dev)
-        flops = sum(2.0 * B * To * 256 * k * Cin for l, (Ti, To, Cin, k, *_r) in enumerate(blocks) if l or need_dx0)
-        nbytes = 4.0 * (gz.numel() + ybuf.numel() + dybuf.numel() + sum(w.numel() for w in weights))
-        _chain_launch("chain1d_bwd_kernel", "dX", flops, nbytes,
+        for l, w in enumerate(weights):
+            if ctx.wts[l] is None:
+                continue
+            wt = WeightMirrors.lookup(w)  # refreshes the optimiser group's mirrors when they are stale (one batched launch for all of them)
+            if wt is None:
+                check(lib.sdt_weight_transpose_f32(_p(weight_storage(w)), _p(ctx.wts[l]), 256, blocks[l][3], blocks[l][2], st))
+            elif wt.data_ptr() != ctx.wts[l].data_ptr():
+                raise RuntimeError("the weight mirrors were rebuilt between forward and backward")
+        ws = _chain_ws(h.device)
+        tab = ctx.btab
+        _chain_launch("chain1d_bwd_kernel", "dX", ctx.bflops, ctx.bbytes,
                       lambda: lib.sdt_chain1d_bwd_f32(tab, n, _p(gz), B, ctx.slope, BN_EPS, int(need_dx0), ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
         for l, (b, w) in enumerate(zip(blocks, weights)):  # weight gradients: the per-block launches, deferred to the side stream inside a train step
             if w.requires_grad:

@@ -8,7 +8,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
-os.environ["SDT_HIP_LIB"] = os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
+os.environ["SDT_HIP_LIB"] = os.environ.get("SDT_CHAIN_LIB") or os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip_tuning.so")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
