@@ -1687,7 +1687,8 @@ def clip_poses_prepare(raw_store, idx, mean, std, num_frames, hierarchical):
     B = idx.numel()
     poses = torch.empty((B, num_frames, 2, 121), device=raw_store.device, dtype=torch.float32)
     score = torch.empty_like(poses)
-    check(_lib.load().sdt_clip_poses_prepare_f32(_p(raw_store), _p(idx.contiguous()), _p(mean.contiguous()), _p(std.contiguous()),
+    idx, mean, std = idx.contiguous(), mean.contiguous(), std.contiguous()  # named: a temporary's block is free (and reusable) once _p() returns
+    check(_lib.load().sdt_clip_poses_prepare_f32(_p(raw_store), _p(idx), _p(mean), _p(std),
                                                  _p(poses), _p(score), N, Tstore, B, num_frames, int(bool(hierarchical)), _stream()))
     return poses, score
 
@@ -1697,7 +1698,8 @@ def rows_gather(src, idx):
     _req_cuda(src, idx)
     assert src.dim() == 2 and src.is_contiguous() and src.dtype == torch.float32 and idx.dtype == torch.int64
     dst = torch.empty((idx.numel(), src.shape[1]), device=src.device, dtype=torch.float32)
-    check(_lib.load().sdt_rows_gather_f32(_p(src), _p(idx.contiguous()), _p(dst), src.shape[0], idx.numel(), src.shape[1], _stream()))
+    idx = idx.contiguous()
+    check(_lib.load().sdt_rows_gather_f32(_p(src), _p(idx), _p(dst), src.shape[0], idx.numel(), src.shape[1], _stream()))
     return dst
 
 
@@ -1712,7 +1714,10 @@ def final_metrics(pred, gt, mean, std, scale, hierarchical, want_final=True):
     fg = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
     work = _ARENA.take(2 * B * T + 4, dev)
     metrics = torch.empty(2, device=dev, dtype=torch.float64)
-    check(_lib.load().sdt_final_metrics_f64(_p(pred), _p(gt), _p(mean.contiguous()), _p(std.contiguous()), _p(scale.contiguous()),
+    # the contiguous copies of broadcast statistics (DeviceClipStore hands out expand()ed views) must outlive the launch call: as unnamed
+    # temporaries the three copies were freed one by one and re-used each other's block -- the kernel then read `std` through `mean`'s pointer
+    mean, std, scale = mean.contiguous(), std.contiguous(), scale.contiguous()
+    check(_lib.load().sdt_final_metrics_f64(_p(pred), _p(gt), _p(mean), _p(std), _p(scale),
                                             1 if hierarchical else 0, B, T, K, _p(fp), _p(fg), _p(work), _p(metrics), _stream()))
     return fp, fg, metrics
 
@@ -1769,7 +1774,8 @@ def mel_spectrogram(audio, basis, fb, bins=None):
             check(lib.sdt_set_conv_math(math))
     nmel = fb.shape[1]
     mel = torch.empty((B, nmel, F), device=audio.device, dtype=torch.float32)
-    check(lib.sdt_mel_fb_f32(_p(spec), _p(fb.contiguous()), _p(lo), _p(hi), _p(mel), B, F, N_FREQ, nmel, st))
+    fb = fb.contiguous()
+    check(lib.sdt_mel_fb_f32(_p(spec), _p(fb), _p(lo), _p(hi), _p(mel), B, F, N_FREQ, nmel, st))
     return mel
 
 

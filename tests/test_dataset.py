@@ -110,10 +110,13 @@ def test_train_step_from_device_clip_store(tmp_path):
         losses, results = pipe.forward_backward(batch)
         pipe.optimizer_updates(losses)
         torch.cuda.synchronize()
-        out.append((losses["G_reg_loss"].detach().clone(), losses["L2_dist"].detach().clone(), results["poses_pred_batch"].detach().clone()))
-    (reg_a, l2_a, pred_a), (reg_b, l2_b, pred_b) = out
+        out.append((losses["G_reg_loss"].detach().clone(), losses["L2_dist"].detach().clone(), results["poses_pred_batch"].detach().clone(),
+                    losses["lip_sync_error_n"].detach().clone()))
+    (reg_a, l2_a, pred_a, lip_a), (reg_b, l2_b, pred_b, lip_b) = out
     assert torch.equal(reg_a, reg_b) and torch.equal(pred_a, pred_b)
-    assert abs(float(l2_a) - float(l2_b)) <= 1e-12 * abs(float(l2_a))  # float64 atomics: summation order only
+    assert abs(float(l2_a) - float(l2_b)) <= 1e-12 * abs(float(l2_a)), (float(l2_a), float(l2_b))  # float64 atomics: summation order only
+    # the store's statistics are expand()ed views: the metrics kernel once read them through pointers of freed contiguous temporaries
+    assert abs(float(lip_a) - float(lip_b)) <= 1e-12 * abs(float(lip_a)), (float(lip_a), float(lip_b))
 
 
 def test_demo_split_reads_wav(tmp_path):

@@ -27,7 +27,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--reserve", type=int, default=0, help="workgroup slots the BACKWARD stream-K plans leave free (ops.SK_RESERVED_SLOTS -> sdt_convsk_set_reserved_slots)")
     ap.add_argument("--lds", type=int, default=65536, help="LDS bytes per spinning workgroup (65536: cannot share a CU with two conv workgroups)")
+    ap.add_argument("--no-chain1d", action="store_true", help="the generator's Conv1d stage block by block (A/B of the persistent chain launch under a collective)")
     a = ap.parse_args()
+    ops.CHAIN1D = not a.no_chain1d
     lib = _lib.load()
     lib.sdt_debug_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sdt_debug_spin.restype = ctypes.c_int
@@ -39,8 +41,9 @@ def main():
     orig = ops.flush_deferred_dw
 
     def hooked():
-        orig()
-        if state["on"]:
+        pending = bool(ops._DEFERRED)  # the flush from the post-encoder hook (the step's closing flush in forward_backward finds nothing queued:
+        orig()                         # a collective launched THERE would start behind the whole backward pass and run serially)
+        if state["on"] and pending:
             comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm):
                 _lib.check(lib.sdt_debug_spin(a.wgs, a.us, a.lds, ctypes.c_void_p(comm.cuda_stream)))
