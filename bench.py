@@ -479,8 +479,10 @@ def main(argv=None):
                         "note": "Conv1d stacks of one train step: U-Net + decoder forward and backward chains (main stream, exposed), "
                                 "their weight gradients and the two no-grad pose-encoder passes (side stream, overlapped with the "
                                 "Conv2d backward); HIP-event windows on the stream each piece runs on, sampled steps that carry ONLY these 8 events; "
-                                "algorithmic bytes / FLOPs from SURVEY.md 8d.  In fp32 the stage is bound by the fp32 MFMA rate and "
-                                "by launch latency, not by HBM: at the MFMA roofline (%.0f us) it would still reach only %.0f %% of 8 TB/s"
+                                "algorithmic bytes / FLOPs from SURVEY.md 8d.  g1d_fwd / g1d_bwd: the generator's sixteen blocks as ONE persistent "
+                                "launch per direction (csrc/chain1d.hip; --no-chain1d: two to three launches per block) + resize / head / loss "
+                                "kernels.  In fp32 the stage is bound by the fp32 MFMA rate and by hand-off / launch latency, not by HBM: at the "
+                                "MFMA roofline (%.0f us) it would still reach only %.0f %% of 8 TB/s"
                                 % (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) * 1e6,
                                    100 * mb * 1e6 / (gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12)) / 1e12 / HBM_PEAK_TBS)}
             hbs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_kernels.txt")) if os.path.isdir(os.path.join(REPO, "profiles")) else []

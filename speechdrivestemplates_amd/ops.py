@@ -953,7 +953,7 @@ def _side_stream(which=0):
     return _SIDE[key]
 
 
-OVERLAP_AUX = True  # the no-grad pose-encoder passes of a train step run on the side stream (voice2pose.py)
+OVERLAP_AUX = True  # the no-grad pose-encoder passes of a train step run on the side stream (voice2pose.py); a stream of their own: no change (r04)
 
 
 class side_stream_scope:
@@ -1047,8 +1047,9 @@ def join_side_stream():
     if not _SIDE:
         return
     dev = torch._C._cuda_getDevice()
-    if (dev, 0) in _SIDE:
-        torch.cuda.current_stream().wait_stream(_SIDE[(dev, 0)])
+    for (d, _which), st in _SIDE.items():
+        if d == dev:
+            torch.cuda.current_stream().wait_stream(st)
 
 
 class ConvFn(torch.autograd.Function):

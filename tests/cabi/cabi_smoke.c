@@ -28,6 +28,23 @@ int main(void) {
     rc = sdt_colnorm_fwd_t(NULL, SDT_BF16, NULL, SDT_BF16, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 1, 1, 4, 1e-5f, 0.1f, 0.2f, 0, NULL);
     if (rc != SDT_ERR_ARG) return 21;
     if (sdt_convsk_set_spin_limit(sdt_convsk_get_spin_limit()) != SDT_OK) return 22;
+    /* the Conv1d chain: the wiring is validated on the host before anything is launched */
+    {
+        sdt_chain1d_layer L[2];
+        float dummy = 0.f;
+        unsigned words[2] = {0u, 0u};
+        memset(L, 0, sizeof L);
+        if (sizeof(sdt_chain1d_layer) != 10 * sizeof(int32_t) + 6 * sizeof(void*)) return 23;
+        L[0].Ti = 64, L[0].To = 64, L[0].Cin = 288, L[0].k = 3, L[0].stride = 1, L[0].pad = 1, L[0].in_mode = SDT_CHAIN_PLAIN, L[0].src_a = L[0].src_b = -1;
+        L[1] = L[0];
+        L[1].Cin = 256, L[1].in_mode = SDT_CHAIN_NORM, L[1].src_a = 1; /* a block cannot read itself */
+        L[0].w = L[1].w = &dummy, L[0].y = L[1].y = &dummy;
+        rc = sdt_chain1d_fwd_f32(L, 2, &dummy, &dummy, 4, 0.2f, 1e-5f, words, words + 1, NULL);
+        if (rc != SDT_ERR_ARG) return 24;
+        L[1].src_a = 0, L[1].k = 5, L[1].pad = 2; /* no K loop was built for a 5-tap block */
+        if (sdt_chain1d_supported(L, 2, 4) != 0) return 25;
+        if (sdt_chain1d_bwd_f32(NULL, 2, &dummy, 4, 0.2f, 1e-5f, 1, words, words + 1, NULL) != SDT_ERR_ARG) return 26;
+    }
     puts("C ABI OK");
     return 0;
 }

@@ -83,3 +83,29 @@ def test_frame_variant_codes_are_rejected_like_the_reference_rejects_them():
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp",
                              env=dict(os.environ, PYTHONPATH="/root/reference", PYTHONDONTWRITEBYTECODE="1"))
         assert "RAISES" in out.stdout and "repeat dims" in out.stdout, (out.stdout, out.stderr[-500:])
+
+
+def test_chain_wiring_of_the_generator():
+    """ops.chain_blocks: frames / channels of the sixteen Conv1d blocks as the chain launch sees them (generator.py:53-85,96-103: e0..e6 halve the
+    frames from e2 on, d5..d1 read upsample(previous) + skip, four decoder blocks) -- and inconsistent wirings raise."""
+    import pytest
+    from speechdrivestemplates_amd import _lib, ops
+    from speechdrivestemplates_amd.config import get_cfg_defaults
+    from speechdrivestemplates_amd.core.networks import get_model
+    cfg = get_cfg_defaults()
+    cfg.merge_from_list(["VOICE2POSE.GENERATOR.CLIP_CODE.DIMENSION", 32])
+    net = get_model("SequenceGeneratorCNN")(cfg)
+    spec, weights, slope = net._chain()
+    assert len(spec) == len(weights) == 16 and slope == ops.LEAKY_SLOPE * bool(cfg.VOICE2POSE.GENERATOR.LEAKY_RELU)
+    blocks = ops.chain_blocks(spec, 64, 288)
+    assert [b[0] for b in blocks] == [64, 64, 64, 32, 16, 8, 4, 4, 8, 16, 32, 64, 64, 64, 64, 64]  # input frames
+    assert [b[1] for b in blocks] == [64, 64, 32, 16, 8, 4, 2, 4, 8, 16, 32, 64, 64, 64, 64, 64]   # output frames
+    assert [b[2] for b in blocks] == [288] + [256] * 15
+    assert [b[6] for b in blocks] == [_lib.CHAIN_PLAIN] + [_lib.CHAIN_NORM] * 6 + [_lib.CHAIN_UPADD] * 5 + [_lib.CHAIN_NORM] * 4
+    assert [(b[7], b[8]) for b in blocks[7:12]] == [(6, 5), (7, 4), (8, 3), (9, 2), (10, 1)]  # (upsampled block, skip block)
+    for w, b in zip(weights, blocks):
+        assert tuple(w.shape) == (256, b[2], b[3])
+    with pytest.raises(ValueError):
+        ops.chain_blocks(((4, 2, 1, _lib.CHAIN_PLAIN, -1, -1),) + tuple((4, 2, 1, _lib.CHAIN_NORM, i, -1) for i in range(7)), 64, 256)  # runs out of frames
+    cfg.merge_from_list(["VOICE2POSE.GENERATOR.NORM", "BN"])
+    assert get_model("SequenceGeneratorCNN")(cfg)._chain() is None  # BatchNorm generators keep the per-block kernels

@@ -25,10 +25,10 @@ __global__ __launch_bounds__(256) void probe(unsigned* counters, unsigned* paylo
     const int window = b >> 6, slot = (b >> 3) & 7, xc = b & 7;  // cluster = (window, xc); member = slot
     const int cluster = window * 8 + xc;
     gu32* cnt = (gu32*)(counters + cluster * 32);
-    unsigned* mine = payload + (size_t)(cluster * 8 + slot) * words;
-    const unsigned* right = payload + (size_t)(cluster * 8 + ((slot + 1) & 7)) * words;
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, words * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)right, 0, words * 4, 0x00020000);
+    // two payload slots per member, alternating by iteration: a fast member's NEXT store must not land in the slot its left neighbour is still reading
+    // (the design's blocks write different tensors, so it has no such hazard; the first version of this probe had it and counted "wrong words")
+    unsigned* mine0 = payload + (size_t)((cluster * 8 + slot) * 2) * words;
+    const unsigned* right0 = payload + (size_t)((cluster * 8 + ((slot + 1) & 7)) * 2) * words;
     if (tid == 0) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void probe(unsigned* counters, unsigned* paylo
     __syncthreads();
     const long long t0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
+        unsigned* mine = mine0 + (size_t)(it & 1) * words;
+        const unsigned* right = right0 + (size_t)(it & 1) * words;
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, words * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)right, 0, words * 4, 0x00020000);
         const unsigned tag = (unsigned)(it + 1) * 0x10001u + (unsigned)slot;
         for (int w = tid * 4; w < words; w += 1024) {
             const u32x4 v = {tag, tag + 1u, tag + 2u, tag + 3u};
@@ -100,7 +104,7 @@ static void run(int words, int iters, unsigned* dcnt, unsigned* dpay, long long*
 int main() {
     unsigned *dcnt, *dpay, *dbad, *dxcc;
     long long* dcyc;
-    CK(hipMalloc(&dcnt, 32 * 32 * 4)); CK(hipMalloc(&dpay, (size_t)256 * 16384)); CK(hipMalloc(&dbad, 4)); CK(hipMalloc(&dxcc, 1024)); CK(hipMalloc(&dcyc, 2048));
+    CK(hipMalloc(&dcnt, 32 * 32 * 4)); CK(hipMalloc(&dpay, (size_t)256 * 2 * 16384)); CK(hipMalloc(&dbad, 4)); CK(hipMalloc(&dxcc, 1024)); CK(hipMalloc(&dcyc, 2048));
     const int iters = 500;
     for (int words : {0, 1024, 4096}) {
         run<false>(words, iters, dcnt, dpay, dcyc, dbad, dxcc);
