@@ -300,7 +300,8 @@ int sdt_upsample_add_bwd_f32(const float* dout, float* dprev, int B, int Ti, int
  * tensor (block 0), the activated output of an earlier block, or F.interpolate(earlier block, Ti, 'linear') + the activated output of another
  * one (generator.py:79-83).  Every block has 256 output channels; <= 64 frames per clip; Cin a multiple of 32 (<= 320, block 0 only: the
  * others read 256-channel block outputs).  Only the RAW conv outputs y travel between blocks; normalisation and activation are applied by
- * the consumer on load.  8 workgroups own a clip (see the file header); the launch needs 64 * ceil(B / 8) co-resident workgroups.           */
+ * the consumer on load.  8 workgroups own a clip (see the file header); a launch holds 8 * (CUs / 64) clips (32 on MI355X) with every cluster
+ * co-resident, a larger batch runs as consecutive launches.                                                                                  */
 enum { SDT_CHAIN_PLAIN = 0, SDT_CHAIN_NORM = 1, SDT_CHAIN_UPADD = 2 };
 typedef struct sdt_chain1d_layer {
     int32_t Ti, To, Cin, k, stride, pad;
@@ -314,9 +315,9 @@ typedef struct sdt_chain1d_layer {
     float* dy;              /* (B, To, 256) backward: gradient of y (the weight gradient's other operand) */
     float* dx;              /* (B, Ti, Cin) backward: gradient of the conv's input */
 } sdt_chain1d_layer;
-/* 1 when the current device can hold the launch (every cluster co-resident), else 0. */
+/* 1 when every block maps to a built K loop and the current device can hold a window of clusters, else 0. */
 int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B);
-/* zout (B, To_last, 256) = act(norm(y[nlayers-1])).  counters: >= B zero-initialised uint32 (zero again when the launch ends); err: one uint32
+/* zout (B, To_last, 256) = act(norm(y[nlayers-1])).  counters: >= min(B, 8 * (CUs / 64)) zero-initialised uint32 (zero again when a launch ends); err: one uint32
  * that a launch sets non-zero when a workgroup gave up waiting for its cluster (sdt_convsk_set_spin_limit) -- results are then invalid. */
 int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* x0, float* zout, int B, float slope, float eps,
                         void* counters, void* err, void* stream);

@@ -53,7 +53,7 @@ struct ch_layer {
 
 struct ch_args {
     ch_layer L[CH_MAXL];
-    int n, B;
+    int n, B, clip0;   // this launch owns clips [clip0, min(B, clip0 + clusters of the grid))
     float slope, eps;
     const float* x0;   // (B, Ti0, Cin0) input of block 0
     float* zout;       // (B, To_last, 256) act(norm(y[n-1])): the chain's output
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
     __shared__ int dead;
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane >> 4, li = lane & 15;
-    const int clip = (bid >> 6) * 8 + (bid & 7), r = (bid >> 3) & 7;
+    const int slot = (bid >> 6) * 8 + (bid & 7), clip = A.clip0 + slot, r = (bid >> 3) & 7;  // slot: the cluster's index within this launch
     if (clip >= A.B) return;
     float* xs = smem;                                   // [CH_ROWS][Cin + 4]
     float* wb = smem + CH_ROWS * (CH_MAXCIN + 4);       // [2][32][KC + 4]
-    gu32* cnt = (gu32*)(A.counters + clip);
+    gu32* cnt = (gu32*)(A.counters + slot);
     const unsigned total = 8u * (unsigned)(A.n + 1);
     if (tid == 0) dead = 0;
     __syncthreads();
@@ -593,12 +593,12 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
     __shared__ int dead;
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane >> 4, li = lane & 15;
-    const int clip = (bid >> 6) * 8 + (bid & 7), r = (bid >> 3) & 7;
+    const int slot = (bid >> 6) * 8 + (bid & 7), clip = A.clip0 + slot, r = (bid >> 3) & 7;  // slot: the cluster's index within this launch
     if (clip >= A.B) return;
     const int RS = CH_C + 4;
     float* ds = smem;                                   // [1 + To][260]
     float* wb = smem + CH_ROWS * (CH_MAXCIN + 4);
-    gu32* cnt = (gu32*)(A.counters + clip);
+    gu32* cnt = (gu32*)(A.counters + slot);
     const unsigned total = 8u * (unsigned)A.n;
     if (tid == 0) dead = 0;
     if (tid < 64) *(f32x4*)(ds + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -748,12 +748,17 @@ static int chain_fill(ch_args& A, const sdt_chain1d_layer* Ls, int n, int B, flo
 
 static const size_t kChainLds = (size_t)(CH_ROWS * (CH_MAXCIN + 4) + 2 * CH_WBUF + 256 * 4) * 4;
 
-extern "C" int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B) {
-    if (chain_check(layers, nlayers, B, false) != SDT_OK) return 0;
+// clips one launch can own: one workgroup per CU (LDS), every cluster co-resident, clusters allotted in windows of 64 block ids (8 clips);
+// a larger batch runs as consecutive launches of this many clips each
+static int chain_clips_per_launch() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    // one workgroup per CU (LDS), every cluster co-resident: 8 workgroups per clip, clusters allotted in windows of 64 block ids
-    return 64 * ((B + 7) / 8) <= cus ? 1 : 0;
+    return 8 * (cus / 64);
+}
+
+extern "C" int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B) {
+    if (chain_check(layers, nlayers, B, false) != SDT_OK) return 0;
+    return chain_clips_per_launch() >= 8 ? 1 : 0;
 }
 
 extern "C" int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* x0, float* zout, int B, float slope, float eps,
@@ -773,7 +778,13 @@ extern "C" int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers,
         (void)hipFuncSetAttribute((const void*)chain1d_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(chain1d_fwd_kernel, dim3(64 * ((B + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+    const int per = chain_clips_per_launch();
+    SDT_CHECK_ARG(per >= 8, "the device cannot hold one window of clusters");
+    for (int c0 = 0; c0 < B; c0 += per) {
+        A.clip0 = c0;
+        const int nclip = std::min(per, B - c0);
+        hipLaunchKernelGGL(chain1d_fwd_kernel, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+    }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
@@ -796,7 +807,13 @@ extern "C" int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers,
         (void)hipFuncSetAttribute((const void*)chain1d_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(chain1d_bwd_kernel, dim3(64 * ((B + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+    const int per = chain_clips_per_launch();
+    SDT_CHECK_ARG(per >= 8, "the device cannot hold one window of clusters");
+    for (int c0 = 0; c0 < B; c0 += per) {
+        A.clip0 = c0;
+        const int nclip = std::min(per, B - c0);
+        hipLaunchKernelGGL(chain1d_bwd_kernel, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+    }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

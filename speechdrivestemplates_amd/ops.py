@@ -1433,7 +1433,7 @@ def chain_blocks(spec, T0, Cin0):
 
 def chain1d_usable(h, spec, weights):
     """The launch exists for this chain on this device: fp32 (B, T <= 64, Cin % 32 == 0) input, every block 256 wide with its weight in the kernel
-    layout, every 8-workgroup cluster co-resident (B <= 32 on MI355X)."""
+    layout (a launch holds 32 clips on MI355X; larger batches run as consecutive launches inside the entry point)."""
     if not (CHAIN1D and h.is_cuda and h.dtype == torch.float32 and h.dim() == 3 and _CONV_MATH_NOW[0] == 0):
         return False
     B, T0, Cin0 = h.shape
