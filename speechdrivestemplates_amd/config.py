@@ -42,7 +42,10 @@ _DEFAULTS = {
             # extensions of this engine (absent from the reference's configs/default.py:4-97; defaults = the reference's behaviour):
             # STORAGE 'bf16' = BASELINE config 4's arithmetic for the Conv2d chain (ops.set_storage), HIP_GRAPH = replay the train step
             # from a captured hipGraph (graph.GraphedStep, single-GPU runs)
-            "STORAGE": "f32", "HIP_GRAPH": False},
+            # CHAIN1D False = the generator's Conv1d blocks one by one: the one-launch chain spins on clusters of co-resident workgroups, so a GPU
+            # that two training processes share must not run two of them at once (each would wait for CUs the other one holds until the spin limit
+            # trips and the Trainer raises)
+            "STORAGE": "f32", "HIP_GRAPH": False, "CHAIN1D": True},
 }
 
 

@@ -178,6 +178,8 @@ class Voice2Pose(Trainer):
         super().__init__(cfg)
 
     def setup_model(self, cfg, state_dict=None, external_codes=None):
+        if not getattr(cfg.SYS, 'CHAIN1D', True):
+            ops.CHAIN1D = False  # process-wide, like the storage mode
         if getattr(cfg.SYS, 'STORAGE', 'f32') != 'f32':
             ops.set_storage(cfg.SYS.STORAGE)  # before setup_optimizer: its weight mirrors allocate the bf16 copies
         self.model = Voice2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank(), external_codes).cuda()
