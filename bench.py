@@ -390,7 +390,7 @@ def main(argv=None):
 
     if rank == 0:
         out = {
-            "metric": "training clips/sec (64-frame, 137-kpt) voice2pose_sdt_bp",
+            "metric": "training clips/sec (64-frame, 137-kpt) %s" % args.config,  # BASELINE.json's metric is quoted on the default config
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16 (Conv2d chain: bf16 tensors in HBM, bf16 MFMA products, fp32 accumulation / statistics / master weights / gradients; "

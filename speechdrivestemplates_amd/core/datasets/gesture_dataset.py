@@ -31,11 +31,19 @@ class PoseTransforms:
     """normalize / denormalize / parted<->global / get_final_results with the reference semantics."""
     root_node, hand_root_l, hand_root_r, head_root = 1, HAND_ROOT_L, HAND_ROOT_R, HEAD_ROOT
 
+    _STAT_ON_DEVICE = {}  # (id(ndarray), device) -> (ndarray kept alive, fp32 tensor): registered statistics are uploaded once, not per step
+
     def _stat(self, t, kp):
         K = self.cfg.NUM_LANDMARKS
         if isinstance(t, np.ndarray):
-            t = torch.tensor(t.astype(np.float64), dtype=torch.float32)  # torch.Tensor(ndarray) -> float32, :174-176
-        t = t.to(kp.device)
+            key = (id(t), str(kp.device))
+            hit = PoseTransforms._STAT_ON_DEVICE.get(key)
+            if hit is None or hit[0] is not t:
+                # torch.Tensor(ndarray) -> float32, :174-176.  (A host-to-device copy per call also made the step un-capturable in a hipGraph.)
+                hit = PoseTransforms._STAT_ON_DEVICE[key] = (t, torch.tensor(t.astype(np.float64), dtype=torch.float32).to(kp.device))
+            t = hit[1]
+        else:
+            t = t.to(kp.device)
         if t.dim() == 1:
             return t.reshape(1, 2, K)
         if t.dim() == 2:
@@ -48,16 +56,29 @@ class PoseTransforms:
     def denormalize_poses(self, kp, speaker_stat):
         return kp * self._stat(speaker_stat['std'], kp) + self._stat(speaker_stat['mean'], kp)
 
+    _PART_INDEX = {}  # device -> (keypoints that hang off a part root, the root of each): built once, so that the transforms below copy no
+                      # index list to the device per call (which also kept the s2g train step from being captured into a hipGraph)
+
+    @staticmethod
+    def _part_index(device):
+        key = str(device)
+        if key not in PoseTransforms._PART_INDEX:
+            sel = list(_HEAD_IDX) + list(range(79, 100)) + list(range(100, 121))
+            root = [HEAD_ROOT] * len(_HEAD_IDX) + [HAND_ROOT_L] * 21 + [HAND_ROOT_R] * 21
+            PoseTransforms._PART_INDEX[key] = (torch.tensor(sel, dtype=torch.int64, device=device), torch.tensor(root, dtype=torch.int64, device=device))
+        return PoseTransforms._PART_INDEX[key]
+
     def parted_to_global(self, poses):
-        poses[..., :2, _HEAD_IDX] = poses[..., :2, _HEAD_IDX] + poses[..., :2, HEAD_ROOT, None]
-        poses[..., :2, 79:100] = poses[..., :2, 79:100] + poses[..., :2, HAND_ROOT_L, None]
-        poses[..., :2, 100:121] = poses[..., :2, 100:121] + poses[..., :2, HAND_ROOT_R, None]
+        """gesture_dataset.py:147-155, in place: head / hand keypoints += their part's root (the roots themselves are in no part)."""
+        sel, root = self._part_index(poses.device)
+        xy = poses[..., :2, :]
+        xy.index_add_(-1, sel, xy.index_select(-1, root))
         return poses
 
     def global_to_parted(self, poses):
-        poses[..., :2, _HEAD_IDX] = poses[..., :2, _HEAD_IDX] - poses[..., :2, HEAD_ROOT, None]
-        poses[..., :2, 79:100] = poses[..., :2, 79:100] - poses[..., :2, HAND_ROOT_L, None]
-        poses[..., :2, 100:121] = poses[..., :2, 100:121] - poses[..., :2, HAND_ROOT_R, None]
+        sel, root = self._part_index(poses.device)
+        xy = poses[..., :2, :]
+        xy.index_add_(-1, sel, xy.index_select(-1, root), alpha=-1)
         return poses
 
     def get_speaker_stat(self, speaker, num_kp, parted):
