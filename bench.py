@@ -394,7 +394,7 @@ def main(argv=None):
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16 (Conv2d chain: bf16 tensors in HBM, bf16 MFMA products, fp32 accumulation / statistics / master weights / gradients; "
-                      "1-D stage fp32)" if args.storage == "bf16" else
+                      "generator Conv1d chain: fp32 tensors, bf16 MFMA products; 1-D weight gradients, head, losses fp32)" if args.storage == "bf16" else
                       ("f32" if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math)),
             "data": "synthetic",
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
@@ -533,7 +533,7 @@ def main(argv=None):
                 ops.set_storage("f32")
             assert alt_loss == alt_loss and alt_loss < 10.0, "bf16 leg diverged: G_loss=%r" % alt_loss
             out["alt_conv_math"] = {"mode": "bf16", "dtype": "bf16 (Conv2d chain: bf16 tensors in HBM + bf16 MFMA products; fp32 accumulation, statistics, "
-                                                             "master weights, gradients; 1-D stage exact fp32)",
+                                                             "master weights, gradients; generator Conv1d chain: fp32 tensors, bf16 MFMA products; 1-D weight gradients, head, losses fp32)",
                                     "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt, "graph": True,
                                     "eager_ms_per_step": eager_ms, "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
                                     "note": "not the headline (the metric is quoted on the reference's fp32 arithmetic): %d further steps of the same run in "

@@ -320,10 +320,12 @@ int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayers, int B);
 /* zout (B, To_last, 256) = act(norm(y[nlayers-1])).  counters: >= min(B, 8 * (CUs / 64)) zero-initialised uint32 (zero again when a launch ends); err: one uint32
  * that a launch sets non-zero when a workgroup gave up waiting for its cluster (sdt_convsk_set_spin_limit) -- results are then invalid. */
 int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* x0, float* zout, int B, float slope, float eps,
-                        void* counters, void* err, void* stream);
-/* gz (B, To_last, 256): gradient of zout.  Writes dy of every block and dx of every block (block 0 only when need_dx0). */
+                        int math, void* counters, void* err, void* stream);
+/* math: SDT_MATH_F32 (exact fp32 products, the default everywhere) or SDT_MATH_BF16 (products of bf16-rounded operands on the bf16 MFMA,
+ * fp32 tensors and accumulation: what the bf16-storage step -- BASELINE config 4 -- runs; the global sdt_set_conv_math is NOT consulted).
+ * gz (B, To_last, 256): gradient of zout.  Writes dy of every block and dx of every block (block 0 only when need_dx0). */
 int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* gz, int B, float slope, float eps, int need_dx0,
-                        void* counters, void* err, void* stream);
+                        int math, void* counters, void* err, void* stream);
 
 /* nn.L1Loss(reduction='none')(pred,gt)*lambda .mean() (voice2pose.py:141-142). partial: >=256 doubles. */
 int sdt_l1_loss_fwd_f32(const float* pred, const float* gt, int64_t n, float lambda, double* partial, float* loss, void* stream);

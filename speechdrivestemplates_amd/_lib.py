@@ -78,8 +78,8 @@ SIGNATURES = {
     "sdt_resize_concat_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_upsample_add_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "sdt_chain1d_supported": [C.POINTER(ChainLayer), _i, _i],
-    "sdt_chain1d_fwd_f32": [C.POINTER(ChainLayer), _i, _p, _p, _i, _f, _f, _p, _p, _p],
-    "sdt_chain1d_bwd_f32": [C.POINTER(ChainLayer), _i, _p, _i, _f, _f, _i, _p, _p, _p],
+    "sdt_chain1d_fwd_f32": [C.POINTER(ChainLayer), _i, _p, _p, _i, _f, _f, _i, _p, _p, _p],
+    "sdt_chain1d_bwd_f32": [C.POINTER(ChainLayer), _i, _p, _i, _f, _f, _i, _i, _p, _p, _p],
     "sdt_upsample_add_bwd_f32": [_p, _p, _i, _i, _i, _i, _p],
     "sdt_l1_loss_fwd_f32": [_p, _p, _i64, _f, _p, _p, _p],
     "sdt_l1_loss_bwd_f32": [_p, _p, _p, _i64, _f, _p, _p],

@@ -209,7 +209,11 @@ __device__ __forceinline__ void ch_barrier() {  // LDS traffic of this wave done
 // then per group of four MFMAs two fragment reads of a later group and two feeding instructions (LDS stores of chunk C + 1 into the other ring
 // slot, then the requests for chunk C + 1 + CH_D into the registers just stored) -- tools/mfma_peak.hip: at one wave per SIMD the matrix pipe
 // idles through every feeding instruction that is not issued under an MFMA.
-template <int NJ, int NCH, int C, typename RowFn>
+typedef __bf16 ch_bf16x8 __attribute__((ext_vector_type(8)));
+// BF: products of bf16-rounded operands on v_mfma_f32_32x32x16_bf16 (SDT_MATH_BF16: the arithmetic of a bf16 run; tensors, LDS tiles and the
+// accumulation stay fp32).  Two 4-float fragment reads per lane = the 8 k values of one MFMA, converted (RNE) in registers: 1/16 of the matrix
+// pipe's time per product, after which the K loop is bound by its fragment reads and barriers.
+template <bool BF, int NJ, int NCH, int C, typename RowFn>
 __device__ __forceinline__ void ch_chunk(ch_wstream& S, f32x16& acc, const float* xs, int RS, float* wb, int CK, int m, RowFn rowfn, int koff, int lane) {
     constexpr int NS = (C + 1) % CH_D;
     constexpr int NW = (C + 1 < NCH) ? 4 : 0, NV = (C + 1 + CH_D < NCH) ? 4 : 0, NF = NW + NV;
@@ -241,16 +245,29 @@ __device__ __forceinline__ void ch_chunk(ch_wstream& S, f32x16& acc, const float
                 CH_ABL_LOAD(S.rg[NS][f - NW] = *(const f32x4*)(S.Wcol + S.goff[f - NW] + (S.ok[f - NW] ? cnext : 0)));
             }
         }
-        CH_MFMA(acc, a[j][0], b[j][0]);
-        CH_MFMA(acc, a[j][1], b[j][1]);
-        CH_MFMA(acc, a[j][2], b[j][2]);
-        CH_MFMA(acc, a[j][3], b[j][3]);
+        if constexpr (!BF) {
+            CH_MFMA(acc, a[j][0], b[j][0]);
+            CH_MFMA(acc, a[j][1], b[j][1]);
+            CH_MFMA(acc, a[j][2], b[j][2]);
+            CH_MFMA(acc, a[j][3], b[j][3]);
+        } else if ((j & 1) || j + 1 == NJ) {  // a pair of fragment groups (an odd last group alone, zero-padded) = one bf16 MFMA
+            const int j0 = (j & 1) ? j - 1 : j;
+            ch_bf16x8 av, bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[e] = (__bf16)a[j0][e];
+                bv[e] = (__bf16)b[j0][e];
+                av[4 + e] = (j0 + 1 < NJ) ? (__bf16)a[j0 + 1 < NJ ? j0 + 1 : j0][e] : (__bf16)0.f;
+                bv[4 + e] = (j0 + 1 < NJ) ? (__bf16)b[j0 + 1 < NJ ? j0 + 1 : j0][e] : (__bf16)0.f;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        }
     }
-    // the same order for the scheduler
+    // the same order for the scheduler (fp32 only: the bf16 loop has an eighth of the MFMAs and is left to the compiler)
 #pragma unroll
-    for (int j = 0; j < 2 * LEAD; ++j) CH_SGB(0x100);
+    for (int j = 0; j < (BF ? 0 : 2 * LEAD); ++j) CH_SGB(0x100);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < (BF ? 0 : NJ); ++j) {
         const int f0 = j * PER < NF ? j * PER : NF, f1 = (j + 1) * PER < NF ? (j + 1) * PER : NF;
         CH_SGB(0x008);
         if (j + LEAD < NJ) CH_SGB(0x100);
@@ -269,13 +286,13 @@ __device__ __forceinline__ void ch_chunk(ch_wstream& S, f32x16& acc, const float
         }
     }
     ch_barrier();
-    if constexpr (C + 1 < NCH) ch_chunk<NJ, NCH, C + 1>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
+    if constexpr (C + 1 < NCH) ch_chunk<BF, NJ, NCH, C + 1>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
 }
 
 // acc (one 32 x 32 tile per wave) = A (rows from LDS through rowfn) x W[n0 .. n0+32)^T over the stream S (K = ntap * CK floats per column); then
 // the K splits are reduced through LDS and rows [0, M) x 32 columns are published to `out` (row stride ldo floats).
 // rowfn(m, tap) -> LDS row of xs that multiplies tap `tap` for output row m.
-template <int NJ, int NCH, typename RowFn>
+template <bool BF, int NJ, int NCH, typename RowFn>
 __device__ __forceinline__ void ch_gemm_store_nj(ch_wstream& S, const float* xs, int RS, float* wb, int CK, int M, RowFn rowfn,
                                                 const __amdgpu_buffer_rsrc_t rsOut, int ldo, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,7 +310,7 @@ __device__ __forceinline__ void ch_gemm_store_nj(ch_wstream& S, const float* xs,
     ch_w_to_lds<0>(S, wb, 0);
     if constexpr (CH_D < NCH) ch_w_issue<0>(S, CH_D);
     ch_barrier();
-    ch_chunk<NJ, NCH, 0>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
+    ch_chunk<BF, NJ, NCH, 0>(S, acc, xs, RS, wb, CK, m, rowfn, koff, lane);
     // K splits -> LDS (the weight ring is free: the loop ended on a barrier), summed in split order, published
     float* red = wb;
 #pragma unroll
@@ -314,18 +331,18 @@ __device__ __forceinline__ void ch_gemm_store_nj(ch_wstream& S, const float* xs,
 
 // (MFMA groups per chunk, chunks) of the blocks this kernel is built for: 64-frame k3 blocks (8, 6), the 288-channel first block (6, 9), blocks of
 // <= 32 frames with k3 (4, 6; 3, 9 with 288 channels) / k4 (4, 8), the input gradient of the first strided block (64 frames, k4: 8, 8); chain_check() admits nothing else.
-template <typename RowFn>
+template <bool BF, typename RowFn>
 __device__ __forceinline__ void ch_gemm_store(ch_wstream& S, const float* xs, int RS, float* wb, int CK, int M, RowFn rowfn,
                                              const __amdgpu_buffer_rsrc_t rsOut, int ldo, int n0) {
     const int nj = (S.KC / (M > 32 ? 2 : 4)) >> 3;
     const int key = nj * 16 + S.nch;
     switch (key) {
-        case 8 * 16 + 6: ch_gemm_store_nj<8, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
-        case 8 * 16 + 8: ch_gemm_store_nj<8, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
-        case 6 * 16 + 9: ch_gemm_store_nj<6, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
-        case 4 * 16 + 6: ch_gemm_store_nj<4, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
-        case 3 * 16 + 9: ch_gemm_store_nj<3, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
-        default: ch_gemm_store_nj<4, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 8 * 16 + 6: ch_gemm_store_nj<BF, 8, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 8 * 16 + 8: ch_gemm_store_nj<BF, 8, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 6 * 16 + 9: ch_gemm_store_nj<BF, 6, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 4 * 16 + 6: ch_gemm_store_nj<BF, 4, 6>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        case 3 * 16 + 9: ch_gemm_store_nj<BF, 3, 9>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
+        default: ch_gemm_store_nj<BF, 4, 8>(S, xs, RS, wb, CK, M, rowfn, rsOut, ldo, n0); break;
     }
 }
 
@@ -383,6 +400,7 @@ __device__ __forceinline__ void ch_put_row(float* dst, const ch_row& a, int li) 
     for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * (li + 16 * q)) = a.v[q];
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int dead;
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
         CH_TL(l, 1);
         const int stride = L.stride;
         const __amdgpu_buffer_rsrc_t rsY = ch_rsrc(L.y + (size_t)clip * L.To * CH_C, L.To * CH_C * 4);
-        ch_gemm_store(S, xs, RS, wb, L.Cin, L.To, [stride](int m, int tap) { return m * stride + tap; }, rsY, CH_C, 32 * r);
+        ch_gemm_store<BF>(S, xs, RS, wb, L.Cin, L.To, [stride](int m, int tap) { return m * stride + tap; }, rsY, CH_C, 32 * r);
         CH_TL(l, 2);
         ch_arrive(cnt, total);
         CH_TL(l, 3);
@@ -588,6 +606,7 @@ __device__ __forceinline__ void ch_bwd_frames(const ch_args& A, const ch_layer& 
     }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int dead;
@@ -654,11 +673,11 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
                 const int to = num / stride;
                 return (num - to * stride == 0 && to < To) ? 1 + to : 0;
             };
-            ch_gemm_store(S, ds, RS, wb, CH_C, L.Ti, rowfn, rsD, L.Cin, 32 * r);
+            ch_gemm_store<BF>(S, ds, RS, wb, CH_C, L.Ti, rowfn, rsD, L.Cin, 32 * r);
             for (int n0 = 32 * r + 256; n0 < L.Cin; n0 += 256) {  // a 288-channel first block: member 0 also owns columns 256 .. 287
                 ch_w_setup(S, L.wt + (size_t)n0 * L.k * CH_C, L.k * CH_C, CH_KCMAX);
                 ch_w_prefetch(S);
-                ch_gemm_store(S, ds, RS, wb, CH_C, L.Ti, rowfn, rsD, L.Cin, n0);
+                ch_gemm_store<BF>(S, ds, RS, wb, CH_C, L.Ti, rowfn, rsD, L.Cin, n0);
             }
         }
         CH_TL(s, 2);
@@ -762,10 +781,11 @@ extern "C" int sdt_chain1d_supported(const sdt_chain1d_layer* layers, int nlayer
 }
 
 extern "C" int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* x0, float* zout, int B, float slope, float eps,
-                                   void* counters, void* err, void* stream) {
+                                   int math, void* counters, void* err, void* stream) {
     int rc = chain_check(layers, nlayers, B);
     if (rc != SDT_OK) return rc;
     SDT_CHECK_ARG(x0 != nullptr && zout != nullptr && counters != nullptr && err != nullptr, "NULL tensor");
+    SDT_CHECK_ARG(math == SDT_MATH_F32 || math == SDT_MATH_BF16, "product arithmetic must be SDT_MATH_F32 or SDT_MATH_BF16");
     ch_args A;
     rc = chain_fill(A, layers, nlayers, B, slope, eps, (unsigned*)counters, (unsigned*)err, false);
     if (rc != SDT_OK) return rc;
@@ -775,7 +795,8 @@ extern "C" int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers,
     A.need_dx0 = 0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)chain1d_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
+        (void)hipFuncSetAttribute((const void*)chain1d_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
+        (void)hipFuncSetAttribute((const void*)chain1d_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
         attr_set = true;
     }
     const int per = chain_clips_per_launch();
@@ -783,17 +804,19 @@ extern "C" int sdt_chain1d_fwd_f32(const sdt_chain1d_layer* layers, int nlayers,
     for (int c0 = 0; c0 < B; c0 += per) {
         A.clip0 = c0;
         const int nclip = std::min(per, B - c0);
-        hipLaunchKernelGGL(chain1d_fwd_kernel, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+        if (math == SDT_MATH_BF16) hipLaunchKernelGGL(chain1d_fwd_kernel<true>, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL(chain1d_fwd_kernel<false>, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
     }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
 
 extern "C" int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers, const float* gz, int B, float slope, float eps, int need_dx0,
-                                   void* counters, void* err, void* stream) {
+                                   int math, void* counters, void* err, void* stream) {
     int rc = chain_check(layers, nlayers, B);
     if (rc != SDT_OK) return rc;
     SDT_CHECK_ARG(gz != nullptr && counters != nullptr && err != nullptr, "NULL tensor");
+    SDT_CHECK_ARG(math == SDT_MATH_F32 || math == SDT_MATH_BF16, "product arithmetic must be SDT_MATH_F32 or SDT_MATH_BF16");
     ch_args A;
     rc = chain_fill(A, layers, nlayers, B, slope, eps, (unsigned*)counters, (unsigned*)err, true);
     if (rc != SDT_OK) return rc;
@@ -804,7 +827,8 @@ extern "C" int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers,
     SDT_CHECK_ARG(!need_dx0 || (layers[0].wt != nullptr && layers[0].dx != nullptr), "need_dx0 without wt / dx of block 0");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)chain1d_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
+        (void)hipFuncSetAttribute((const void*)chain1d_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
+        (void)hipFuncSetAttribute((const void*)chain1d_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
         attr_set = true;
     }
     const int per = chain_clips_per_launch();
@@ -812,7 +836,8 @@ extern "C" int sdt_chain1d_bwd_f32(const sdt_chain1d_layer* layers, int nlayers,
     for (int c0 = 0; c0 < B; c0 += per) {
         A.clip0 = c0;
         const int nclip = std::min(per, B - c0);
-        hipLaunchKernelGGL(chain1d_bwd_kernel, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+        if (math == SDT_MATH_BF16) hipLaunchKernelGGL(chain1d_bwd_kernel<true>, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL(chain1d_bwd_kernel<false>, dim3(64 * ((nclip + 7) / 8)), dim3(256), kChainLds, (hipStream_t)stream, A);
     }
     SDT_LAUNCH_CHECK();
     return SDT_OK;

@@ -1402,6 +1402,15 @@ class UpsampleAddFn(torch.autograd.Function):
 # The generator's Conv1d stage as ONE persistent launch per direction (csrc/chain1d.hip): 8 workgroups per clip, raw conv outputs handed from
 # block to block inside the launch, normalisation + activation (+ upsampling + skip) applied by the consumer on load.
 CHAIN1D = True
+# product arithmetic of the chain launches: None = follow the storage mode (exact fp32 with fp32 storage; products of bf16-rounded operands on the
+# bf16 MFMA in a bf16-storage run, like its Conv2d chain: BASELINE config 4), or 'f32' / 'bf16' to pin it
+CHAIN_MATH = None
+
+
+def chain_math():
+    mode = CHAIN_MATH if CHAIN_MATH is not None else STORAGE
+    return CONV_MATH['bf16'] if mode == 'bf16' else CONV_MATH['f32']
+
 _CHAIN_WS = {}  # device index -> int32 [64 cluster counters | error word]
 _CHAIN_ERR = 64
 
@@ -1482,6 +1491,7 @@ class Chain1dFn(torch.autograd.Function):
         lib = _lib.load()
         h = h.contiguous()
         B, T0, Cin0 = h.shape
+        math = ctx.math = chain_math()
         blocks = chain_blocks(spec, T0, Cin0)
         n = len(blocks)
         dev = h.device
@@ -1501,8 +1511,8 @@ class Chain1dFn(torch.autograd.Function):
         flops = sum(2.0 * B * To * 256 * k * Cin for (Ti, To, Cin, k, *_r) in blocks)
         nbytes = 4.0 * (h.numel() + zout.numel() + sum(w.numel() for w in weights))
         st = _stream()
-        _chain_launch("chain1d_fwd_kernel", "fwd", flops, nbytes,
-                      lambda: lib.sdt_chain1d_fwd_f32(tab, n, _p(h), _p(zout), B, float(slope), BN_EPS, ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
+        _chain_launch("chain1d_fwd_kernel" + (" bf16" if math else ""), "fwd", flops, nbytes,
+                      lambda: lib.sdt_chain1d_fwd_f32(tab, n, _p(h), _p(zout), B, float(slope), BN_EPS, math, ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
         ctx.blocks, ctx.slope, ctx.xs = blocks, float(slope), xs
         if want_grad:
             # everything backward() needs besides the gradient itself is prepared HERE: in a train step the host is about a millisecond ahead of
@@ -1549,8 +1559,8 @@ class Chain1dFn(torch.autograd.Function):
                 raise RuntimeError("the weight mirrors were rebuilt between forward and backward")
         ws = _chain_ws(h.device)
         tab = ctx.btab
-        _chain_launch("chain1d_bwd_kernel", "dX", ctx.bflops, ctx.bbytes,
-                      lambda: lib.sdt_chain1d_bwd_f32(tab, n, _p(gz), B, ctx.slope, BN_EPS, int(need_dx0), ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
+        _chain_launch("chain1d_bwd_kernel" + (" bf16" if ctx.math else ""), "dX", ctx.bflops, ctx.bbytes,
+                      lambda: lib.sdt_chain1d_bwd_f32(tab, n, _p(gz), B, ctx.slope, BN_EPS, int(need_dx0), ctx.math, ws.data_ptr(), ws.data_ptr() + 4 * _CHAIN_ERR, st))
         for l, (b, w) in enumerate(zip(blocks, weights)):  # weight gradients: the per-block launches, deferred to the side stream inside a train step
             if w.requires_grad:
                 _conv_backward(h if l == 0 else xs[l], w, None, dys[l], b[4], b[5], False)

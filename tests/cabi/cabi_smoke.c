@@ -39,11 +39,11 @@ int main(void) {
         L[1] = L[0];
         L[1].Cin = 256, L[1].in_mode = SDT_CHAIN_NORM, L[1].src_a = 1; /* a block cannot read itself */
         L[0].w = L[1].w = &dummy, L[0].y = L[1].y = &dummy;
-        rc = sdt_chain1d_fwd_f32(L, 2, &dummy, &dummy, 4, 0.2f, 1e-5f, words, words + 1, NULL);
+        rc = sdt_chain1d_fwd_f32(L, 2, &dummy, &dummy, 4, 0.2f, 1e-5f, SDT_MATH_F32, words, words + 1, NULL);
         if (rc != SDT_ERR_ARG) return 24;
         L[1].src_a = 0, L[1].k = 5, L[1].pad = 2; /* no K loop was built for a 5-tap block */
         if (sdt_chain1d_supported(L, 2, 4) != 0) return 25;
-        if (sdt_chain1d_bwd_f32(NULL, 2, &dummy, 4, 0.2f, 1e-5f, 1, words, words + 1, NULL) != SDT_ERR_ARG) return 26;
+        if (sdt_chain1d_bwd_f32(NULL, 2, &dummy, 4, 0.2f, 1e-5f, 1, SDT_MATH_F32, words, words + 1, NULL) != SDT_ERR_ARG) return 26;
     }
     puts("C ABI OK");
     return 0;

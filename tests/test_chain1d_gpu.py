@@ -102,6 +102,51 @@ def test_chain_full_batch_with_the_leaky_slope():
     assert float(per_clip.max()) <= 0.1, "more than an activation kink's worth: %s" % per_clip.tolist()
 
 
+def test_chain_with_bf16_products_follows_the_per_block_kernels_in_bf16_math():
+    """ops.CHAIN_MATH = 'bf16' (what a bf16-storage run selects): products of bf16-rounded operands on the bf16 MFMA, fp32 tensors and accumulation --
+    the arithmetic of the per-block kernels under set_conv_math('bf16').
+    (a) ONE block (no upstream rounding decisions): identical operands, exact products, only the fp32 summation order differs -> 1e-5 (forward).
+    (b) the whole chain: a last-bit difference upstream moves a value across a bf16 rounding boundary now and then, and sixteen normalised layers
+        amplify such flips to the size of bf16's own error -- so the two bf16 computations are each compared with the fp32 chain: the chain's bf16
+        deviation must be of the per-block kernels' size (within 1.5x), and their mutual distance no larger than those deviations."""
+    from speechdrivestemplates_amd import _lib, ops
+    B, T, cin0 = 8, 64, 288
+    torch.manual_seed(5)
+    ws_a, ws_b = _weights(cin0, 7), _weights(cin0, 7)
+    h = torch.randn((B, T, cin0), device="cuda")
+    gz = torch.randn((B, T, 256), device="cuda")
+
+    def run(fn, math_chain, math_global):
+        x = h.detach().clone().requires_grad_(True)
+        ops.begin_step(torch.device("cuda", 0))
+        ops.CHAIN_MATH = math_chain
+        ops.set_conv_math(math_global)
+        try:
+            z = fn(x)
+            z.backward(gz[:, :z.shape[1]])
+        finally:
+            ops.CHAIN_MATH = None
+            ops.set_conv_math("f32")
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        return z.detach(), x.grad
+
+    one = (_wiring()[0],)
+    z1a, g1a = run(lambda x: ops.Chain1dFn.apply(x, one, SLOPE, ws_a[0]), "bf16", "f32")
+    z1b, g1b = run(lambda x: ops.ConvRowNormFn.apply(x, ws_b[0], 1, 1, SLOPE), None, "bf16")
+    # forward: measured 3e-7.  The gradient's first operand (the normalisation backward of gz) is itself rounded to bf16: its last-bit differences
+    # between the two implementations move a few of its 131072 values across a rounding boundary (measured 1.1e-5)
+    assert _rel(z1a, z1b) <= 1e-5 and _rel(g1a, g1b) <= 1e-4, (_rel(z1a, z1b), _rel(g1a, g1b))
+    z_f, g_f = run(lambda x: ops.Chain1dFn.apply(x, _wiring(), 1.0, *ws_a), "f32", "f32")
+    z_a, g_a = run(lambda x: ops.Chain1dFn.apply(x, _wiring(), 1.0, *ws_a), "bf16", "f32")
+    z_b, g_b = run(lambda x: _per_block(x, ws_b, 1.0), None, "bf16")
+    assert not ops.streamk_error_codes()
+    for name, a, b, f in (("z", z_a, z_b, z_f), ("dh", g_a, g_b, g_f)):
+        ea, eb, eab = _rel(a, f), _rel(b, f), _rel(a, b)
+        print("  %s: chain bf16 vs fp32 %.2e, per-block bf16 vs fp32 %.2e, chain vs per-block %.2e" % (name, ea, eb, eab))
+        assert 1e-4 < ea <= 1.5 * eb + 1e-3 and eab <= 1.2 * max(ea, eb), (name, ea, eb, eab)
+
+
 def test_chain_leaves_its_counters_at_zero_and_replays():
     """two launches back to back on the same counters (what a hipGraph replay does): the second sees them lowered"""
     from speechdrivestemplates_amd import ops
