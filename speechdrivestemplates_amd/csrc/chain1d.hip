@@ -537,7 +537,7 @@ struct ch_bwd_src {
 // gradient of the raw output of frames t0 + fq (one pass of a wave): gather the output gradient, normalisation backward (norm.hip rownorm_kernel<BWD>)
 template <bool UP, bool TWO>
 __device__ __forceinline__ void ch_bwd_frames(const ch_args& A, const ch_layer& L, const ch_bwd_src& G, const float* ysrc, float* dyo, float* ds, int RS,
-                                              int t0, int fq, int li, int r) {
+                                              int t0, int fq, int li, int r, const ch_row* ypre) {
     constexpr int NP = UP ? 1 : 4;  // frames in flight per lane group: a 64-frame block is one batch of loads per wave
     ch_row g[NP], yv[NP], up[UP ? 6 : 1];
     float uw[UP ? 6 : 1];
@@ -550,9 +550,13 @@ __device__ __forceinline__ void ch_bwd_frames(const ch_args& A, const ch_layer& 
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[p].v[q] += g1.v[q];
         }
+        if constexpr (!UP) {
+            yv[p] = ypre[p];  // requested before the wait for the cluster (the forward launch wrote it: no dependence on this launch's progress)
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            yv[p].v[q] = t < L.To ? *(const f32x4*)(ysrc + (size_t)t * CH_C + 4 * (li + 16 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q)
+                yv[p].v[q] = t < L.To ? *(const f32x4*)(ysrc + (size_t)t * CH_C + 4 * (li + 16 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         if constexpr (UP) {
             const int jlo = (int)floorf(((float)t - 0.5f) / G.usc - 0.5f) - 1;
 #pragma unroll
@@ -638,9 +642,19 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
             ch_w_setup(S, L.wt + (size_t)(32 * r) * L.k * CH_C, L.k * CH_C, CH_KCMAX);
             ch_w_prefetch(S);
         }
+        const float* ysrc = L.y + (size_t)clip * L.To * CH_C;
+        ch_row ypre[4];
+        if (L.g_up < 0) {  // the block's own raw output (HBM by now): in flight across the wait, like the weights
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int t = wave * 16 + 4 * p + fq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ypre[p].v[q] = t < L.To ? *(const f32x4*)(ysrc + (size_t)t * CH_C + 4 * (li + 16 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
         ch_wait(cnt, 8u * (unsigned)s, A, &dead, 64 + l);
         CH_TL(s, 0);
-        const float* ysrc = L.y + (size_t)clip * L.To * CH_C;
         float* dyo = L.dy + (size_t)clip * L.To * CH_C;
         const bool ext0 = L.g_id0 == A.n;
         const ch_layer& G0 = A.L[(L.g_id0 >= 0 && !ext0) ? L.g_id0 : 0];
@@ -656,10 +670,10 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
         G.TiU = GU.Ti;
         G.usc = G.up ? (float)L.To / (float)GU.Ti : 1.f;  // upsampling source index scale: in / out
         if (G.up) {
-            for (int t0 = wave * 4; t0 < L.To; t0 += 16) ch_bwd_frames<true, true>(A, L, G, ysrc, dyo, ds, RS, t0, fq, li, r);
+            for (int t0 = wave * 4; t0 < L.To; t0 += 16) ch_bwd_frames<true, true>(A, L, G, ysrc, dyo, ds, RS, t0, fq, li, r, ypre);
         } else if (wave * 16 < L.To) {  // <= 64 frames: one batch per wave
-            if (L.g_id1 >= 0) ch_bwd_frames<false, true>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r);
-            else ch_bwd_frames<false, false>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r);
+            if (L.g_id1 >= 0) ch_bwd_frames<false, true>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r, ypre);
+            else ch_bwd_frames<false, false>(A, L, G, ysrc, dyo, ds, RS, wave * 16, fq, li, r, ypre);
         }
         __syncthreads();
         CH_TL(s, 1);

@@ -41,7 +41,9 @@ def report(tl, nwg, nsteps, names):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16"], help="bf16: products of bf16-rounded operands (what a bf16-storage run selects)")
     a = ap.parse_args()
+    ops.CHAIN_MATH = a.math
     lib = _lib.load()
     lib.sdt_debug_set_timeline_chain.argtypes = [ctypes.c_void_p]
     B = a.batch
