@@ -214,7 +214,8 @@ int sdt_col_sum_f32(const float* x, float* out, int64_t rows, int c, void* strea
  * and the arithmetic stay fp32, only what moves through HBM is bf16.  Built combinations: all fp32; forward y bf16 -> z bf16 | fp32;
  * backward y and dy bf16 with dz bf16 | fp32.
  * fwd writes z, mean[G*C], rstd[G*C]; if running_mean != NULL updates running stats with
- * momentum (unbiased variance), as nn.BatchNorm does in training mode.
+ * momentum (unbiased variance), as nn.BatchNorm does in training mode -- with G > 1 as G consecutive calls of the module on the G
+ * slices would: G updates in slice order, num_batches_tracked += G (the two no-grad pose-encoder passes of a train step in one launch).
  * eval: z = act(gamma*(y-running_mean)/sqrt(running_var+eps)+beta).
  */
 int sdt_colnorm_fwd_f32(const float* y, float* z, double* sums, float* mean, float* rstd,

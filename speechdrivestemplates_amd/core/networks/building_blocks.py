@@ -44,13 +44,15 @@ class ConvNormRelu(nn.Module):
         return (self.conv_type == '2d' and c.in_channels == 1 and c.out_channels == 64 and tuple(c.kernel_size) == (3, 3)
                 and self.stride == 1 and self.padding == 1 and (self.norm_type == 'IN' or self.training))
 
-    def forward_cl(self, x_cl, in_holder=None, out_holder=None, out_f32=False):
+    def forward_cl(self, x_cl, in_holder=None, out_holder=None, out_f32=False, bn_groups=1):
         """(B,H,W,Cin)|(B,T,Cin) channels-last -> (B,Ho,Wo,Cout)|(B,To,Cout) channels-last.
         ``in_holder`` / ``out_holder`` (ops.NormBwdHolder, 2-D blocks of a strictly sequential chain only): ``x_cl`` is the output of
         the normalisation that filled ``in_holder`` and has no other consumer; this block's normalisation fills ``out_holder``.
         bf16-storage path (ops.STORAGE == 'bf16'): the first block writes bf16, a 2-D block whose input is bf16 runs the bf16 kernels and
         hands bf16 on -- fp32 with ``out_f32`` (the last encoder block, whose consumer is the fp32 1-D stage); a block the bf16 kernels do
-        not cover converts its input and continues in fp32."""
+        not cover converts its input and continues in fp32.
+        ``bn_groups`` > 1 (no-grad forward of a training-mode BatchNorm block only): the batch holds that many equal slices that the reference
+        sends through the module one call after the other -- batch statistics per slice, running statistics updated slice by slice."""
         if self._is_l0_block():  # single-channel mel image: conv + norm + activation fused, output written once
             n = self.norm
             if self.norm_type == 'IN':
@@ -80,7 +82,9 @@ class ConvNormRelu(nn.Module):
             return ops.RowNormActFn.apply(y, self.slope)  # InstanceNorm1d on the permuted tensor == norm over C
         n = self.norm
         if self.training:
-            return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, 1,
+            if bn_groups > 1 and (torch.is_grad_enabled() and y.requires_grad):
+                raise RuntimeError("bn_groups > 1 is a no-grad path (the affine gradients of a grouped launch are not built)")
+            return ops.ColNormActFn.apply(y, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked, int(bn_groups),
                                           self.slope, None, out_holder if self.conv_type == '2d' else None)
         if torch.is_grad_enabled() and y.requires_grad:
             raise RuntimeError("eval-mode BatchNorm is an inference-only path in this engine (wrap in torch.no_grad())")

@@ -27,6 +27,19 @@ class PoseSeqEncoder(nn.Module):
         return h[:, 0::2], h[:, 1::2]
 
 
+    def forward_pair(self, xa, xb):
+        """forward(xa), forward(xb) -- the two no-grad calls of a train step (voice2pose.py:160-176) -- as ONE pass over the concatenated batch:
+        half the launches of a stack whose launches are latency-bound.  BatchNorm blocks in training mode normalise each half with its own batch
+        statistics and update their running statistics half by half (``bn_groups=2``), so results and buffers equal the two calls'."""
+        assert xa.shape == xb.shape and not (torch.is_grad_enabled() and (xa.requires_grad or xb.requires_grad))
+        B = xa.shape[0]
+        h = torch.cat([xa.reshape(B, xa.shape[1], -1), xb.reshape(B, xb.shape[1], -1)], 0)
+        for block in self.blocks:
+            h = block.forward_cl(h, bn_groups=2)
+        h = h[:, 0, :]
+        return (h[:B, 0::2], h[:B, 1::2]), (h[B:, 0::2], h[B:, 1::2])
+
+
 class PoseSeqDecoder(nn.Module):
     def __init__(self, cfg) -> None:
         super().__init__()

@@ -148,8 +148,11 @@ class Voice2PoseModel(nn.Module):
                     e_gt = dataset.transform_normalized_parted2global(poses_gt.clone(), speaker)
                 side.uses(e_pred, e_gt)
                 ops.stage_mark("pose_enc:begin")
-                mu_pred, logvar_pred = self.pose_encoder(e_pred)
-                mu_gt, logvar_gt = self.pose_encoder(e_gt)
+                if ops.PAIR_AUX:  # one pass over the concatenated batch, statistics and running-statistics updates per half (= the two calls)
+                    (mu_pred, logvar_pred), (mu_gt, logvar_gt) = self.pose_encoder.forward_pair(e_pred, e_gt)
+                else:
+                    mu_pred, logvar_pred = self.pose_encoder(e_pred)
+                    mu_gt, logvar_gt = self.pose_encoder(e_gt)
                 ops.stage_mark("pose_enc:end")
             results.update(mu_pred=mu_pred, mu_gt=mu_gt, logvar_pred=logvar_pred, logvar_gt=logvar_gt)
 

@@ -135,14 +135,27 @@ __global__ __launch_bounds__(256) void colnorm_apply_fwd_kernel(const TY* __rest
         *(f32x4*)(mean + (size_t)g * C + 4 * cv) = mu;
         *(f32x4*)(rstd + (size_t)g * C + 4 * cv) = rs;
         if (rmean != nullptr && g == 0) {  // nn.BatchNorm training-mode running statistics (unbiased variance)
+            // G > 1 with running statistics: G calls of the module on G equal slices of the batch, batched into one launch (the two no-grad
+            // pose-encoder passes of a train step, voice2pose.py:160-176): the running statistics take the G updates in call order
             const double unb = R > 1 ? (double)R / (double)(R - 1) : 1.0;
+            const int G = (int)gridDim.y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * cv + e;
-                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu[e];
-                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var[e] * unb);
+                float rm = (1.f - momentum) * rmean[c] + momentum * mu[e];
+                float rv = (1.f - momentum) * rvar[c] + momentum * (float)(var[e] * unb);
+                for (int gg = 1; gg < G; ++gg) {
+                    const double s = sums[((size_t)gg * C + c) * 2], q = sums[((size_t)gg * C + c) * 2 + 1];
+                    const double m = s / (double)R;
+                    double v = q / (double)R - m * m;
+                    v = v > 0.0 ? v : 0.0;
+                    rm = (1.f - momentum) * rm + momentum * (float)m;
+                    rv = (1.f - momentum) * rv + momentum * (float)(v * unb);
+                }
+                rmean[c] = rm;
+                rvar[c] = rv;
             }
-            if (nbt != nullptr && cv == 0) nbt[0] += 1;
+            if (nbt != nullptr && cv == 0) nbt[0] += G;
         }
     }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;

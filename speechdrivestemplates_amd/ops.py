@@ -953,6 +953,7 @@ def _side_stream(which=0):
     return _SIDE[key]
 
 
+PAIR_AUX = True     # the two no-grad pose-encoder passes of a train step as one pass over the concatenated batch (PoseSeqEncoder.forward_pair)
 OVERLAP_AUX = True  # the no-grad pose-encoder passes of a train step run on the side stream (voice2pose.py); a stream of their own: no change (r04)
 
 
