@@ -211,6 +211,7 @@ def main(argv=None):
     ap.add_argument("--no-overlap-aux", action="store_true", help="keep the no-grad pose-encoder passes on the main stream")
     ap.add_argument("--no-stats-fusion", action="store_true", help="separate statistics pass for the 2-D norms (A/B of the fused conv epilogue)")
     ap.add_argument("--no-pair-aux", action="store_true", help="the two no-grad pose-encoder passes as two passes (A/B of the batched pass)")
+    ap.add_argument("--no-group-dw", action="store_true", help="the deferred small weight gradients one launch + reduce per layer instead of one grouped launch (A/B)")
     ap.add_argument("--no-chain1d", action="store_true", help="the generator's Conv1d stage block by block (two to three launches each) instead of one persistent launch per direction (A/B)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="keep the weight-gradient kernels on the main stream (default: side stream, +4 %)")
     ap.add_argument("--atomic-dw", action="store_true",
@@ -286,6 +287,7 @@ def main(argv=None):
             ops.USE_STREAMK_DW = False
         ops.PROFILER_NO_FUSION = bool(args.no_stats_fusion)
         ops.CHAIN1D = not args.no_chain1d
+        ops.GROUP_DW = not args.no_group_dw
         ops.PAIR_AUX = not args.no_pair_aux
         ops.CAPTURE_SIDE_STREAMS = bool(args.graph_streams)
         ops.OVERLAP_AUX = not args.no_overlap_aux

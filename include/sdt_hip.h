@@ -185,6 +185,15 @@ enum { SDT_MATH_F32 = 0, SDT_MATH_BF16 = 1, SDT_MATH_BF16X3 = 3, SDT_MATH_BF16X6
 int sdt_set_conv_math(int mode);
 int sdt_get_conv_math(void);
 
+
+/* Deterministic weight gradients of up to 24 SMALL layers in one grid + one ordered reduce (the generator's sixteen Conv1d blocks: launched one by
+ * one each layer splits its rows ~32 ways to fill the chip and spends its time on slab traffic; together they need 2 row ranges each).
+ * plan: host-built once per set of geometries (sdt_conv_dw_group_plan_bytes(n) bytes; the caller keeps a host and a device copy);
+ * *workspace_bytes: slab space, no initialisation needed.  Accumulates into every dw[i] like sdt_conv_dw_det_f32 (fixed order, exact fp32).  */
+int64_t sdt_conv_dw_group_plan_bytes(int n);
+int sdt_conv_dw_group_plan(const sdt_conv_geom* const* geoms, int n, void* plan_out, int64_t* workspace_bytes);
+int sdt_conv_dw_group_f32(const void* const* x, const void* const* dy, void* const* dw, int n, const void* plan_host, const void* plan_dev,
+                          void* workspace, void* stream);
 /* The same transposition for many layers in ONE launch (all mirrors of an optimiser group are refreshed right after its
  * Adam step).  table: device array of n_layers descriptors; tile_begin = running sum of
  * ceil(cin/32)*ceil(cout/32)*taps over the preceding layers, total_tiles = that sum over all layers. */

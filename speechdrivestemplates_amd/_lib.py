@@ -77,6 +77,8 @@ SIGNATURES = {
     "sdt_resize_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_resize_concat_bwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sdt_upsample_add_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sdt_conv_dw_group_plan": [C.POINTER(_G), _i, _p, C.POINTER(C.c_int64)],
+    "sdt_conv_dw_group_f32": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _p, _p, _p, _p],
     "sdt_chain1d_supported": [C.POINTER(ChainLayer), _i, _i],
     "sdt_chain1d_fwd_f32": [C.POINTER(ChainLayer), _i, _p, _p, _i, _f, _f, _i, _p, _p, _p],
     "sdt_chain1d_bwd_f32": [C.POINTER(ChainLayer), _i, _p, _i, _f, _f, _i, _i, _p, _p, _p],
@@ -153,6 +155,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.sdt_conv_dw_group_plan_bytes.argtypes = [_i]
+    lib.sdt_conv_dw_group_plan_bytes.restype = C.c_int64
     lib.sdt_conv_dw_workspace_bytes.argtypes = [_G]
     lib.sdt_conv_dw_workspace_bytes.restype = C.c_int64
     lib.sdt_convsk_plan_bytes.argtypes = [_G, _i]

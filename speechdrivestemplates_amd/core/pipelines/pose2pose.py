@@ -78,7 +78,12 @@ class Pose2Pose(Trainer):
         losses['L2_dist'], losses['lip_sync_error_n'] = metrics[0], metrics[1]
         opt = self.optimizers['optimizer']
         opt.zero_grad()
-        losses['loss'].backward()
+        ops.defer_small_dw(True)  # every weight gradient of this model is small: one grouped launch at the end of backward (ops.flush_deferred_dw)
+        try:
+            losses['loss'].backward()
+        finally:
+            ops.defer_small_dw(False)
+            ops.flush_deferred_dw()
         return losses, results
 
     def optimizer_updates(self, losses):

@@ -1139,10 +1139,11 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&out)[NS
 // SLAB: the deterministic variant -- every row range writes its partial product with plain stores into its own slab
 // dW + range * (Cout * Tw * Cin) and dw_slab_reduce_kernel adds the slabs to the gradient in a fixed order (no atomics, bit-identical
 // from run to run).
-template <int BM, int BN, bool VEC4, int NS = 0, bool SLAB = false>
-__global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                      float* __restrict__ dW, const sdt_conv_geom g,
-                                                      const int rows_per_split) {
+// (the body is a device function so that the grouped launch below -- many small geometries in one grid -- shares it; ``lin``: the workgroup's
+// index within its geometry's grid of ``nblk`` workgroups)
+template <int BM, int BN, bool VEC4, int NS, bool SLAB>
+__device__ __forceinline__ void conv_dw_body(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
+                                             const sdt_conv_geom& g, const int rows_per_split, const int lin) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;      // float4 loads per thread per tile
     constexpr int PA = 1024 / BM, PB = 1024 / BN;  // tile rows covered per pass
@@ -1159,7 +1160,6 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
     const int ncb = (g.Cin + BN - 1) / BN;
     const int ncol = VEC4 ? g.ntaps * ncb : (g.ntaps * g.Cin + BN - 1) / BN;
     const int nnt = (g.Cout + BM - 1) / BM;
-    const int lin = xcd_remap(blockIdx.x, (int)gridDim.x);
     const int bx = lin / (ncol * nnt), by = (lin / nnt) % ncol, bz = lin % nnt;
     const int mbeg = bx * rows_per_split;
     const int mend = min(M, mbeg + rows_per_split);
@@ -1375,6 +1375,53 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ 
                 }
             }
         }
+}
+
+template <int BM, int BN, bool VEC4, int NS = 0, bool SLAB = false>
+__global__ __launch_bounds__(256) void conv_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                      float* __restrict__ dW, const sdt_conv_geom g,
+                                                      const int rows_per_split) {
+    conv_dw_body<BM, BN, VEC4, NS, SLAB>(X, dY, dW, g, rows_per_split, xcd_remap(blockIdx.x, (int)gridDim.x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// GROUPED deterministic weight gradient: the weight gradients of many small layers -- the generator's sixteen Conv1d blocks, 0.8 GFLOP each --
+// in ONE grid + one ordered reduce instead of a kernel and a reduce per layer.  Launched alone, each of those layers split its 2048 rows over
+// ~32 row ranges to fill the chip (1536 workgroups), i.e. wrote and re-read 32 slabs of its 786 KB gradient: 0.8 GB of slab traffic per step, which
+// is what its 17 us were spent on.  In one grid the layers fill the chip together and a layer needs 2 row ranges.
+#define SDT_DW_GROUP_MAX 24
+struct dw_group_item {
+    sdt_conv_geom g;
+    int32_t rows, nsplit, block0, nblocks;
+    int64_t slab_off, n, vec0;  // floats: start of this layer's slabs; elements of its gradient; first 16-byte vector of it in the reduce's index space
+};
+struct dw_group_args {
+    const float* x[SDT_DW_GROUP_MAX];
+    const float* dy[SDT_DW_GROUP_MAX];
+    float* dw[SDT_DW_GROUP_MAX];
+    const dw_group_item* items;
+    float* slabs;
+    int n;
+};
+
+__global__ __launch_bounds__(256) void conv_dw_group_kernel(const dw_group_args A) {
+    int i = 0;
+    while (i + 1 < A.n && (int)blockIdx.x >= A.items[i + 1].block0) ++i;
+    const dw_group_item& it = A.items[i];
+    conv_dw_body<64, 64, true, 0, true>(A.x[i], A.dy[i], A.slabs + it.slab_off, it.g, it.rows, xcd_remap((int)blockIdx.x - it.block0, it.nblocks));
+}
+
+__global__ __launch_bounds__(256) void dw_slab_reduce_group_kernel(const dw_group_args A, const int64_t total_vec) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (int64_t)gridDim.x * 256) {
+        int i = 0;
+        while (i + 1 < A.n && v >= A.items[i + 1].vec0) ++i;
+        const dw_group_item& it = A.items[i];
+        const int64_t e = 4 * (v - it.vec0);
+        const float* sl = A.slabs + it.slab_off + e;
+        f32x4 a = *(const f32x4*)sl;
+        for (int sidx = 1; sidx < it.nsplit; ++sidx) a += *(const f32x4*)(sl + (size_t)sidx * it.n);
+        *(f32x4*)(A.dw[i] + e) += a;
+    }
 }
 
 // dw[i] += slab[0][i] + slab[1][i] + ... in that order (deterministic weight gradient)
@@ -1865,6 +1912,73 @@ extern "C" int sdt_conv_dw_det_f32(const float* x, const float* dy, float* dw, c
         for (int u = 0; u < t; ++u) SDT_CHECK_ARG(g->wt[t] != g->wt[u], "deterministic weight gradient needs distinct weight taps");
     const bool vec4 = (g->Cin % 4 == 0) && (g->Cout % 4 == 0);
     launch_dw<64, 64>(vec4, x, dy, dw, *g, (hipStream_t)stream, (float*)workspace);
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
+
+// ---- grouped form: plan (host, once per set of geometries), then launches with fresh tensor pointers
+static int dw_group_ok(const sdt_conv_geom* g) {
+    if (check_geom(g)) return 0;
+    if (g->Cin % 4 || g->Cout % 4 || g->ntaps != g->Tw) return 0;
+    for (int t = 0; t < g->ntaps; ++t)
+        for (int u = 0; u < t; ++u)
+            if (g->wt[t] == g->wt[u]) return 0;
+    return 1;
+}
+extern "C" int64_t sdt_conv_dw_group_plan_bytes(int n) { return n >= 1 && n <= SDT_DW_GROUP_MAX ? (int64_t)n * (int64_t)sizeof(dw_group_item) : -1; }
+// plan_out: n items (host memory, sdt_conv_dw_group_plan_bytes(n)); *workspace_bytes: slabs of all layers.  Every geometry must be one the
+// deterministic single-layer entry point takes (full 4-channel vectors, each weight tap once).
+extern "C" int sdt_conv_dw_group_plan(const sdt_conv_geom* const* geoms, int n, void* plan_out, int64_t* workspace_bytes) {
+    SDT_CHECK_ARG(geoms && plan_out && workspace_bytes && n >= 1 && n <= SDT_DW_GROUP_MAX, "1..24 geometries");
+    dw_group_item* it = (dw_group_item*)plan_out;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        SDT_CHECK_ARG(geoms[i] && dw_group_ok(geoms[i]), "geometry not supported by the deterministic weight gradient");
+        tiles += geoms[i]->ntaps * cdiv(geoms[i]->Cin, 64) * cdiv(geoms[i]->Cout, 64);
+    }
+    // ~6 workgroups per CU over the whole group (what dw_split aims at for one layer), at least 4 K steps per workgroup
+    const int want = std::max(1, (1536 + tiles / 2) / tiles);
+    int block = 0;
+    int64_t slab = 0, vec = 0;
+    for (int i = 0; i < n; ++i) {
+        const sdt_conv_geom& g = *geoms[i];
+        const int M = g.B * g.Ho * g.Wo;
+        const int ns0 = std::max(1, std::min(want, M / (4 * BK)));
+        const int rows = cdiv(cdiv(M, ns0), BK) * BK;
+        const int nsplit = cdiv(M, rows);
+        const int64_t nel = (int64_t)g.Cout * g.Tw * g.Cin;
+        it[i].g = g;
+        it[i].rows = rows, it[i].nsplit = nsplit, it[i].block0 = block;
+        it[i].nblocks = nsplit * g.ntaps * cdiv(g.Cin, 64) * cdiv(g.Cout, 64);
+        it[i].slab_off = slab, it[i].n = nel, it[i].vec0 = vec;
+        block += it[i].nblocks;
+        slab += (int64_t)nsplit * nel;
+        vec += nel / 4;
+    }
+    *workspace_bytes = slab * (int64_t)sizeof(float);
+    return SDT_OK;
+}
+extern "C" int sdt_conv_dw_group_f32(const void* const* x, const void* const* dy, void* const* dw, int n, const void* plan_host,
+                                     const void* plan_dev, void* workspace, void* stream) {
+    SDT_CHECK_ARG(x && dy && dw && plan_host && plan_dev && workspace && n >= 1 && n <= SDT_DW_GROUP_MAX, "bad argument");
+    SDT_CHECK_ARG(g_conv_math == SDT_MATH_F32, "the grouped weight gradient is exact fp32 only");
+    const dw_group_item* it = (const dw_group_item*)plan_host;
+    dw_group_args A;
+    uintptr_t bits = (uintptr_t)workspace;
+    for (int i = 0; i < n; ++i) {
+        SDT_CHECK_ARG(x[i] && dy[i] && dw[i], "null tensor");
+        A.x[i] = (const float*)x[i], A.dy[i] = (const float*)dy[i], A.dw[i] = (float*)dw[i];
+        bits |= (uintptr_t)x[i] | (uintptr_t)dy[i] | (uintptr_t)dw[i];
+    }
+    SDT_CHECK_ARG(bits % 16 == 0, "operands must be 16-byte aligned");
+    A.items = (const dw_group_item*)plan_dev;
+    A.slabs = (float*)workspace;
+    A.n = n;
+    const int blocks = it[n - 1].block0 + it[n - 1].nblocks;
+    const int64_t total_vec = it[n - 1].vec0 + it[n - 1].n / 4;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_dw_group_kernel, dim3(blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(dw_slab_reduce_group_kernel, dim3((unsigned)std::min<int64_t>((total_vec + 255) / 256, 4096)), dim3(256), 0, s, A, total_vec);
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }

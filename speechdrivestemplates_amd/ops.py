@@ -996,18 +996,89 @@ _DEFER_ON = [False]
 
 
 def defer_small_dw(on):
-    _DEFER_ON[0] = bool(on) and DEFER_SMALL_DW and OVERLAP_DW and torch.cuda.is_available() and _side_ok()
+    # (also without a side stream -- inside a hipGraph capture: the batch then runs on the capturing stream, still as ONE grouped launch)
+    _DEFER_ON[0] = bool(on) and DEFER_SMALL_DW and torch.cuda.is_available()
+
+
+GROUP_DW = True   # the deferred small weight gradients of a step in one grouped launch + one ordered reduce (sdt_conv_dw_group_f32)
+_DW_GROUPS = {}   # (geometry bytes ..., device) -> (host plan, device plan, workspace, n)
+
+
+def _dw_group_launch(items):
+    """``items``: [(x4, gy4, gradient storage, geometry)], 2..24 of them, fp32, every geometry one the deterministic weight gradient takes."""
+    import ctypes as C
+    lib = _lib.load()
+    dev = items[0][0].device
+    key = tuple(_geom_key(it[3]) for it in items) + (dev.index,)
+    grp = _DW_GROUPS.get(key)
+    n = len(items)
+    if grp is None:
+        nbytes = lib.sdt_conv_dw_group_plan_bytes(n)
+        host = (C.c_int32 * (nbytes // 4))()
+        garr = (C.POINTER(_lib.ConvGeom) * n)(*[C.pointer(it[3]) for it in items])
+        wsb = C.c_int64(0)
+        check(lib.sdt_conv_dw_group_plan(garr, n, C.addressof(host), C.byref(wsb)))
+        grp = _DW_GROUPS[key] = (host, torch.frombuffer(host, dtype=torch.int32).to(dev), torch.empty(wsb.value // 4, device=dev, dtype=torch.float32))
+    host, plan_dev, ws = grp
+    xs = (C.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    dys = (C.c_void_p * n)(*[it[1].data_ptr() for it in items])
+    dws = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    st = _stream()
+    call = lambda: lib.sdt_conv_dw_group_f32(xs, dys, dws, n, C.addressof(host), _p(plan_dev), _p(ws), st)  # noqa: E731
+    if PROFILER is None:
+        check(call())
+        return
+    flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for _x, _y, _w, g in items)
+    nbytes = sum(4.0 * (g.B * g.Hi * g.Wi * g.Cin + g.B * g.Ho * g.Wo * g.Cout + g.Cout * g.ntaps * g.Cin) for _x, _y, _w, g in items)
+    e0, e1 = PROFILER.event(), PROFILER.event()
+    e0.record()
+    check(call())
+    e1.record()
+    PROFILER.records.append(("conv_dw_group_kernel", "dW", False, flops, nbytes, e0, e1))
+
+
+def _launch_weight_grads(jobs):
+    """[(x_cl, gy, w, stride, pad)]: the small fp32 layers the ordered slab kernel would take go into grouped launches, the rest one by one."""
+    group, gjobs, rest = [], [], []
+    for job in jobs:
+        x_cl, gy, w, stride, pad = job
+        ok = (GROUP_DW and DETERMINISTIC_DW and _CONV_MATH_NOW[0] == 0 and x_cl.dtype == torch.float32 and gy.dtype == torch.float32
+              and not (USE_STREAMK_DW and w.dim() == 4))
+        if ok:
+            x4, gy4 = _as4(x_cl.contiguous()), _as4(gy.contiguous())
+            g = conv_geom_for(x4.shape, w, stride, pad)
+            gw = grad_buffer(w)
+            gws = weight_storage(gw)
+            ok = (g.ntaps == g.Tw and g.Cin % 4 == 0 and g.Cout % 4 == 0 and gws.data_ptr() == gw.data_ptr()
+                  and (x4.data_ptr() | gy4.data_ptr() | gws.data_ptr()) % 16 == 0)
+            if ok:
+                group.append((x4, gy4, gws, g))
+                gjobs.append(job)
+                continue
+        rest.append(job)
+    for i in range(0, len(group), 24):
+        if len(group[i:i + 24]) >= 2:
+            _dw_group_launch(group[i:i + 24])
+        else:  # nothing to share a grid with
+            rest.append(gjobs[i])
+    for x_cl, gy, w, stride, pad in rest:
+        conv_weight_grad(x_cl, gy, w, stride, pad)
 
 
 def flush_deferred_dw():
     if not _DEFERRED:
         return
+    if not (OVERLAP_DW and _side_ok()):  # no side stream (hipGraph capture, --no-overlap-dw): the batch runs here
+        stage_mark("dw1d:begin")
+        _launch_weight_grads(list(_DEFERRED))
+        stage_mark("dw1d:end")
+        _DEFERRED.clear()
+        return
     side = _side_stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         stage_mark("dw1d:begin")
-        for x_cl, gy, w, stride, pad in _DEFERRED:
-            conv_weight_grad(x_cl, gy, w, stride, pad)
+        _launch_weight_grads(list(_DEFERRED))
         stage_mark("dw1d:end")
     for x_cl, gy, _w, _s, _p2 in _DEFERRED:
         gy.record_stream(side)

@@ -170,3 +170,31 @@ def test_chain_without_an_input_gradient():
     ops.join_side_stream()
     torch.cuda.synchronize()
     assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in ws)
+
+
+def test_grouped_weight_gradient_matches_the_per_layer_launches():
+    """ops._launch_weight_grads: the sixteen small weight gradients of the chain in ONE grouped launch + one ordered reduce (sdt_conv_dw_group_f32)
+    against one launch + reduce per layer (sdt_conv_dw_det_f32): same products, different row split -> fp32 summation order only; and the grouped
+    launch repeats bit-identically."""
+    from speechdrivestemplates_amd import ops
+    torch.manual_seed(11)
+    B, T = 32, 64
+    spec = _wiring()
+    blocks = ops.chain_blocks(spec, T, 288)
+    grads = []
+    for mode in (True, True, False):
+        ws = _weights(288, 7)
+        jobs = []
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for (Ti, To, Cin, k, stride, pad, *_r), w in zip(blocks, ws):
+            jobs.append((torch.randn((B, Ti, Cin), device="cuda", generator=g), torch.randn((B, To, 256), device="cuda", generator=g), w, stride, pad))
+        ops.GROUP_DW = mode
+        try:
+            ops._launch_weight_grads(jobs)
+        finally:
+            ops.GROUP_DW = True
+        torch.cuda.synchronize()
+        grads.append([ops.weight_storage(w.grad).clone() for w in ws])
+    for a, b, c in zip(*grads):
+        assert torch.equal(a, b), "the grouped launch is not run-to-run deterministic"
+        assert _rel(a, c) <= 2e-6, _rel(a, c)

@@ -152,7 +152,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
     extra = {"sdt_last_error", "sdt_abi_version", "sdt_get_conv_math", "sdt_conv_dw_workspace_bytes", "sdt_convsk_plan_bytes",
              "sdt_convsk_workspace_bytes", "sdt_convsk_dw_plan_bytes", "sdt_convsk_dw_workspace_bytes", "sdt_convsk_plan_bytes_t",
-             "sdt_convsk_dw_plan_bytes_t", "sdt_convsk_get_spin_limit"}
+             "sdt_convsk_dw_plan_bytes_t", "sdt_convsk_get_spin_limit", "sdt_conv_dw_group_plan_bytes"}
     declared |= set(re.findall(r"^\s*(?:int64_t|unsigned)\s+(sdt_\w+)\s*\(", hdr, flags=re.M))
     for name in sorted(declared):
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
