@@ -1685,9 +1685,12 @@ extern "C" int sdt_conv_taps_splitk_hint(const sdt_conv_geom* g) {
     const int var = taps_variant(g, true);
     const int bm = var / 10 / 1000, bn = var / 10 % 1000;
     const int64_t tiles = cdiv64((int64_t)g->B * g->Ho * g->Wo, bm) * cdiv(g->Cout, bn);
-    if (tiles >= 192) return 1;
+    // 1-D launches keep splitting up to ~1024 workgroups: with 192-767 tiles (one to three per CU of a kernel that fits seven) every workgroup
+    // walks its whole K alone -- the 256-tile first block of the paired pose-encoder pass (242 input channels, scalar loader): 78 us unsplit
+    const bool one_d = g->Hi == 1 && g->Ho == 1;
+    if (tiles >= (one_d ? 768 : 192)) return 1;
     const int nsteps = (var % 10) ? g->ntaps * cdiv(g->Cin, BK) : cdiv(g->ntaps * g->Cin, BK);
-    int k = (int)std::min<int64_t>(std::min<int64_t>(cdiv64(512, tiles), nsteps / 4), 16);
+    int k = (int)std::min<int64_t>(std::min<int64_t>(cdiv64(tiles >= 192 ? 1024 : 512, tiles), nsteps / 4), 16);
     return std::max(k, 1);
 }
 
