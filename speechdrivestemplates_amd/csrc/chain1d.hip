@@ -76,8 +76,17 @@ extern "C" int sdt_debug_set_timeline_chain(void* p) {
     do {                                                                                                                          \
         if (threadIdx.x == 0 && ch_dbg_tl != nullptr) ch_dbg_tl[((size_t)blockIdx.x * 24 + (step)) * 4 + (slot)] = wall_clock64(); \
     } while (0)
+// fault injection (tests/test_chain1d_gpu.py::test_chain_lost_member_is_loud): member 3 of this clip's cluster leaves before its first arrival --
+// what a workgroup that was never dispatched looks like to the other seven
+__device__ int ch_dbg_mute_clip = -1;
+extern "C" int sdt_debug_chain_mute_clip(int clip) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(ch_dbg_mute_clip), &clip, sizeof(clip));
+    return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
+}
+#define CH_MUTED(clip, r) ((clip) == ch_dbg_mute_clip && (r) == 3)
 #else
 #define CH_TL(step, slot)
+#define CH_MUTED(clip, r) false
 #endif
 
 __device__ __forceinline__ void ch_src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {  // misc.hip src_index
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane >> 4, li = lane & 15;
     const int slot = (bid >> 6) * 8 + (bid & 7), clip = A.clip0 + slot, r = (bid >> 3) & 7;  // slot: the cluster's index within this launch
-    if (clip >= A.B) return;
+    if (clip >= A.B || CH_MUTED(clip, r)) return;
     float* xs = smem;                                   // [CH_ROWS][Cin + 4]
     float* wb = smem + CH_ROWS * (CH_MAXCIN + 4);       // [2][32][KC + 4]
     gu32* cnt = (gu32*)(A.counters + slot);
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fq = lane >> 4, li = lane & 15;
     const int slot = (bid >> 6) * 8 + (bid & 7), clip = A.clip0 + slot, r = (bid >> 3) & 7;  // slot: the cluster's index within this launch
-    if (clip >= A.B) return;
+    if (clip >= A.B || CH_MUTED(clip, r)) return;
     const int RS = CH_C + 4;
     float* ds = smem;                                   // [1 + To][260]
     float* wb = smem + CH_ROWS * (CH_MAXCIN + 4);

@@ -550,8 +550,8 @@ def check_streamk():
     """Raise if any stream-K launch of this process reported a lost partner (Trainer calls this on log steps and before every checkpoint)."""
     codes = streamk_error_codes()
     if codes:
-        raise RuntimeError("a persistent stream-K convolution launch gave up waiting for a partner workgroup (error words %r: range id + 1 per "
-                           "(device, stream)); its output tile was poisoned with NaN.  The GPU is probably shared with another process or a "
+        raise RuntimeError("a persistent launch gave up waiting for a partner workgroup (error words %r: stream-K convolution: range id + 1 per "
+                           "(device, stream), its output tile was poisoned with NaN; Conv1d chain: 0x40000000 + block, its outputs are invalid).  The GPU is probably shared with another process or a "
                            "kernel that holds workgroup slots (see ops.SK_RESERVED_SLOTS); results since the last check are invalid" % (codes,))
 
 

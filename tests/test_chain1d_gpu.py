@@ -198,3 +198,37 @@ def test_grouped_weight_gradient_matches_the_per_layer_launches():
     for a, b, c in zip(*grads):
         assert torch.equal(a, b), "the grouped launch is not run-to-run deterministic"
         assert _rel(a, c) <= 2e-6, _rel(a, c)
+
+
+@pytest.mark.tuning
+def test_chain_lost_member_is_loud():
+    """Fault injection (-DSDT_TUNING library): one of the 8 workgroups of a clip's cluster never arrives.  The other seven give up after the spin
+    limit, the launch ends, the error word is set and ops.check_streamk() -- what Trainer.check_kernels() calls on log steps, before checkpoints
+    and in validate -- raises; after the counters are cleared the next launch is correct again."""
+    import ctypes
+    from speechdrivestemplates_amd import _lib, ops
+    lib = _lib.load()
+    lib.sdt_debug_chain_mute_clip.argtypes = [ctypes.c_int]
+    ws = _weights(288, 3)
+    h = torch.randn((8, 64, 288), device="cuda")
+    with torch.no_grad():
+        good = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+    prev = lib.sdt_convsk_get_spin_limit()
+    _lib.check(lib.sdt_convsk_set_spin_limit(5000))
+    assert lib.sdt_debug_chain_mute_clip(5) == 0
+    try:
+        with torch.no_grad():
+            ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+        torch.cuda.synchronize()
+        codes = ops.streamk_error_codes()
+        assert len(codes) == 1 and list(codes.values())[0] >= 0x40000000, codes
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            ops.check_streamk()
+    finally:
+        lib.sdt_debug_chain_mute_clip(-1)
+        _lib.check(lib.sdt_convsk_set_spin_limit(prev))
+        ops._chain_ws(h.device).zero_()  # counters of the abandoned cluster + the error word
+    with torch.no_grad():
+        again = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+    torch.cuda.synchronize()
+    assert torch.equal(good, again) and ops.streamk_error_codes() == {}
