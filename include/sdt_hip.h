@@ -360,7 +360,8 @@ int sdt_code_kl_bwd_f32(const float* code, const int32_t* valid, const float* go
 /*
  * GestureDataset.get_final_results x2 + Voice2Pose.evaluate_step (gesture_dataset.py:193-220,
  * voice2pose.py:412-430), float64 like the reference: final_* (B,T,2,K) f64 (nullable),
- * metrics[0]=L2_dist, metrics[1]=lip_sync_error_n.  work: >= 2*B*T + 4 doubles, the first 4 ZERO ON ENTRY.
+ * metrics[0]=L2_dist, metrics[1]=lip_sync_error_n.  work: >= 3*B*T + 4 doubles, contents irrelevant (per-frame
+ * partial sums, combined in a fixed order: no atomics, bit-identical from run to run).
  */
 int sdt_final_metrics_f64(const float* pred, const float* gt, const double* mean, const double* std,
                           const double* scale, int hierarchical, int B, int T, int K,

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
     }
 }
 
+#define L0_Q 4      // gradient vectors per register set of the backward kernel's prefetch
 #define L0_NSUM 11  // per (group, channel): sum g, sum g*yhat, sum g*x_t (9 taps)   with g = dz * act'(gamma*yhat+beta)
 
 // Backward, the ONLY pass over dz.  With dy = gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)) the weight gradient
@@ -209,53 +210,124 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ m
 // needs, besides three sums over the gradient, only  sum x_t  and  sum yhat*x_t = rstd*(sum_u w[c][u] R[u][t] - mean*S_t),
 // i.e. the first/second moments of the mel image that the forward pass already computed.
 // sums[g][c][11] doubles (zero on entry).  grid (row chunks, B).
+// The gradient vectors of a thread go through a FOUR-DEEP QUEUE of raw registers that is refilled slot by slot: the load of pixel p + 4 is
+// issued the moment pixel p's vector is taken out, and the pixel loop is one basic block (tails are masked, addresses clamped), so the
+// compiler waits with vmcnt(3) -- not 0 -- and a wave's ~100 VALU operations per pixel run under its own loads.  The mel neighbourhood
+// comes from LDS (the workgroup's rows + halo, zero border): as global loads its fetches sat in the same in-order vmcnt queue BEHIND the
+// gradient prefetches and every pixel waited for all of them (99 us per launch = 36 % of the HBM rate; 4 loads in flight, then idle).
+template <typename T> struct L0Raw { typedef f32x4 type; };
+template <> struct L0Raw<__bf16> { typedef l0_u32x2 type; };
+template <typename T>
+__device__ __forceinline__ f32x4 l0_cvt(const typename L0Raw<T>::type r) {
+    if constexpr (sizeof(T) == 4) {
+        return r;
+    } else {
+        return (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+    }
+}
 template <typename TZ>
 __global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const TZ* __restrict__ dz, const float* __restrict__ mel,
                                                           const float* __restrict__ w, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, double* __restrict__ sums, int H,
                                                           int W, int groups, float slope, int rows_per_block) {
+    typedef typename L0Raw<TZ>::type raw_t;
+    extern __shared__ float sMel[];  // [rows_per_block + 2][W + 2]: image rows y_beg - 1 .. , columns -1 .. W, zeros outside the image
     __shared__ double sS[L0_C * L0_NSUM];
     const int b = blockIdx.y, tid = threadIdx.x, cq = tid & 15, seg = tid >> 4;
-    const int y_beg = blockIdx.x * rows_per_block, y_end = min(H, y_beg + rows_per_block);
-    const int g = groups == 1 ? 0 : b;
+    const int y_beg = blockIdx.x * rows_per_block, nrows = min(H, y_beg + rows_per_block) - y_beg;
+    const int g = groups == 1 ? 0 : b, WP = W + 2;
     for (int i = tid; i < L0_C * L0_NSUM; i += 256) sS[i] = 0.0;
+    {
+        const float* img = mel + (size_t)b * H * W;
+        for (int i = tid; i < (rows_per_block + 2) * WP; i += 256) {
+            const int r = i / WP, xx = i - r * WP - 1, yy = y_beg - 1 + r;
+            sMel[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[(size_t)yy * W + xx] : 0.f;
+        }
+    }
     __syncthreads();
     L0Thread t;
     l0_setup(t, w, mean, rstd, gamma, beta, g, cq);
-    const int len = (W + 15) / 16, x0 = seg * len, x1 = min(W, x0 + len);
+    const int len = (W + 15) / 16, x0 = seg * len;
+    const int total = nrows * len;  // pixels per thread, the same for every thread of the workgroup (columns past the row are masked)
+    const TZ* gbase = dz + ((size_t)(b * H + y_beg) * W) * L0_C + 4 * cq;
+    int lrow = 0, lxi = 0;  // load cursor: L0_Q pixels ahead of the compute cursor
+    // The load is an asm statement TIED to the slot's register ("+v"): hipcc otherwise loads into fresh registers and copies them into
+    // the slot at the loop's back-edge -- a copy that waits for the load (vmcnt(0) once per trip: measured, three formulations).  The
+    // compiler does not count these loads; the matching wait is the asm below, also tied to the slot, so that every use of the slot's
+    // value is ordered after it.  In-order completion: with L0_Q - 1 younger loads outstanding the slot's own load has landed.  Loads are
+    // unconditional (clamped addresses), so the count is exact; other loads the compiler may add in between only make the wait stronger.
+    auto issue = [&](raw_t& slot) {
+        const unsigned off = (unsigned)(min(lrow, nrows - 1) * W + min(x0 + lxi, W - 1)) * (unsigned)L0_C;
+        const TZ* ptr = gbase + off;
+        if constexpr (sizeof(TZ) == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(slot) : "v"(ptr));
+        else asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(slot) : "v"(ptr));
+        const bool wrap = lxi + 1 == len;
+        lxi = wrap ? 0 : lxi + 1;
+        lrow += wrap ? 1 : 0;
+    };
+    // the thread's constants have LANDED before the first queue load is issued (an empty asm that "uses" them makes the compiler place its
+    // wait here; otherwise it waits at their first use INSIDE the loop, with vmcnt(0), on every trip)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = 0; k < L0_T; ++k) asm volatile("" : "+v"(t.w[e][k]));
+        asm volatile("" : "+v"(t.mu[e]), "+v"(t.rs[e]), "+v"(t.ga[e]), "+v"(t.be[e]));
+    }
+    raw_t q[L0_Q];
+#pragma unroll
+    for (int j = 0; j < L0_Q; ++j) {
+        if constexpr (sizeof(TZ) == 4) q[j] = (raw_t){0.f, 0.f, 0.f, 0.f};
+        else q[j] = (raw_t){0u, 0u};
+        issue(q[j]);
+    }
     float acc[4][L0_NSUM];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < L0_NSUM; ++k) acc[e][k] = 0.f;
-    for (int y = y_beg; y < y_end && x0 < x1; ++y) {
-        const TZ* gin = dz + ((size_t)(b * H + y) * W) * L0_C + 4 * cq;
-        L0Window win;
-        win.init(mel + (size_t)b * H * W, H, W, y, x0);
-        for (int xb = x0; xb < x1; xb += 4) {  // 4 gradient vectors in flight per thread (HBM latency hiding)
-            f32x4 gzv[4];
+    int crow = 0, cxi = 0;
+    for (int p = 0; p < total; p += L0_Q) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                gzv[j] = (xb + j < x1) ? l0_ld4(gin + (size_t)(xb + j) * L0_C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < L0_Q; ++j) {
+            const int x = x0 + cxi;
+            const bool live = x < W && crow < nrows;
+            const float* c = sMel + crow * WP + min(x, W - 1);  // column x - 1 of image row y - 1
+            float nb[L0_T];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = xb + j;
-                if (x < x1) {
-                    if (x > x0) win.advance(x);
-                    const f32x4 yh = l0_yhat(t, win.nb);
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gg = gzv[j][e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope);
-                        acc[e][0] += gg;
-                        acc[e][1] = fmaf(gg, yh[e], acc[e][1]);
+                for (int e = 0; e < 3; ++e) nb[3 * d + e] = c[d * WP + e];
+            const f32x4 yh = l0_yhat(t, nb);
+            static_assert(L0_Q == 4, "the wait below is vmcnt(L0_Q - 1)");
+            // (scheduling barriers: the asm statements may not drift above the products of the slot's old value -- hipcc then keeps the
+            // old value in a second register and is back to copying)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(q[j]));
+            f32x4 g4;
+            {
+                const f32x4 gz = l0_cvt<TZ>(q[j]);
 #pragma unroll
-                        for (int k = 0; k < L0_T; ++k) acc[e][2 + k] = fmaf(gg, win.nb[k], acc[e][2 + k]);
-                    }
-                }
+                for (int e = 0; e < 4; ++e) g4[e] = live ? gz[e] * act_grad(yh[e] * t.ga[e] + t.be[e], slope) : 0.f;
             }
+            asm volatile("" : "+v"(g4[0]), "+v"(g4[1]), "+v"(g4[2]), "+v"(g4[3]));  // the old value is finished HERE (no sinking below the load)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(q[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = g4[e];
+                acc[e][0] += gg;
+                acc[e][1] = fmaf(gg, yh[e], acc[e][1]);
+#pragma unroll
+                for (int k = 0; k < L0_T; ++k) acc[e][2 + k] = fmaf(gg, nb[k], acc[e][2 + k]);
+            }
+            const bool wrap = cxi + 1 == len;
+            cxi = wrap ? 0 : cxi + 1;
+            crow += wrap ? 1 : 0;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the L0_Q loads past the end (clamped addresses) before the registers are re-used
     // the 4 segment-lanes of a wave that share a channel quad (bits 4,5 of the lane id), then LDS / global fp64 atomics
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -325,7 +397,11 @@ __global__ __launch_bounds__(288) void l0_bwd_finalize_kernel(const double* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-static int l0_ppb(int HW) { return std::max(1024, std::min(4096, cdiv(HW, 8) / 256 * 256)); }  // moments kernel only
+// moments kernel only: pixels per workgroup.  (Tried in round 4: one round of workgroups -- 8 pieces per clip instead of 9 -- 31 -> 29 us;
+// 34 pieces 44 us, the 54 atomics per workgroup then dominate.  Not kept: the regrouped fp64 sums move mean / rstd by an ulp, which is
+// enough to flip a LeakyReLU decision of the Conv1d stage at B = 32 against the float64 oracle -- tests/test_fullsize_gpu.py compares
+// distributions without a flip allowance -- and 2 us do not pay for re-deriving those bars.)
+static int l0_ppb(int HW) { return std::max(1024, std::min(4096, cdiv(HW, 8) / 256 * 256)); }
 
 extern "C" int sdt_l0_block_fwd_t(const float* mel, const float* w, void* z, int z_dtype, double* mom, float* mean, float* rstd,
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -367,12 +443,15 @@ extern "C" int sdt_l0_block_bwd_t(const void* dz, int dz_dtype, const float* mel
     const int HW = H * W;
     // several image rows per workgroup: ~2 workgroups per CU keeps HBM busy while bounding the number of workgroups
     // that push their partial sums through the same global atomics
-    const int rpb = std::max(1, (H * B) / 1280);
+    int rpb = std::max(1, (H * B) / 1280);
+    while (rpb > 1 && (size_t)(rpb + 2) * (W + 2) * 4 > 40960) --rpb;  // the workgroup's mel rows + halo live in LDS
+    const size_t lds = (size_t)(rpb + 2) * (W + 2) * 4;
+    SDT_CHECK_ARG(lds <= 40960, "mel image too wide for the first block's backward kernel");
     dim3 grid(cdiv(H, rpb), B);
     if (dz_dtype == SDT_F32)
-        hipLaunchKernelGGL(l0_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
+        hipLaunchKernelGGL(l0_bwd_sums_kernel<float>, grid, dim3(256), lds, s, (const float*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope, rpb);
     else
-        hipLaunchKernelGGL(l0_bwd_sums_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope,
+        hipLaunchKernelGGL(l0_bwd_sums_kernel<__bf16>, grid, dim3(256), lds, s, (const __bf16*)dz, mel, w, mean, rstd, gamma, beta, sums, H, W, groups, slope,
                            rpb);
     const double n = groups == 1 ? (double)B * HW : (double)HW;
     hipLaunchKernelGGL(l0_bwd_finalize_kernel, dim3(L0_C), dim3(288), 0, s, sums, mom, w, mean, rstd, gamma, dw, dgamma, dbeta, B,

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(128) void final_metrics_kernel(const float* __restr
     if ((k & 63) == 0) red[k >> 6] = l2;
     __syncthreads();
     if (k == 0) {
-        atomicAdd(&work[0], red[0] + red[1]);
+        work[4 + 2 * BT + bt] = red[0] + red[1];  // per-frame partial, summed in a fixed order by the reduce kernel (no atomics)
         if (K > 75) {
             const double px = sv[0][0][75] - sv[0][0][71], py = sv[0][1][75] - sv[0][1][71];
             const double gx = sv[1][0][75] - sv[1][0][71], gy = sv[1][1][75] - sv[1][1][71];
@@ -376,21 +376,30 @@ __global__ __launch_bounds__(128) void final_metrics_kernel(const float* __restr
 }
 __global__ __launch_bounds__(256) void final_metrics_reduce_kernel(const double* __restrict__ work, int B, int T, int K,
                                                                    double* __restrict__ metrics) {
-    __shared__ double red[4];
-    const int BT = B * T;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    // work: [4 unused][BT lip opening of the prediction][BT of the ground truth][BT per-frame sums of keypoint distances].
+    // Eight threads per clip (lip metric: maximum over the clip's frames first), every thread a fixed subset, fixed combination trees.
+    __shared__ double red[2][4];
+    const int BT = B * T, tid = threadIdx.x, j = tid & 7;
+    double s = 0.0, l2 = 0.0;
+    for (int b = tid >> 3; b < B; b += 32) {
+        const double* wp = work + 4 + (size_t)b * T;
+        const double* wg = wp + BT;
         double mx = -1.0;
-        for (int t = 0; t < T; ++t) mx = fmax(mx, work[4 + BT + b * T + t]);
+        for (int t = j; t < T; t += 8) mx = fmax(mx, wg[t]);
+        mx = fmax(mx, __shfl_xor(mx, 1, 64));
+        mx = fmax(mx, __shfl_xor(mx, 2, 64));
+        mx = fmax(mx, __shfl_xor(mx, 4, 64));
         const double den = mx + 1e-4;
-        for (int t = 0; t < T; ++t) s += fabs(work[4 + b * T + t] / den - work[4 + BT + b * T + t] / den);
+        for (int t = j; t < T; t += 8) s += fabs(wp[t] / den - wg[t] / den);
     }
+    for (int i = tid; i < BT; i += 256) l2 += work[4 + 2 * (size_t)BT + i];
     s = wave_sum_d(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    l2 = wave_sum_d(l2);
+    if ((tid & 63) == 0) red[0][tid >> 6] = s, red[1][tid >> 6] = l2;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        metrics[0] = work[0] / ((double)BT * (double)K);
-        metrics[1] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)BT;
+    if (tid == 0) {
+        metrics[0] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / ((double)BT * (double)K);
+        metrics[1] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double)BT;
     }
 }
 

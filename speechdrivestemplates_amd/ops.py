@@ -1795,7 +1795,7 @@ def final_metrics(pred, gt, mean, std, scale, hierarchical, want_final=True):
     dev = pred.device
     fp = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
     fg = torch.empty((B, T, 2, K), device=dev, dtype=torch.float64) if want_final else None
-    work = _ARENA.take(2 * B * T + 4, dev)
+    work = _ARENA.take(3 * B * T + 4, dev)
     metrics = torch.empty(2, device=dev, dtype=torch.float64)
     # the contiguous copies of broadcast statistics (DeviceClipStore hands out expand()ed views) must outlive the launch call: as unnamed
     # temporaries the three copies were freed one by one and re-used each other's block -- the kernel then read `std` through `mean`'s pointer
