@@ -163,11 +163,13 @@ def test_instance_norm2d_leaky(ops, shape):
 
 
 @pytest.mark.parametrize("norm", ["IN", "BN"])
-@pytest.mark.parametrize("hw", [(80, 427), (80, 300), (7, 5)])
+@pytest.mark.parametrize("hw", [(80, 427), (80, 300), (7, 5), (81, 37, 33)])
 def test_fused_first_block(ops, norm, hw):
-    """Conv2d(1,64,k3,p1) + IN2d|BN2d(train) + LeakyReLU fused (stats from mel moments, yhat recomputed in backward)."""
-    H, W = hw
-    B = 3
+    """Conv2d(1,64,k3,p1) + IN2d|BN2d(train) + LeakyReLU fused (stats from mel moments, yhat recomputed in backward).
+    (81, 37) at B = 33: the backward kernel takes TWO image rows per workgroup there (as at the bench size), the last workgroup of a clip
+    has one, and with 3 columns per thread segment the last segments lie partly or wholly past the row (masked pixels, clamped loads)."""
+    H, W = hw[:2]
+    B = hw[2] if len(hw) > 2 else 3
     g = torch.Generator().manual_seed(H * W)
     mel = (torch.rand(B, H, W, generator=g, dtype=torch.float64) ** 3) * 40.0  # power-mel like: non-negative, heavy tail
     w = (torch.randn(64, 1, 3, 3, generator=g, dtype=torch.float64) * (2.0 / 9) ** 0.5).requires_grad_(True)
