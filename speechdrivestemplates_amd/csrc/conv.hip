@@ -73,8 +73,9 @@ extern "C" int sdt_debug_set_timeline(void* p) {
 // symbol for every forward / input-gradient launch; the branch is uniform and outside the K loop.)
 // EPI selects the epilogue at compile time (each statistics epilogue costs registers: a run-time switch took the plain kernel
 // from 7 to 5 waves per SIMD): 0 = store only, 1 = + forward statistics (stats), 2 = + normalisation-backward statistics (nb).
+// The 64x64 instantiations are held to 7 waves per SIMD (72 registers): what hides a workgroup's prologue and epilogue is its six neighbours.
 template <int BM, int BN, bool VEC4, int PRIO = 0, int EPI = 0>
-__global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? 7 : 1) void conv_taps_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         const geom_pack gp, const int splitk,
                                                         float* __restrict__ partial, const size_t ysize,
@@ -472,6 +473,30 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
         Y = partial + (size_t)blockIdx.z * ysize;
         bias = nullptr;
     }
+    // EPI 2 reads the forward output y at every position of the tile: all of those loads are issued first, branch-free (positions outside
+    // the tensor read element 0 and are masked below), so the tile pays ONE memory latency instead of one per group of four rows behind
+    // the stores -- as in convsk.hip, where the same change was worth 19 % on the input-gradient launches
+    float yv[EPI == 2 ? TM * TN * 16 : 1];
+    if constexpr (EPI == 2) {
+        // (buffer loads: one offset register per load instead of a 64-bit address -- the kernel has to stay at 72 registers, 7 workgroups per CU)
+        const __amdgpu_buffer_rsrc_t rsNY = __builtin_amdgcn_make_buffer_rsrc((void*)nb.y, 0, 0x7ffffffc, 0x00020000);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+                const bool nok = n < g.Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = sOut[wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                    yv[(tm * TN + tn) * 16 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsNY, (off >= 0 && nok) ? (off + n) * 4 : (int)0x80000000, 0, 0));
+                }
+            }
+    }
+    // stores: branch-free buffer stores when the tensor's byte offsets fit 31 bits (rows / columns outside the tensor get an out-of-range
+    // offset and the hardware drops the store); the guarded 64-bit form otherwise
+    const bool ysmall = (size_t)g.B * g.Hy * g.Wy * g.Cout * 4 < (size_t)0x7ffffff0u;
+    const __amdgpu_buffer_rsrc_t rsYs = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, 0x7ffffffc, 0x00020000);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -479,11 +504,19 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
             const int n = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
             const bool nok = n < g.Cout;
             const float bv = (bias != nullptr && nok) ? bias[n] : 0.f;
+            if (ysmall) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int off = sOut[row];
-                if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
+                for (int r = 0; r < 16; ++r) {
+                    const int off = sOut[wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tm][tn][r] + bv), rsYs, (off >= 0 && nok) ? (off + n) * 4 : (int)0x80000000, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int off = sOut[row];
+                    if (off >= 0 && nok) Y[(size_t)off + n] = acc[tm][tn][r] + bv;
+                }
             }
             if constexpr (EPI == 1) {
                 const int g0 = m0 / rows_per_group;
@@ -534,14 +567,13 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict_
                     if (nb.beta != nullptr) be = nb.beta[n];
                 }
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-#pragma unroll 4
+#pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int off = sOut[row];
                     if (off >= 0 && nok) {
-                        const float yv = nb.y[(size_t)off + n];
                         const bool second = m0 + row >= mb;
-                        const float yh = (yv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
+                        const float yh = (yv[(tm * TN + tn) * 16 + r] - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
                         const float gg = acc[tm][tn][r] * act_grad(yh * ga + be, nb.slope);
                         if (!second) {
                             s0 += gg;
@@ -1756,6 +1788,8 @@ extern "C" int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y,
         for (int c = 0; c < ncls; ++c)
             SDT_CHECK_ARG(nbw->groups == 1 ? (int64_t)gs[c]->B * gs[c]->Ho * gs[c]->Wo >= 64 : gs[c]->Ho * gs[c]->Wo >= 64,
                           "a group must span at least one 64-row tile");
+        // (the epilogue reads y through a buffer resource: 32-bit byte offsets)
+        SDT_CHECK_ARG((int64_t)gs[0]->B * gs[0]->Hy * gs[0]->Wy * gs[0]->Cout * 4 < (1ll << 31) - 4, "output tensor too large for the fused backward statistics");
         nb = {(const float*)nbw->y, nbw->mean, nbw->rstd, nbw->gamma, nbw->beta, nbw->sums, nbw->slope, nbw->groups};
     }
     return taps_dispatch(x, w, nullptr, y, gs, ncls, splitk, partial, nb, stream);

@@ -816,7 +816,7 @@ def conv_input_grad(gy_cl, w, x_shape, stride, pad, norm_holder=None):
         part = torch.empty((k,) + tuple(dx.shape), device=w.device, dtype=torch.float32) if k > 1 else None
         nb = None
         if (norm_holder is not None and FUSE_BWD_STATS and k == 1 and not one_d and Cout % 32 == 0 and norm_holder.y is not None
-                and tuple(norm_holder.y.shape) == tuple(dx.shape)
+                and tuple(norm_holder.y.shape) == tuple(dx.shape) and dx.numel() * 4 < 2 ** 31 - 4  # (the epilogue's reads of y: 32-bit byte offsets)
                 and all((g.B * g.Ho * g.Wo if norm_holder.groups == 1 else g.Ho * g.Wo) >= 64 for g in gs)):
             h = norm_holder
             h.sums = _ARENA.take(2 * h.groups * Cin, w.device)
