@@ -1095,16 +1095,34 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
             }
 }
 
-// dw[n, wt(t), c] += the slabs of tile (nt, ct), chunk 0 first.  One thread per 4 consecutive columns of a tile row.
+// dw[n, wt(t), c] += the slabs of tile (nt, ct).  Q lanes per 4 consecutive columns of a tile row: lane q adds the chunks
+// [q * nchunk / Q, (q + 1) * nchunk / Q) in order, then the Q sums are added in order q = 0 .. Q-1 -- a fixed tree, no atomics.  Every
+// launch reads the same 33.5 MB of slabs (T * nchunk = 512 units of 64 KB), so the few-tile layers are short of workgroups, not of
+// bandwidth: Q = 1 took 17-19 us with 64 / 72 workgroups (1.8 TB/s) against 9 us with 1024; the host picks Q so that the grid has >= 512.
+template <int Q>
 __global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, const sk_args P, const int ncol,
                                                            const int nchunk, const int Cout, const int Tw, const int BM, const int BN) {
-    const int per_tile = BM * BN / 4 / 256;                  // workgroups per tile
+    const int per_tile = BM * BN / 4 * Q / 256;              // workgroups per tile
     const int tile = blockIdx.x / per_tile;
-    const int e = (blockIdx.x % per_tile) * 256 + threadIdx.x;  // float4 index inside the tile
+    const int lt = (blockIdx.x % per_tile) * 256 + threadIdx.x;
+    const int e = lt / Q, q = lt % Q;                        // float4 index inside the tile, chunk group
     const int nl = e / (BN / 4), jl = (e % (BN / 4)) * 4;
     const int nt = tile / ncol, ct = tile - nt * ncol;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nchunk; ++ch) sum += *(const f32x4*)(slabs + ((size_t)ch * P.T + tile) * (size_t)(BM * BN) + nl * BN + jl);
+    const int c0 = (int)((long)q * nchunk / Q), c1 = (int)((long)(q + 1) * nchunk / Q);
+    for (int ch = c0; ch < c1; ++ch) sum += *(const f32x4*)(slabs + ((size_t)ch * P.T + tile) * (size_t)(BM * BN) + nl * BN + jl);
+    if constexpr (Q > 1) {  // lanes q = 1 .. Q-1 of the group hand their sums to lane q = 0, which adds them in order
+        f32x4 tot = sum;
+#pragma unroll
+        for (int k = 1; k < Q; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = __shfl_down(sum[c], k, Q);
+            tot += o;
+        }
+        sum = tot;
+        if (q != 0) return;
+    }
     const sk_class& cl = P.cls[0];
     const int j = ct * BN + jl, t = j / cl.Cin, c = j - t * cl.Cin;
     const int n = nt * BM + nl;
@@ -1692,7 +1710,14 @@ static int dw_go(const void* xv, const void* dyv, float* dw, const void* plan_ho
     else if (bm == 64 && bn == 64 && wpc == 2) DW_GO(64, 64, 2);
     else DW_GO(64, 64, 1);
 #undef DW_GO
-    hipLaunchKernelGGL(dw_sk_reduce_kernel, dim3(A.T * (bm * bn / 4 / 256)), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
+    {
+        const int blocks1 = A.T * (bm * bn / 4 / 256);  // workgroups at one lane per float4
+        const int q = (blocks1 >= 512 || nchunk < 8) ? 1 : (blocks1 >= 256 || nchunk < 16) ? 2 : (blocks1 >= 128 || nchunk < 32) ? 4 : 8;
+        if (q == 1) hipLaunchKernelGGL(dw_sk_reduce_kernel<1>, dim3(blocks1), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
+        else if (q == 2) hipLaunchKernelGGL(dw_sk_reduce_kernel<2>, dim3(blocks1 * 2), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
+        else if (q == 4) hipLaunchKernelGGL(dw_sk_reduce_kernel<4>, dim3(blocks1 * 4), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
+        else hipLaunchKernelGGL(dw_sk_reduce_kernel<8>, dim3(blocks1 * 8), dim3(256), 0, s, (const float*)workspace, dw, A, ncol, nchunk, k.Cout, k.Tw, bm, bn);
+    }
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
