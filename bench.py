@@ -55,8 +55,9 @@ EVENT_STEPS_MAX = int(os.environ.get("SDT_EVENT_STEPS", "6"))
 
 def event_steps(steps):
     """sampled steps of the timed region: below 16 steps one "alone" + one "stages only"; from 16 steps on THREE "alone" steps + one
-    "stages only" (one sampled step of 20 was a thin basis for roofline.achieved; an "alone" step costs ~1.2 ms, i.e. the
-    driver's 20-step run pays ~2 % for them); a rotation alone / stages / as-run from 40 steps on, two rotations from 60 on"""
+    "stages only" (one sampled step of 20 was a thin basis for roofline.achieved) -- the first with events around every conv
+    launch, the other two around the dominant kernel's launches only (a fully instrumented step costs ~0.7 ms; three of them were 2 % of the
+    driver's 20-step run); a rotation alone / stages / as-run from 40 steps on, two rotations from 60 on"""
     if steps < 2:
         return steps  # a single timed step still carries the roofline sample
     if steps < 16:
@@ -309,6 +310,18 @@ def main(argv=None):
         gs = GraphedStep(pipe, warmup=min(3, max(1, args.warmup - 1)))
         runner = lambda i: gs.run(batches[i % len(batches)])  # noqa: E731
 
+    # (the event pools are created BEFORE the warm-up: creating and recording ~5000 events takes the host ~50 ms, the GPU idles and drops
+    # its clocks meanwhile, and the first six timed steps then ran 0.2-2 ms slow -- 2.5 % of the driver's 20-step run)
+    prof = prof_ovl = prof_dom = stages = None
+    if not stub and not args.no_kernel_events and not (args.graph and world == 1):
+        prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX)
+        prof_dom = ops.ConvProfiler(pool=2 * 40 * EVENT_STEPS_MAX)  # short runs: "alone" steps that time the dominant kernel's launches only
+        prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX) if ops.OVERLAP_DW else None
+        stages = ops.StageTimer()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if on_gpu else None
+    if marks is not None:
+        for e in marks:  # hipEventCreate happens at the first record()
+            e.record()
     for i in range(args.warmup):
         runner(i)
     reducer = getattr(pipe, "reducer", None)
@@ -318,22 +331,16 @@ def main(argv=None):
     # weight-gradient kernels run on a second stream, concurrently with the input-gradient chain, so a launch's duration
     # then includes the time it shared the GPU: sampled steps therefore ALTERNATE between "alone" (side stream off for
     # that step: the kernel-quality figure reported as roofline.achieved) and "as run" (roofline.overlapped).
-    prof = prof_ovl = stages = None
-    if not stub and not args.no_kernel_events and not (args.graph and world == 1):
-        prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX)
-        prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX) if ops.OVERLAP_DW else None
-        stages = ops.StageTimer()
     n_ev = event_steps(args.steps) if prof is not None else 0
     sampled = sorted({(j + 1) * args.steps // (n_ev + 1) for j in range(n_ev)}) if n_ev else []  # spread over the timed region
     # one event per step boundary on the main stream: per-step GPU time without a host synchronisation
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if on_gpu else None
     host_marks = []
     sync()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     overlap_dw = ops.OVERLAP_DW if ops is not None else False
-    n_alone = n_ovl = n_stage = 0
+    n_alone = n_ovl = n_stage = n_dom = 0
     for i in range(args.steps):
         if marks is not None:
             marks[i].record()
@@ -345,7 +352,16 @@ def main(argv=None):
                 # three kinds of sampled step in rotation: per-launch events with the side stream off ("alone"), per-launch events
                 # as run, and stage windows only (a handful of events per step: per-launch events would inflate the windows)
                 short_run = 16 <= args.steps < 40  # three "alone" steps, then one "stages only"
-                if (short_run and n_alone < 3) or (not short_run and n_alone <= n_ovl):
+                if short_run and 0 < n_alone and n_alone + n_dom < 3:
+                    # the second and third "alone" step of a short run carry events around the dominant kernel's launches only: an event
+                    # pair costs a launch its overlap with its neighbours (~0.5 ms per fully instrumented step, 2 % of a 20-step run)
+                    if prof_dom.only is None:  # the kernel with the most algorithmic FLOPs on the first sampled step (no synchronisation here)
+                        fl = {}
+                        for rec in prof.records:
+                            fl[rec[0]] = fl.get(rec[0], 0.0) + rec[3]
+                        prof_dom.only = {max(fl, key=fl.get)} if fl else set()
+                    ops.PROFILER, ops.OVERLAP_DW, n_dom = prof_dom, False, n_dom + 1
+                elif (short_run and n_alone < 1) or (not short_run and n_alone <= n_ovl):
                     ops.PROFILER, ops.OVERLAP_DW, n_alone = prof, False, n_alone + 1
                 elif n_stage < n_alone:
                     ops.STAGES, n_stage = stages, n_stage + 1
@@ -414,7 +430,7 @@ def main(argv=None):
             # SURVEY.md 8d's definition: clips / MEDIAN step time (per-step events on the main stream, max over ranks); `value`
             # above stays the driver's wall-clock mean over all K steps, the event-instrumented ones included
             "median_ms_per_step": median_ms, "value_at_median": world * B / (median_ms * 1e-3),
-            "event_instrumented_steps": sampled,
+            "event_instrumented_steps": sampled, "step_ms": [round(t, 3) for t in step_ms],
             "ms_per_step_uninstrumented": clean_mean_ms, "value_uninstrumented": world * B / (clean_mean_ms * 1e-3),
         }
         if stub:
@@ -424,6 +440,19 @@ def main(argv=None):
         if prof is not None and prof_steps > 0:
             summ = prof.summary()
             name, d = max(summ.items(), key=lambda kv: kv[1]["us"])
+            n_dom_used = 0
+            if n_dom > 0 and prof_dom.only == {name}:  # merge the dominant kernel's launches of the dominant-only "alone" steps
+                dd = prof_dom.summary().get(name)
+                if dd is not None:
+                    d = dict(d, roles={k: list(v) for k, v in d["roles"].items()})
+                    for k in ("launches", "us", "flops", "bytes"):
+                        d[k] += dd[k]
+                    d["max_launch_tflops"] = max(d["max_launch_tflops"], dd["max_launch_tflops"])
+                    for r, v in dd["roles"].items():
+                        acc = d["roles"].setdefault(r, [0, 0.0, 0.0])
+                        acc[0], acc[1], acc[2] = acc[0] + v[0], acc[1] + v[1], acc[2] + v[2]
+                    n_dom_used = n_dom
+            dom_steps = prof_steps + n_dom_used  # sampled steps behind the dominant kernel's figures
             avg_us = d["us"] / d["launches"]
             flops_per_launch = d["flops"] / d["launches"]
             achieved = flops_per_launch / (avg_us * 1e-6) / 1e12
@@ -434,8 +463,8 @@ def main(argv=None):
                     "%s: a launch 'achieved' %.1f TFLOP/s > fp32 matrix peak: FLOP accounting is wrong" % (kname, kd["max_launch_tflops"])
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                               "launches_per_step": d["launches"] / prof_steps, "avg_launch_us": avg_us,
-                               "event_sampled_steps": prof_steps,
+                               "launches_per_step": d["launches"] / dom_steps, "avg_launch_us": avg_us,
+                               "event_sampled_steps": dom_steps, "event_sampled_steps_all_kernels": prof_steps,
                                "measured": "HIP events on the launching stream, sampled steps of the timed region with the "
                                            "weight-gradient side stream switched off (the kernel alone on the GPU)",
                                "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
@@ -444,7 +473,7 @@ def main(argv=None):
             # the same kernel serves the MFMA-bound Conv2d launches and the latency-bound 1-D launches (M = B*T <= 2048 rows):
             # the average above mixes them, the split shows each (role = forward / input gradient, 2-D / 1-D stage)
             out["roofline"]["by_role"] = {
-                r: {"launches_per_step": v[0] / prof_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
+                r: {"launches_per_step": v[0] / dom_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
                     "frac": v[2] / (v[1] * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS} for r, v in sorted(d["roles"].items())}
             out["roofline"].update(cited_traffic(name))
             # the whole step against the fp32-MFMA floor of its convolutions: algorithmic conv FLOPs of a step / matrix peak / step time

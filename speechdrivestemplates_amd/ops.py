@@ -273,8 +273,11 @@ class ConvProfiler:
     """Optional HIP-event timing of every MFMA conv launch (bench.py's roofline leg).  Events are recorded on the
     stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
 
-    def __init__(self, pool=0):
+    def __init__(self, pool=0, only=None):
         self.records = []  # (kernel name, role, is_2d, algorithmic flops, algorithmic bytes, start, end)
+        # ``only``: a set of kernel names -- launches of other kernels run without events (bench.py's short runs time every conv launch on
+        # ONE sampled step and only the dominant kernel's on the others: an event pair costs the launch its overlap with its neighbours)
+        self.only = only
         # hipEventCreate happens at an event's first record(): warm a pool before the timed region so that recording
         # inside it is a bare hipEventRecord
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
@@ -354,7 +357,7 @@ def _conv_launch(kind, is2d, g, call, flops=None, name=None, esz=4):
     """``flops``: algorithmic FLOPs of the launch when they are not the geometry's ``2*M*Cout*ntaps*Cin`` (an input-gradient
     class of a valid-correlation layer: the tap table spans input positions no output position reaches; SURVEY.md 8d counts
     dX = forward)."""
-    if PROFILER is None:
+    if PROFILER is None or (PROFILER.only is not None and name not in PROFILER.only):
         check(call())
         return
     lib = _lib.load()
@@ -378,7 +381,7 @@ def _conv_launch_multi(kind, is2d, gs, call, extra_bytes=0.0, flops=None, name=N
     what a fused epilogue has to read on top of the GEMM's operands (the raw y of the block below for the backward statistics);
     ``flops``: the algorithmic FLOPs (input gradients pass the FORWARD layer's count, SURVEY.md 8d -- the classes' tap tables
     also cover (position, tap) pairs that fall outside the forward output, which the kernel culls and nobody should count)"""
-    if PROFILER is None:
+    if PROFILER is None or (PROFILER.only is not None and name not in PROFILER.only):
         check(call())
         return
     lib = _lib.load()
@@ -1025,7 +1028,7 @@ def _dw_group_launch(items):
     dws = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
     st = _stream()
     call = lambda: lib.sdt_conv_dw_group_f32(xs, dys, dws, n, C.addressof(host), _p(plan_dev), _p(ws), st)  # noqa: E731
-    if PROFILER is None:
+    if PROFILER is None or (PROFILER.only is not None and "conv_dw_group_kernel" not in PROFILER.only):
         check(call())
         return
     flops = sum(2.0 * g.B * g.Ho * g.Wo * g.Cout * g.ntaps * g.Cin for _x, _y, _w, g in items)
@@ -1533,7 +1536,7 @@ def chain1d_usable(h, spec, weights):
 
 
 def _chain_launch(name, kind, flops, nbytes, call):
-    if PROFILER is None:
+    if PROFILER is None or (PROFILER.only is not None and name not in PROFILER.only):
         check(call())
         return
     e0, e1 = PROFILER.event(), PROFILER.event()
