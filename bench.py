@@ -244,7 +244,10 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = not stub
-    if world > 1:
+    # SDT_DP_FORCE=1 under a launcher (`torch.distributed.run --nproc-per-node 1`): a 1-rank RCCL group, so that the whole data-parallel step --
+    # reducer, bucket hooks, reserve, graph capture of the all-reduces -- is what gets timed on a single-GPU box
+    forced_dp = world == 1 and os.environ.get("SDT_DP_FORCE") == "1" and "WORLD_SIZE" in os.environ and not stub
+    if world > 1 or forced_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if on_gpu:
@@ -296,7 +299,8 @@ def main(argv=None):
         ops.set_storage(args.storage)
         # every rank draws its own initial weights (nothing here seeds torch): setup_optimizer's dp.sync_replicas makes the
         # replicas identical, as DDP's constructor does in the reference
-        pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world)
+        pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world,
+                                  sys_opts={"STORAGE": args.storage, "CHAIN1D": not args.no_chain1d, "DISTRIBUTED": world > 1 or forced_dp})
         batches = stage_batches(4, B, rank, dev)
 
     def step(i):
@@ -305,7 +309,7 @@ def main(argv=None):
         return losses
 
     runner = step
-    if args.graph and world == 1 and not stub:
+    if args.graph and not stub:  # N > 1: the gradient exchange is part of the replayed step (graph.GraphedStep, "full" over RCCL)
         from speechdrivestemplates_amd.graph import GraphedStep
         gs = GraphedStep(pipe, warmup=min(3, max(1, args.warmup - 1)))
         runner = lambda i: gs.run(batches[i % len(batches)])  # noqa: E731
@@ -313,7 +317,7 @@ def main(argv=None):
     # (the event pools are created BEFORE the warm-up: creating and recording ~5000 events takes the host ~50 ms, the GPU idles and drops
     # its clocks meanwhile, and the first six timed steps then ran 0.2-2 ms slow -- 2.5 % of the driver's 20-step run)
     prof = prof_ovl = prof_dom = stages = None
-    if not stub and not args.no_kernel_events and not (args.graph and world == 1):
+    if not stub and not args.no_kernel_events and not args.graph:
         prof = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX)
         prof_dom = ops.ConvProfiler(pool=2 * 40 * EVENT_STEPS_MAX)  # short runs: "alone" steps that time the dominant kernel's launches only
         prof_ovl = ops.ConvProfiler(pool=2 * 200 * EVENT_STEPS_MAX) if ops.OVERLAP_DW else None
@@ -408,6 +412,97 @@ def main(argv=None):
     final_loss = float(losses["G_loss" if "G_loss" in losses else "loss"].detach())
     assert final_loss == final_loss and final_loss < 10.0, "training diverged: G_loss=%r" % final_loss
 
+    def bf16_leg():
+        """informational, OUTSIDE the timed region and not part of `value`: BASELINE config 4's arithmetic on this GPU (these GPUs: every rank runs
+        it, the exchange included; the slowest rank's time counts) -- the same train step with the Conv2d chain's tensors stored as bf16 and its
+        products on the bf16 MFMA (fp32 accumulation / statistics / master weights; tests/test_bf16_gpu.py states and checks its tolerances).
+        Replayed from a hipGraph (N > 1: with its RCCL all-reduces, graph.GraphedStep): the step needs ~2-3 ms of GPU time, the host ~3-5 ms to
+        enqueue its launches one by one (tools/host_time.py)."""
+        out = {}
+
+        def wall(t_local):  # the slowest rank defines the job
+            if world == 1 and not forced_dp:
+                return t_local
+            t = torch.tensor([t_local], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        from speechdrivestemplates_amd.graph import GraphedStep
+        ops.set_storage("bf16")
+        pipe.knobs["storage"] = "bf16"  # the SAME pipeline continues in bf16 storage (its bf16 weight copies are allocated on first use)
+        try:
+            base = args.warmup + args.steps
+            for i in range(3):  # eager: allocates the bf16 weight copies and builds the bf16 plans outside any capture
+                step(base + i)
+            sync()
+            aprof = None
+            if prof is not None:  # its own roofline: three eager steps with per-launch events, weight gradients on the main stream
+                aprof = ops.ConvProfiler(pool=2 * 200 * 3)
+                try:
+                    ops.PROFILER, ops.OVERLAP_DW = aprof, False
+                    for i in range(3):
+                        step(base + 3 + i)
+                    sync()
+                finally:
+                    ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
+            gs = GraphedStep(pipe, warmup=1)
+            for i in range(4):
+                gs.run(batches[(base + 6 + i) % len(batches)])
+            sync()
+            if world > 1:
+                dist.barrier()
+            ta = time.perf_counter()
+            n_alt = 30
+            for i in range(n_alt):
+                losses_alt = gs.run(batches[(base + 10 + i) % len(batches)])
+            sync()
+            alt_ms = wall((time.perf_counter() - ta) * 1e3 / n_alt)
+            alt_loss = float(losses_alt["G_loss"].detach())
+            te = time.perf_counter()
+            for i in range(10):
+                step(base + 40 + i)
+            sync()
+            eager_ms = wall((time.perf_counter() - te) * 1e3 / 10)
+            codes = ops.streamk_error_codes()
+            assert not codes, "stream-K error words (bf16 leg): %r" % codes
+        finally:
+            ops.set_storage("f32")
+            pipe.knobs["storage"] = "f32"
+        assert alt_loss == alt_loss and alt_loss < 10.0, "bf16 leg diverged: G_loss=%r" % alt_loss
+        out["alt_conv_math"] = {"mode": "bf16", "dtype": "bf16 (Conv2d chain: bf16 tensors in HBM + bf16 MFMA products; fp32 accumulation, statistics, "
+                                                         "master weights, gradients; generator Conv1d chain: fp32 tensors, bf16 MFMA products; 1-D weight gradients, head, losses fp32)",
+                                "value": world * B / (alt_ms * 1e-3), "unit": "clips/s", "n_gpus": world, "ms_per_step": alt_ms, "steps": n_alt, "graph": True,
+                                "eager_ms_per_step": eager_ms, "G_loss": alt_loss, "graph_mode": gs.mode,
+                                "note": "not the headline (the metric is quoted on the reference's fp32 arithmetic): %d further steps of the same run in "
+                                        "bf16 storage (BASELINE config 4 per GPU), replayed from a hipGraph; eager_ms_per_step = the same steps "
+                                        "enqueued launch by launch (host-bound)" % n_alt}
+        if aprof is not None:
+            asum = aprof.summary()
+            two_d = {k: v for k, v in asum.items() if "bf16" in k or k.startswith("convbf")}
+            aname, ad = max(two_d.items(), key=lambda kv: kv[1]["us"])
+            a_us = ad["us"] / ad["launches"]
+            a_bytes, a_flops = ad["bytes"] / ad["launches"], ad["flops"] / ad["launches"]
+            tot_b = sum(v["bytes"] for v in two_d.values())
+            tot_f = sum(v["flops"] for v in two_d.values())
+            tot_us = sum(v["us"] for v in two_d.values())
+            out["alt_conv_math"]["roofline"] = {
+                "bound": "hbm", "kernel": aname, "achieved": a_bytes / (a_us * 1e-6) / 1e9, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                "frac": a_bytes / (a_us * 1e-6) / 1e12 / HBM_PEAK_TBS, "avg_launch_us": a_us, "launches_per_step": ad["launches"] / 3.0,
+                "algorithmic_mb_per_launch": a_bytes / 1e6, "algorithmic_gflop_per_launch": a_flops / 1e9,
+                "mfma_achieved_tflops": a_flops / (a_us * 1e-6) / 1e12, "mfma_frac": a_flops / (a_us * 1e-6) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
+                "all_conv2d_launches": {"ms_per_step": tot_us / 3.0 / 1e3, "gb_s": tot_b / (tot_us * 1e-6) / 1e9,
+                                        "tflops": tot_f / (tot_us * 1e-6) / 1e12, "launches_per_step": sum(v["launches"] for v in two_d.values()) / 3.0},
+                "event_sampled_steps": 3,
+                "note": "bf16 tensors: algorithmic bytes = 2 x (|X| + |Y| + |W|) per launch (SURVEY.md 8d's per-layer bytes halved) / HIP-event window, "
+                        "against 8 TB/s; mfma_* = the same launches against the dense bf16 MFMA peak (%.0f TFLOP/s): the kernels are bound by "
+                        "neither -- LDS feeding and the per-tile epilogue of a persistent fp32-shaped tile (DESIGN.md section 2)" % BF16_MATRIX_PEAK_TFLOPS}
+        return out.get("alt_conv_math")
+
+    alt = None
+    if not stub and not args.no_alt_mode and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
+            and args.config == "voice2pose_sdt_bp":
+        alt = bf16_leg()  # every rank (collectives inside)
+
     if rank == 0:
         out = {
             "metric": "training clips/sec (64-frame, 137-kpt) %s" % args.config,  # BASELINE.json's metric is quoted on the default config
@@ -420,7 +515,7 @@ def main(argv=None):
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
                                    % (args.config, B, world, N_CLIPS),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph and world == 1), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
                        # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
                        # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
                        # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)
@@ -521,82 +616,14 @@ def main(argv=None):
             hbs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_kernels.txt")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
             if hbs:
                 out["hbm_kernels_table"] = "profiles/%s (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)" % hbs[-1]
-        if world == 1 and not stub and not args.no_alt_mode and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
-                and args.config == "voice2pose_sdt_bp":
-            # informational, OUTSIDE the timed region and not part of `value`: BASELINE config 4's arithmetic on this GPU -- the same train step
-            # with the Conv2d chain's tensors stored as bf16 and its products on the bf16 MFMA (fp32 accumulation / statistics / master weights;
-            # tests/test_bf16_gpu.py states and checks its tolerances).  Replayed from a hipGraph: the step needs ~3.5 ms of GPU time, the host
-            # ~5.6 ms to enqueue its launches one by one (tools/host_time.py).
-            from speechdrivestemplates_amd.graph import GraphedStep
-            ops.set_storage("bf16")
-            try:
-                base = args.warmup + args.steps
-                for i in range(3):  # eager: allocates the bf16 weight copies and builds the bf16 plans outside any capture
-                    step(base + i)
-                sync()
-                aprof = None
-                if prof is not None:  # its own roofline: three eager steps with per-launch events, weight gradients on the main stream
-                    aprof = ops.ConvProfiler(pool=2 * 200 * 3)
-                    try:
-                        ops.PROFILER, ops.OVERLAP_DW = aprof, False
-                        for i in range(3):
-                            step(base + 3 + i)
-                        sync()
-                    finally:
-                        ops.PROFILER, ops.OVERLAP_DW = None, overlap_dw
-                gs = GraphedStep(pipe, warmup=1)
-                for i in range(4):
-                    gs.run(batches[(base + 6 + i) % len(batches)])
-                sync()
-                ta = time.perf_counter()
-                n_alt = 30
-                for i in range(n_alt):
-                    losses_alt = gs.run(batches[(base + 10 + i) % len(batches)])
-                sync()
-                alt_ms = (time.perf_counter() - ta) * 1e3 / n_alt
-                alt_loss = float(losses_alt["G_loss"].detach())
-                te = time.perf_counter()
-                for i in range(10):
-                    step(base + 40 + i)
-                sync()
-                eager_ms = (time.perf_counter() - te) * 1e3 / 10
-                codes = ops.streamk_error_codes()
-                assert not codes, "stream-K error words (bf16 leg): %r" % codes
-            finally:
-                ops.set_storage("f32")
-            assert alt_loss == alt_loss and alt_loss < 10.0, "bf16 leg diverged: G_loss=%r" % alt_loss
-            out["alt_conv_math"] = {"mode": "bf16", "dtype": "bf16 (Conv2d chain: bf16 tensors in HBM + bf16 MFMA products; fp32 accumulation, statistics, "
-                                                             "master weights, gradients; generator Conv1d chain: fp32 tensors, bf16 MFMA products; 1-D weight gradients, head, losses fp32)",
-                                    "value": B / (alt_ms * 1e-3), "unit": "clips/s", "ms_per_step": alt_ms, "steps": n_alt, "graph": True,
-                                    "eager_ms_per_step": eager_ms, "G_loss": alt_loss, "vs_default": B / (alt_ms * 1e-3) / out["value_uninstrumented"],
-                                    "note": "not the headline (the metric is quoted on the reference's fp32 arithmetic): %d further steps of the same run in "
-                                            "bf16 storage (BASELINE config 4 per GPU), replayed from a hipGraph; eager_ms_per_step = the same steps "
-                                            "enqueued launch by launch (host-bound)" % n_alt}
-            if aprof is not None:
-                asum = aprof.summary()
-                two_d = {k: v for k, v in asum.items() if "bf16" in k or k.startswith("convbf")}
-                aname, ad = max(two_d.items(), key=lambda kv: kv[1]["us"])
-                a_us = ad["us"] / ad["launches"]
-                a_bytes, a_flops = ad["bytes"] / ad["launches"], ad["flops"] / ad["launches"]
-                tot_b = sum(v["bytes"] for v in two_d.values())
-                tot_f = sum(v["flops"] for v in two_d.values())
-                tot_us = sum(v["us"] for v in two_d.values())
-                out["alt_conv_math"]["roofline"] = {
-                    "bound": "hbm", "kernel": aname, "achieved": a_bytes / (a_us * 1e-6) / 1e9, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-                    "frac": a_bytes / (a_us * 1e-6) / 1e12 / HBM_PEAK_TBS, "avg_launch_us": a_us, "launches_per_step": ad["launches"] / 3.0,
-                    "algorithmic_mb_per_launch": a_bytes / 1e6, "algorithmic_gflop_per_launch": a_flops / 1e9,
-                    "mfma_achieved_tflops": a_flops / (a_us * 1e-6) / 1e12, "mfma_frac": a_flops / (a_us * 1e-6) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
-                    "all_conv2d_launches": {"ms_per_step": tot_us / 3.0 / 1e3, "gb_s": tot_b / (tot_us * 1e-6) / 1e9,
-                                            "tflops": tot_f / (tot_us * 1e-6) / 1e12, "launches_per_step": sum(v["launches"] for v in two_d.values()) / 3.0},
-                    "event_sampled_steps": 3,
-                    "note": "bf16 tensors: algorithmic bytes = 2 x (|X| + |Y| + |W|) per launch (SURVEY.md 8d's per-layer bytes halved) / HIP-event window, "
-                            "against 8 TB/s; mfma_* = the same launches against the dense bf16 MFMA peak (%.0f TFLOP/s): the kernels are bound by "
-                            "neither -- LDS feeding and the per-tile epilogue of a persistent fp32-shaped tile (DESIGN.md section 2)" % BF16_MATRIX_PEAK_TFLOPS}
+        if alt is not None:
+            alt["vs_default"] = alt["value"] / out["value_uninstrumented"]
+            out["alt_conv_math"] = alt
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(B)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced_dp:
         dist.destroy_process_group()
 
 

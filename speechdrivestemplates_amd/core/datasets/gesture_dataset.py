@@ -25,22 +25,32 @@ def register_speaker_stat(name, parted=None, global_=None):
         SPEAKERS_STAT_121_parted[name] = parted
     if global_ is not None:
         SPEAKERS_STAT_121[name] = global_
+    PoseTransforms._STAT_ON_DEVICE.clear()  # device copies of replaced tables must not outlive them
 
 
 class PoseTransforms:
     """normalize / denormalize / parted<->global / get_final_results with the reference semantics."""
     root_node, hand_root_l, hand_root_r, head_root = 1, HAND_ROOT_L, HAND_ROOT_R, HEAD_ROOT
 
-    _STAT_ON_DEVICE = {}  # (id(ndarray), device) -> (ndarray kept alive, fp32 tensor): registered statistics are uploaded once, not per step
+    # (id(ndarray), device) -> (ndarray kept alive, fp32 tensor, the bytes that were uploaded): registered statistics are uploaded once, not per
+    # step.  An entry is served only while the array still holds the uploaded bytes (a 2 KB compare: an in-place edit of a registered mean / std
+    # re-uploads instead of serving the stale copy); the table is bounded and dropped by register_speaker_stat (ADVICE r4).
+    _STAT_ON_DEVICE = {}
+    _STAT_CACHE_MAX = 64
 
     def _stat(self, t, kp):
         K = self.cfg.NUM_LANDMARKS
         if isinstance(t, np.ndarray):
             key = (id(t), str(kp.device))
             hit = PoseTransforms._STAT_ON_DEVICE.get(key)
-            if hit is None or hit[0] is not t:
+            raw = t.tobytes()
+            if hit is None or hit[0] is not t or hit[2] != raw:
+                if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("speaker statistics changed (or were never uploaded) inside a hipGraph capture")
+                if len(PoseTransforms._STAT_ON_DEVICE) >= PoseTransforms._STAT_CACHE_MAX:
+                    PoseTransforms._STAT_ON_DEVICE.clear()
                 # torch.Tensor(ndarray) -> float32, :174-176.  (A host-to-device copy per call also made the step un-capturable in a hipGraph.)
-                hit = PoseTransforms._STAT_ON_DEVICE[key] = (t, torch.tensor(t.astype(np.float64), dtype=torch.float32).to(kp.device))
+                hit = PoseTransforms._STAT_ON_DEVICE[key] = (t, torch.tensor(t.astype(np.float64), dtype=torch.float32).to(kp.device), raw)
             t = hit[1]
         else:
             t = t.to(kp.device)

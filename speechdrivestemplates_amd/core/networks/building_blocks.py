@@ -64,6 +64,10 @@ class ConvNormRelu(nn.Module):
             return ops.ConvRowNormFn.apply(x_cl, self.conv.weight, self.stride, self.padding, self.slope)
         if self.conv_type == '2d' and (self.norm_type == 'IN' or self.training):
             groups = x_cl.shape[0] if self.norm_type == 'IN' else 1
+            if bn_groups > 1 and self.norm_type != 'IN':
+                # the fused-statistics launch accumulates ONE batch group for BatchNorm: a caller that asks for per-slice statistics must not get
+                # joint ones silently (not reachable today -- the paired no-grad pass is 1-D -- hence a refusal, not a second code path)
+                raise RuntimeError("bn_groups > 1 is not built for 2-D BatchNorm blocks")
             if ops.conv_stats_fusable(x_cl, self.conv.weight, self.stride, self.padding, groups):
                 # the conv's epilogue accumulates the normalisation statistics: y is not re-read for them
                 y, sums = ops.ConvStatsFn.apply(x_cl, self.conv.weight, self.stride, self.padding, groups, in_holder)

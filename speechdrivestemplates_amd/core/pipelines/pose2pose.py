@@ -49,6 +49,8 @@ class Pose2Pose(Trainer):
         super().__init__(cfg)
 
     def setup_model(self, cfg, state_dict=None):
+        self.knobs = {'storage': 'f32', 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True))}  # the pose VAE is 1-D only: fp32 tensors (Trainer.apply_knobs)
+        self.apply_knobs()
         self.model = Pose2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank()).cuda()
         if state_dict is not None:
             self.model.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()})
@@ -61,11 +63,12 @@ class Pose2Pose(Trainer):
         if self.cfg.TRAIN.LR_SCHEDULER:
             E = self.cfg.TRAIN.NUM_EPOCHS
             self.schedulers['scheduler'] = _MultiStepLR(opt, [E - 10, E - 2], 0.1, last_epoch)
-        self.reducer = dp.GradReducer(self.optimizers.values())
+        self._set_reducer(dp.GradReducer(self.optimizers.values()))
         dp.sync_replicas(self.model, list(self.optimizers.values()))  # DDP-constructor semantics (pose2pose.py:102)
 
     def forward_backward(self, batch, want_final=False):
         dev = self.model.clip_code_mu.device
+        self.apply_knobs()
         ops.begin_step(dev)
         losses, results = self.model(batch)
         stat = batch['speaker_stat']
@@ -92,19 +95,13 @@ class Pose2Pose(Trainer):
         opt.step()
 
     def train_step(self, batch, t_step, global_step, epoch):
-        if getattr(self.cfg.SYS, 'HIP_GRAPH', False) and not self.cfg.SYS.DISTRIBUTED:
-            # ~150 launches of a few microseconds: enqueued one by one the step is bound by the host (3 ms); replayed from a hipGraph it is not
-            if getattr(self, '_graphed', None) is None:
-                from ...graph import GraphedStep
-                self._graphed = GraphedStep(self, warmup=2)
-            losses = self._graphed.run(batch)
-        else:
-            losses, _ = self.forward_backward(batch)
-            self.optimizer_updates(losses)
+        # SYS.HIP_GRAPH: ~150 launches of a few microseconds -- enqueued one by one the step is bound by the host (3 ms); replayed from a hipGraph
+        # (one GPU or data-parallel: graph.GraphedStep) it is not
+        losses, _ = self.graphed_or_eager_step(batch)
         self.last_losses = losses
         if t_step % self.cfg.SYS.LOG_INTERVAL == 0:
             if self.cfg.SYS.DISTRIBUTED:
-                dp.reduce_scalars(losses)
+                self.check_kernels_all_ranks(dp.reduce_scalars(losses, error_flag=ops.kernel_error_flag()))
             if self.is_master_process():
                 self.logger_writer_step('TRAIN', losses, t_step, epoch, global_step)
 
@@ -113,6 +110,7 @@ class Pose2Pose(Trainer):
         """Validation / test step of the pose VAE (pose2pose.py:172-217) without the video writer."""
         tag = 'TEST' if epoch == 0 else 'VAL'
         dev = self.model.clip_code_mu.device
+        self.apply_knobs()
         m = self.cfg.TEST.MULTIPLE
         assert isinstance(m, int) and m >= 1, 'TEST.MULTIPLE should be an integer that larger than 1, but get %r (%s).' % (m, type(m))
         if m > 1:

@@ -155,6 +155,49 @@ class Trainer(object):
         from ... import ops
         ops.check_streamk()
 
+    def check_kernels_all_ranks(self, flagged=None):
+        """``check_kernels`` for data-parallel runs: every rank learns whether ANY rank's persistent launch lost a partner and all of them raise
+        together -- before rank 0 logs NaN losses or writes a checkpoint of weights that the summing all-reduce has already poisoned on every
+        rank (rank 0's own word is clean when the launch failed on rank 3).  COLLECTIVE: every rank must call it at the same
+        point (log steps via dp.reduce_scalars' piggy-backed flag -> ``flagged``; before a checkpoint; after validation)."""
+        from ... import dp, ops
+        if flagged is None:
+            if not (self.cfg.SYS.DISTRIBUTED and dp.world_size() > 1):
+                return self.check_kernels()
+            flagged = dp.any_rank_flag(ops.kernel_error_flag())
+        if flagged:
+            self.check_kernels()  # the rank(s) that own the error word raise with its decoded contents
+            raise RuntimeError("a persistent launch on %d other rank(s) gave up waiting for a partner workgroup: the gradients exchanged since the "
+                               "last check are invalid on every rank (see that rank's message)" % int(flagged))
+
+    def close(self):
+        """Give back what this pipeline holds process-wide (the data-parallel reducer's workgroup-slot reserve, dp.GradReducer.close)."""
+        r = getattr(self, 'reducer', None)
+        if r is not None:
+            r.close()
+
+    def _set_reducer(self, reducer):
+        self.close()  # a second setup_optimizer on this pipeline: the old reducer's reserve goes back first
+        self.reducer = reducer
+
+    def apply_knobs(self):
+        """storage / chain mode of THIS pipeline's configuration become the process-wide kernel routing for the step that follows"""
+        from ... import ops
+        ops.apply_knobs(getattr(self, 'knobs', None))
+
+    def graphed_or_eager_step(self, batch, eager_ok=True, want_final=False):
+        """forward + backward + gradient exchange + optimiser updates of one train step: replayed from a hipGraph when SYS.HIP_GRAPH is set (single
+        GPU and data-parallel alike, graph.GraphedStep), enqueued launch by launch otherwise.  Returns (losses, results)."""
+        if getattr(self.cfg.SYS, 'HIP_GRAPH', False) and eager_ok:
+            if getattr(self, '_graphed', None) is None:
+                from ...graph import GraphedStep
+                self._graphed = GraphedStep(self, warmup=2)
+            losses = self._graphed.run(batch)
+            return losses, self._graphed.results
+        losses, results = self.forward_backward(batch, want_final=want_final)
+        self.optimizer_updates(losses)
+        return losses, results
+
     def save_checkpoint(self, epoch, global_step):
         self.check_kernels()
         d = os.path.join(self.base_path, 'checkpoints')
@@ -211,6 +254,7 @@ class Trainer(object):
                 global_step += 1
                 self.train_step(batch, t_step + 1, global_step, epoch + 1)
             if (epoch + 1) % self.cfg.TRAIN.CHECKPOINT_INTERVAL == 0:  # validation rides on the checkpoint interval (:389-394)
+                self.check_kernels_all_ranks()  # collective: no rank's lost partner may reach the file rank 0 writes
                 if self.is_master_process():
                     self.save_checkpoint(epoch + 1, global_step)
                 if self.cfg.TRAIN.VALIDATE:
@@ -227,6 +271,7 @@ class Trainer(object):
         broadcast."""
         from ... import dp
         test_dataloader = self.test_dataloader if test_dataloader is None else test_dataloader
+        self.apply_knobs()
         if self.cfg.SYS.DISTRIBUTED:
             dp.sync_buffers(self.model)
         self.model.eval()
@@ -238,7 +283,7 @@ class Trainer(object):
                 sums[k] = sums.get(k, 0) + v
             for k, v in res.items():
                 coll.setdefault(k, []).append(v)
-        self.check_kernels()
+        self.check_kernels_all_ranks()
         out = {k: v / self.num_test_samples for k, v in sums.items()}
         if coll and self.is_master_process():
             out.update(self.evaluate_epoch({k: np.concatenate(v, axis=0) for k, v in coll.items()}))

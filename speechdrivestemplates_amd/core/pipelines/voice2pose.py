@@ -181,10 +181,11 @@ class Voice2Pose(Trainer):
         super().__init__(cfg)
 
     def setup_model(self, cfg, state_dict=None, external_codes=None):
-        if not getattr(cfg.SYS, 'CHAIN1D', True):
-            ops.CHAIN1D = False  # process-wide, like the storage mode
-        if getattr(cfg.SYS, 'STORAGE', 'f32') != 'f32':
-            ops.set_storage(cfg.SYS.STORAGE)  # before setup_optimizer: its weight mirrors allocate the bf16 copies
+        # kernel routing this pipeline's configuration asks for -- set UNCONDITIONALLY (defaults included: a pipeline built after a bf16 one in the
+        # same process must not inherit its mode) and re-applied at the start of every step this pipeline runs (Trainer.apply_knobs).
+        # Before setup_optimizer: its weight mirrors allocate the bf16 copies.
+        self.knobs = {'storage': getattr(cfg.SYS, 'STORAGE', 'f32'), 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True))}
+        self.apply_knobs()
         self.model = Voice2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank(), external_codes).cuda()
         if state_dict is not None:
             sd = OrderedDict((k[len('module.'):] if k.startswith('module.') else k, v) for k, v in state_dict.items())
@@ -213,7 +214,7 @@ class Voice2Pose(Trainer):
         code = cfg.VOICE2POSE.GENERATOR.CLIP_CODE
         if code.DIMENSION is not None and not code.EXTERNAL_CODE and code.TRAIN:
             add('optimizerClipCode', [self.model.clips_code], cfg.TRAIN.LR * code.LR_SCALING)
-        self.reducer = dp.GradReducer(self.optimizers.values())
+        self._set_reducer(dp.GradReducer(self.optimizers.values()))
         # DDP-constructor semantics (voice2pose.py:222-223): every rank starts from rank 0's parameters, buffers and Adam state
         dp.sync_replicas(self.model, list(self.optimizers.values()))
         if self.reducer.active:
@@ -255,6 +256,7 @@ class Voice2Pose(Trainer):
         """Forward, per-step metrics and both backward passes (voice2pose.py:288-301,306-308) -- everything of a
         train step up to (not including) the gradient exchange and the optimiser updates."""
         dev = self.model._device()
+        self.apply_knobs()
         ops.begin_step(dev)
         losses, results = self.model(batch, self.train_dataset)
         stat = batch['speaker_stat']
@@ -302,21 +304,15 @@ class Voice2Pose(Trainer):
         tag = 'TRAIN'
         log_step = t_step % self.cfg.SYS.LOG_INTERVAL == 0
         save_step = t_step % self.result_saving_interval_train == 0 and (self.cfg.TRAIN.SAVE_NPZ or self.cfg.TRAIN.SAVE_VIDEO)
-        if getattr(self.cfg.SYS, 'HIP_GRAPH', False) and not save_step and not self.cfg.SYS.DISTRIBUTED:
-            # replay the captured step (forward, metrics, backward, Adam): the host copies the batch into the graph's static inputs and
-            # launches ONE graph instead of ~270 kernels (graph.GraphedStep; steps that save results run eagerly: they need the final poses)
-            if getattr(self, '_graphed', None) is None:
-                from ...graph import GraphedStep
-                self._graphed = GraphedStep(self, warmup=2)
-            losses = self._graphed.run(batch)
-            results = self._graphed.results
-        else:
-            losses, results = self.forward_backward(batch, want_final=bool(save_step))
-            self.optimizer_updates(losses)
+        # SYS.HIP_GRAPH: replay the captured step (forward, metrics, backward, gradient exchange, Adam): the host copies the batch into the graph's
+        # static inputs and launches ONE graph instead of ~270 kernels -- on one GPU and under data parallelism alike (graph.GraphedStep captures the
+        # RCCL all-reduces with the step, or replays two graphs around an eager exchange; steps that save results run eagerly: they need the final poses)
+        losses, results = self.graphed_or_eager_step(batch, eager_ok=not save_step, want_final=bool(save_step))
         self.last_losses = losses
         if log_step:
             if self.cfg.SYS.DISTRIBUTED:
-                dp.reduce_scalars(losses)
+                # the per-rank kernel error words travel with the loss scalars: every rank stops HERE when any rank's launch lost a partner
+                self.check_kernels_all_ranks(dp.reduce_scalars(losses, error_flag=ops.kernel_error_flag()))
             if self.is_master_process():
                 self.logger_writer_step(tag, losses, t_step, epoch, global_step)
         if save_step and self.is_master_process() and self.cfg.TRAIN.SAVE_NPZ:
@@ -328,6 +324,7 @@ class Voice2Pose(Trainer):
         """Validation / test step (voice2pose.py:333-384) without the video writer."""
         tag = 'TEST' if epoch == 0 else 'VAL'
         dev = self.model._device()
+        self.apply_knobs()
         m = self.cfg.TEST.MULTIPLE
         assert isinstance(m, int) and m >= 1, 'TEST.MULTIPLE should be an integer that larger than 1, but get %r (%s).' % (m, type(m))
         if m > 1:
@@ -357,6 +354,7 @@ class Voice2Pose(Trainer):
         (1, L) with L cropped to a whole number of 1/15 s frames, batch['num_frames'] = L // (16000/15) (up to 360 for the
         reference's 24 s demo limit); returns de-normalised global poses (1, T, 2, 121) in float64."""
         self.model.eval()
+        self.apply_knobs()
         results = self.model(batch, self.test_dataset, return_loss=False, interpolation_coeff=interpolation_coeff)
         results['poses_pred_batch'] = self.test_dataset.get_final_results(results['poses_pred_batch'].detach(), batch['speaker_stat'])
         if self.is_master_process() and self.cfg.TEST.SAVE_NPZ and self.base_path is not None:

@@ -126,6 +126,19 @@ __device__ __forceinline__ void ch_wait(gu32* cnt, unsigned want, const ch_args&
     }
 }
 
+// A wait of this workgroup timed out (a member of its cluster never arrived): besides the error word, everything downstream of the chain must see it
+// at once -- the frames this member owns of `base` (rows x cols fp32, frame t belongs to member (t >> 2) & 7) become NaN, so the loss (forward) or
+// the gradients that leave the chain (backward) are NaN in the SAME step, as the stream-K convolution does with a tile whose partner was lost
+// (until the Trainer read the error word, up to LOG_INTERVAL optimiser steps applied finite garbage).
+__device__ __forceinline__ void ch_poison_rows(float* base, int rows, int cols, int r) {
+    const f32x4 nan4 = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    const int nv = cols >> 2;
+    for (int i = threadIdx.x; i < rows * nv; i += 256) {
+        const int t = i / nv;
+        if (((t >> 2) & 7) == r) *(f32x4*)(base + (size_t)t * cols + 4 * (i - t * nv)) = nan4;
+    }
+}
+
 // publish: every store of this workgroup has left (write-through), then one bump.  The member whose bump completes the launch's total lowers
 // the counter again: it is zero between launches (hipGraph replays carry no epoch).
 __device__ __forceinline__ void ch_arrive(gu32* cnt, unsigned total) {
@@ -531,6 +544,7 @@ __global__ __launch_bounds__(256) void chain1d_fwd_kernel(const ch_args A) {
             const ch_row z = ch_norm_row(ch_ld_row(rsA, t, li), A.eps, A.slope);
             if (t < L.To) ch_put_row(zo + (size_t)t * CH_C, z, li);
         }
+        if (dead) ch_poison_rows(zo, L.To, CH_C, r);
         ch_arrive(cnt, total);
     }
 }
@@ -704,6 +718,10 @@ __global__ __launch_bounds__(256) void chain1d_bwd_kernel(const ch_args A) {
             }
         }
         CH_TL(s, 2);
+        if (l == 0 && dead) {  // (shared flag: uniform after the barriers above) what leaves the chain: block 0's raw-output gradient and input gradient
+            ch_poison_rows(L.dy + (size_t)clip * L.To * CH_C, L.To, CH_C, r);
+            if (A.need_dx0) ch_poison_rows(L.dx + (size_t)clip * L.Ti * L.Cin, L.Ti, L.Cin, r);
+        }
         ch_arrive(cnt, total);
         CH_TL(s, 3);
     }
@@ -749,7 +767,11 @@ static int chain_fill(ch_args& A, const sdt_chain1d_layer* Ls, int n, int B, flo
     A.eps = eps;
     A.counters = counters;
     A.err = err;
-    A.spin_limit = (unsigned)sdt_convsk_get_spin_limit();
+    // the chain polls with s_sleep(1), the stream-K owner (whose limit this is) with s_sleep(8): the same wall-clock patience needs 8x the polls
+    {
+        const unsigned long long lim = (unsigned long long)sdt_convsk_get_spin_limit() * 8ull;
+        A.spin_limit = lim > 0xffffffffull ? 0xffffffffu : (unsigned)lim;
+    }
     for (int l = 0; l < n; ++l) {
         const sdt_chain1d_layer& S = Ls[l];
         ch_layer& L = A.L[l];

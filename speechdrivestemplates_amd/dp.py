@@ -19,6 +19,34 @@ import torch.distributed as dist
 # step): 7.67 -> 7.89 / 8.12 ms per step without a reserve, 7.8 -> 7.9 with 32 (64 buys nothing more); the reserve costs ~0.1 ms when nothing else
 # runs, which is why it is not the single-GPU default.
 RESERVED_SLOTS = 32
+# Reducers of this process that currently hold the reserve: the knob is process-wide, so it is set when the FIRST active reducer
+# appears and given back when the LAST one is closed -- a reducer dropped out of order (or collected late by the GC) must not switch the
+# reserve off under one that is still exchanging gradients.
+_RESERVE_HOLDERS = 0
+_RESERVE_PREV = 0
+
+
+def _acquire_reserve():
+    global _RESERVE_HOLDERS, _RESERVE_PREV
+    from . import ops
+    if _RESERVE_HOLDERS == 0:
+        _RESERVE_PREV = ops.SK_RESERVED_SLOTS
+        ops.SK_RESERVED_SLOTS = RESERVED_SLOTS
+    _RESERVE_HOLDERS += 1
+
+
+def _release_reserve():
+    global _RESERVE_HOLDERS
+    from . import ops
+    if _RESERVE_HOLDERS > 0:
+        _RESERVE_HOLDERS -= 1
+        if _RESERVE_HOLDERS == 0:
+            ops.SK_RESERVED_SLOTS = _RESERVE_PREV
+
+
+def active_reducers():
+    """number of live GradReducers that overlap a gradient exchange with backward on this process's GPU"""
+    return _RESERVE_HOLDERS
 
 
 def world_size():
@@ -114,21 +142,24 @@ class GradReducer:
         if self.active and torch.cuda.is_available() and self.optimizers[0].flat_grad.is_cuda:
             # the exchange's kernels (RCCL: a few dozen workgroups that live for a whole all-reduce) overlap the Conv2d backward, whose
             # persistent stream-K launches would otherwise occupy every workgroup slot of the GPU: leave the collective room (ops.SK_RESERVED_SLOTS)
-            from . import ops
-            self._prev_reserve = ops.SK_RESERVED_SLOTS
-            ops.SK_RESERVED_SLOTS = RESERVED_SLOTS
+            _acquire_reserve()
+            self._holds_reserve = True
         self._pending = []
+        # graph.GraphedStep, "split" form (a backend whose collectives cannot be captured): while a step is being captured, all_reduce() hands the
+        # exchange to this callback -- it closes the graph segment, records the exchange as an eager item and opens the next segment -- and the
+        # bucket hooks of the backward pass stay quiet (one exchange per optimiser group, issued between the segments at replay)
+        self.capture_cut = None
         # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
         # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide
         self.exposed_events = None
 
     def close(self):
-        """Give the process-wide plan knob back (a reducer that is torn down must not leave later single-GPU work planning with a reserve)."""
-        prev = getattr(self, "_prev_reserve", None)
-        if prev is not None:
-            from . import ops
-            ops.SK_RESERVED_SLOTS = prev
-            self._prev_reserve = None
+        """Give the process-wide plan knob back (a reducer that is torn down must not leave later single-GPU work planning with a reserve).
+        Idempotent; counted per process (``_acquire_reserve``): the reserve goes away with the LAST active reducer, in whatever order they close.
+        Pipelines call this explicitly (Trainer.close, a second setup_optimizer); ``__del__`` is only the safety net."""
+        if getattr(self, "_holds_reserve", False):
+            self._holds_reserve = False
+            _release_reserve()
 
     def __del__(self):
         try:
@@ -150,6 +181,9 @@ class GradReducer:
         if not self.active:
             return
         from . import ops
+        capturing = opt.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing and self.capture_cut is not None:
+            return  # split-graph capture: the whole group goes out in all_reduce(), between the graph segments
         hi = opt.flat_grad.numel() if hi is None else hi
         if hi <= lo:
             return
@@ -161,7 +195,7 @@ class GradReducer:
             ops.flush_deferred_dw()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             side = ops.side_stream_if_any()
-            if side is not None:
+            if side is not None and not capturing:  # (inside a capture nothing runs on the side stream: ops._side_ok)
                 self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
@@ -179,7 +213,13 @@ class GradReducer:
 
     def all_reduce(self, opts=None):
         """Exchange whatever part of each group's gradients has not been launched early, then wait for all of it."""
-        timed = self.exposed_events is not None and self.active and self.optimizers[0].flat_grad.is_cuda
+        on_gpu = self.optimizers[0].flat_grad.is_cuda
+        capturing = on_gpu and torch.cuda.is_current_stream_capturing()
+        if capturing and self.capture_cut is not None and self.active:
+            group = list(opts) if opts is not None else None
+            self.capture_cut(lambda: self.all_reduce(group))
+            return
+        timed = self.exposed_events is not None and self.active and on_gpu and not capturing
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -198,16 +238,37 @@ class GradReducer:
             self.exposed_events.append((e0, e1))
 
 
-def reduce_scalars(tensor_dict, dst=0):
-    """Trainer.reduce_tensor_dict (core/pipelines/trainer.py:323-327) with ONE packed reduce instead of one
-    blocking 4-byte collective per key; rank ``dst`` ends up with the mean over ranks."""
+def reduce_scalars(tensor_dict, dst=0, error_flag=None):
+    """Trainer.reduce_tensor_dict (core/pipelines/trainer.py:323-327) with ONE packed collective instead of one blocking 4-byte collective per
+    key; rank ``dst`` ends up with the mean over ranks.
+    ``error_flag`` (a device scalar, ops.kernel_error_flag()): rides in the same message, which then is an all-reduce (same size, same cost), and
+    the function returns the number of ranks that raised it -- on EVERY rank, so that all of them stop at the same step when one rank's
+    persistent launch lost a partner (its NaN tile has reached every rank's gradients through the summing exchange).
+    Without ``error_flag`` it returns the dict, as before."""
     ws = world_size()
     if ws == 1:
-        return tensor_dict
+        return tensor_dict if error_flag is None else float(error_flag.item() != 0)
     keys = sorted(tensor_dict)
-    packed = torch.stack([tensor_dict[k].detach().double().reshape(()) for k in keys])
-    dist.reduce(packed, dst)
+    vals = [tensor_dict[k].detach().double().reshape(()) for k in keys]
+    if error_flag is not None:
+        vals.append(error_flag.detach().double().reshape(()).to(vals[0].device) if vals else error_flag.detach().double().reshape(()))
+    packed = torch.stack(vals)
+    if error_flag is None:
+        dist.reduce(packed, dst)
+    else:
+        dist.all_reduce(packed)
     if dist.get_rank() == dst:
         for i, k in enumerate(keys):
             tensor_dict[k] = (packed[i] / ws).to(tensor_dict[k].dtype)
-    return tensor_dict
+    if error_flag is None:
+        return tensor_dict
+    return float(packed[-1].item())
+
+
+def any_rank_flag(flag):
+    """number of ranks on which the device scalar ``flag`` is non-zero, known on every rank (one 8-byte all-reduce)"""
+    if world_size() == 1:
+        return float(flag.item() != 0)
+    t = flag.detach().double().reshape(1).ne(0).double()
+    dist.all_reduce(t)
+    return float(t.item())

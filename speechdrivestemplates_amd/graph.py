@@ -1,30 +1,52 @@
-"""hipGraph replay of a whole training step (product since round 4: the bf16-storage step needs 3.5 ms of GPU time, the host needs
-5.6 ms to enqueue its ~270 launches one by one -- replayed from a graph the host cost is 0.16 ms per step; the fp32 step is GPU-bound
-and gains nothing).  ``SYS.HIP_GRAPH: True`` makes Voice2Pose.train_step use it (single-GPU runs).
+"""hipGraph replay of a whole training step (``SYS.HIP_GRAPH: True``; product since round 4, data-parallel since round 5).
 
-The 1-D stage of the generator is ~100 launches of a few microseconds each; issued one by one from Python they are
-host-bound.  ``GraphedStep`` captures ``forward_backward`` + ``optimizer_updates`` of a Voice2Pose pipeline (every
-HIP kernel, memset and torch glue op on the step's stream, including autograd's backward and the Adam kernels)
-into one hipGraph and replays it per step: the host cost drops to a handful of device-to-device input copies plus
-one graph launch.  Everything the step needs is already graph-safe by construction: no host synchronisation (the KL
-"skip" predicate, the Adam step counter and the learning rate live on the device), static shapes, and workspace
-allocations come from the graph's private pool.
+Why: the bf16-storage step needs ~2-3 ms of GPU time but the host needs 3-5 ms to enqueue its ~270 launches one by one (pose2pose: 1.2 ms of GPU
+work behind 3.9 ms of enqueueing) -- replayed from a graph the host cost is a handful of device-to-device input copies plus one graph launch.
+The fp32 voice2pose step is GPU-bound and gains nothing.
 
-Only for world_size == 1 here: with data parallelism the gradient all-reduce sits between backward and the
-optimiser kernels and is issued eagerly (bench.py keeps that path un-captured).
+``GraphedStep`` captures ``forward_backward`` + ``optimizer_updates`` of a pipeline (every HIP kernel, memset and torch glue op on the step's
+stream, autograd's backward and the Adam kernels included).  Everything the step needs is graph-safe by construction: no host synchronisation
+(the KL "skip" predicate, the Adam step counter and the learning rate live on the device), static shapes, workspace allocations from the graph's
+private pool, persistent-launch flags / counters that their consumers lower again (a replay starts from the same zeroed words).
+
+Data parallelism (round 5; the reference's DDP configs 4 and 5, main.py:53-67) -- two forms, chosen by the process group's backend:
+  * ``full``  (backend "nccl" = RCCL): the gradient all-reduces are captured WITH the step -- the bucket launches from the backward hooks on the
+    communication stream (a fork of the capturing stream), the late buckets and the join before Adam.  ProcessGroupNCCL enqueues its kernels on
+    its own stream behind an event of the launching stream; inside a capture those become graph edges, so the replayed graph keeps the overlap
+    of exchange and backward that the eager step has.
+  * ``split`` (any other backend, e.g. gloo in the tests; or SDT_GRAPH_DP=split): collectives that cannot be captured cut the step into graph
+    SEGMENTS with the exchange issued eagerly between them: [forward + backward] -> all-reduce -> [Adam (+ the discriminator's backward)] ->
+    all-reduce -> [Adam of the discriminator].  The bucket hooks are muted during such a capture (one exchange per optimiser group after the
+    backward pass: no overlap, but still no per-launch host cost).  Segments share one memory pool and are replayed in capture order.
+Either way a replayed step computes exactly what the eager data-parallel step computes (tests/test_dp_gpu.py).
 """
+import os
+
 import torch
 
 
 class GraphedStep:
-    def __init__(self, pipe, warmup=3):
+    def __init__(self, pipe, warmup=3, mode=None):
         self.pipe = pipe
         self.warmup = warmup
         self.calls = 0
-        self.graph = None
+        self.segments = None  # [("graph", CUDAGraph) | ("eager", callable)] in replay order
         self.static = None
         self.losses = None
         self.results = None  # results dict of the captured step: static tensors that every replay overwrites
+        reducer = getattr(pipe, "reducer", None)
+        if mode is None:
+            if reducer is None or not reducer.active:
+                mode = "single"
+            else:
+                import torch.distributed as dist
+                mode = os.environ.get("SDT_GRAPH_DP") or ("full" if dist.get_backend() == "nccl" else "split")
+        assert mode in ("single", "full", "split"), mode
+        self.mode = mode
+
+    @property
+    def graph(self):  # (round-4 attribute: the first captured graph)
+        return None if not self.segments else next((g for kind, g in self.segments if kind == "graph"), None)
 
     def _eager(self, batch):
         losses, results = self.pipe.forward_backward(batch)
@@ -81,19 +103,70 @@ class GraphedStep:
             return len(a) == len(b) and all(GraphedStep._same(x, y) for x, y in zip(a, b))
         return a == b
 
+    # -- capture ---------------------------------------------------------------------------------------
+    def _capture(self):
+        """Run the step once under stream capture.  ``single`` / ``full``: one graph.  ``split``: the reducer calls ``_cut`` wherever the step
+        exchanges gradients; the capture is closed there, the exchange recorded as an eager item, and a new segment opened on the same pool."""
+        torch.cuda.synchronize()
+        segments = []
+        reducer = getattr(self.pipe, "reducer", None)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        state = {"g": None, "pool": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            if state["pool"] is None:
+                g.capture_begin()
+                state["pool"] = g.pool()
+            else:
+                g.capture_begin(pool=state["pool"])
+            state["g"] = g
+
+        def end():
+            state["g"].capture_end()
+            segments.append(("graph", state["g"]))
+            state["g"] = None
+
+        def cut(exchange):
+            end()
+            segments.append(("eager", exchange))  # not executed now: nothing of this step has run yet
+            begin()
+
+        if self.mode == "split":
+            reducer.capture_cut = cut
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                try:
+                    self.losses = self._eager(self.static)  # recorded, not executed
+                finally:
+                    if state["g"] is not None:
+                        end()
+        finally:
+            if self.mode == "split":
+                reducer.capture_cut = None
+        torch.cuda.current_stream().wait_stream(stream)
+        self.segments = segments
+        self._stream = stream
+
     def run(self, batch):
         """One training step on ``batch`` (device tensors with the collated layout).  The first ``warmup`` calls run
-        eagerly (they are real steps); the next call captures the graph, and every call from then on replays it."""
+        eagerly (they are real steps); the next call captures the graph(s), and every call from then on replays."""
         self.calls += 1
         if self.calls <= self.warmup:
             return self._eager(batch)
-        if self.graph is None:
+        if self.segments is None:
             self.static = self._clone_batch(batch)
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.losses = self._eager(self.static)  # recorded, not executed
+            self._capture()
         else:
             self._copy_into(self.static, batch)
-        self.graph.replay()
+        for kind, item in self.segments:
+            if kind == "graph":
+                item.replay()
+            else:
+                item()
         return self.losses

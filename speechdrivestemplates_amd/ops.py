@@ -412,7 +412,9 @@ _SK_WS = {}          # (device index, raw stream) -> workspace tensor
 
 # Storage of the Conv2d chain's activations (and of the conv operands' weight copies) in HBM: 'f32' (default: the reference's arithmetic, what
 # the metric is quoted on) or 'bf16' (BASELINE config 4): the first block writes a bf16 tensor and every kernel up to the resize reads / writes
-# bf16 -- products on v_mfma_f32_32x32x16_bf16, fp32 accumulation / statistics / master weights / gradients.  The 1-D stage stays exact fp32.
+# bf16 -- products on v_mfma_f32_32x32x16_bf16, fp32 accumulation / statistics / master weights / gradients.  The 1-D stage keeps fp32 TENSORS;
+# its forward / input-gradient products follow the storage mode unless CHAIN_MATH pins them (bf16 storage -> products of bf16-rounded operands
+# in the chain launches, like the Conv2d chain; its weight gradients, the head, the losses and the optimiser are exact fp32 either way).
 STORAGE = "f32"
 
 
@@ -422,6 +424,22 @@ def set_storage(mode):
     assert mode in ("f32", "bf16"), mode
     prev, STORAGE = STORAGE, mode
     return prev
+
+
+def apply_knobs(knobs):
+    """The process-wide mode switches a PIPELINE owns (``Trainer.knobs``: {'storage', 'chain1d'} from its cfg.SYS), applied at the start of every
+    step it runs: two pipelines with different configurations in one process (train in bf16 storage and validate another model in fp32; the
+    reference's voice2pose + pose2pose tools) no longer inherit each other's settings (VERDICT r4 weak 14 / ADVICE r4).  Not allowed to change
+    under a hipGraph capture (the captured launches were chosen under the knobs in force)."""
+    global STORAGE, CHAIN1D
+    if not knobs:
+        return
+    st, ch = knobs.get("storage", STORAGE), bool(knobs.get("chain1d", CHAIN1D))
+    if st != STORAGE or ch != CHAIN1D:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a pipeline's storage / chain mode cannot change inside a hipGraph capture")
+        set_storage(st)
+        CHAIN1D = ch
 
 
 def _dt(t):
@@ -547,6 +565,18 @@ def streamk_error_codes():
         if code:
             out[(dev, "chain1d")] = code
     return out
+
+
+def kernel_error_flag(dev=None):
+    """Device-side float64 scalar (no host synchronisation): 1.0 when any error word of this process's persistent-launch workspaces on ``dev`` is
+    non-zero.  dp.reduce_scalars / Trainer.check_kernels_all_ranks carry it through a collective so that EVERY rank learns that SOME rank lost a
+    partner workgroup (the summing all-reduce has spread that rank's NaN gradients to all of them)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
+    words = [ws[_SK_ERR_WORD] for (d, _st), ws in _SK_WS.items() if d == dev.index]
+    words += [ws[_CHAIN_ERR] for d, ws in _CHAIN_WS.items() if d == dev.index]
+    if not words:
+        return torch.zeros((), device=dev, dtype=torch.float64)
+    return torch.stack(words).ne(0).any().to(torch.float64)
 
 
 def check_streamk():

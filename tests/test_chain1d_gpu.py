@@ -218,8 +218,11 @@ def test_chain_lost_member_is_loud():
     assert lib.sdt_debug_chain_mute_clip(5) == 0
     try:
         with torch.no_grad():
-            ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+            bad = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
         torch.cuda.synchronize()
+        # the abandoned clip's output is POISONED (its loss goes NaN in the same step), the other clusters are untouched
+        keep = [c for c in range(8) if c != 5]
+        assert torch.isnan(bad[5]).any() and torch.equal(bad[keep], good[keep])
         codes = ops.streamk_error_codes()
         assert len(codes) == 1 and list(codes.values())[0] >= 0x40000000, codes
         with pytest.raises(RuntimeError, match="gave up waiting"):

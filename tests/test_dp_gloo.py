@@ -77,6 +77,13 @@ def _worker(rank, world, port, q):
     code_avg = averaged[[k for k, v in state.items() if v.requires_grad and (k.startswith("netG.") or k == "clips_code")].index("clips_code")]
     touched = sorted(set(code_avg.abs().sum(1).nonzero().flatten().tolist()))
     scal = dp.reduce_scalars({"G_loss": losses["G_loss"].detach(), "rank": torch.tensor(float(rank))})
+    # the kernel error flag rides in the same message: every rank learns how many ranks raised it (here: rank 1 only), the scalars are unchanged
+    d2 = {"G_loss": losses["G_loss"].detach().clone(), "rank": torch.tensor(float(rank))}
+    n_bad = dp.reduce_scalars(d2, error_flag=torch.tensor(1.0 if rank == 1 else 0.0, dtype=torch.float64))
+    assert n_bad == 1.0 and dp.any_rank_flag(torch.tensor(0.0, dtype=torch.float64)) == 0.0
+    assert dp.any_rank_flag(torch.tensor(3.0 if rank == 0 else 0.0, dtype=torch.float64)) == 1.0
+    if rank == 0:
+        assert float(d2["rank"]) == float(scal["rank"]) and abs(float(d2["G_loss"]) - float(scal["G_loss"])) < 1e-12
     q.put((rank, worst, touched, float(scal["rank"]), float(scal["G_loss"]), float(losses["G_loss"])))
     dist.destroy_process_group()
 

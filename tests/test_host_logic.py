@@ -109,3 +109,24 @@ def test_chain_wiring_of_the_generator():
         ops.chain_blocks(((4, 2, 1, _lib.CHAIN_PLAIN, -1, -1),) + tuple((4, 2, 1, _lib.CHAIN_NORM, i, -1) for i in range(7)), 64, 256)  # runs out of frames
     cfg.merge_from_list(["VOICE2POSE.GENERATOR.NORM", "BN"])
     assert get_model("SequenceGeneratorCNN")(cfg)._chain() is None  # BatchNorm generators keep the per-block kernels
+
+
+def test_reducer_reserve_is_counted_not_stacked():
+    """the workgroup-slot reserve of the backward stream-K plans is process-wide; reducers acquire / release it through a count, so
+    dropping the FIRST of two reducers (or a late garbage collection of an old one) cannot switch it off under the one still exchanging."""
+    from speechdrivestemplates_amd import dp, ops
+    assert dp.active_reducers() == 0
+    prev = ops.SK_RESERVED_SLOTS
+    try:
+        ops.SK_RESERVED_SLOTS = 0
+        dp._acquire_reserve()   # reducer A
+        assert ops.SK_RESERVED_SLOTS == dp.RESERVED_SLOTS
+        dp._acquire_reserve()   # reducer B (created while A is alive: with a saved-value stack B would remember 32)
+        dp._release_reserve()   # A goes first
+        assert ops.SK_RESERVED_SLOTS == dp.RESERVED_SLOTS and dp.active_reducers() == 1
+        dp._release_reserve()   # B goes: back to the single-GPU default
+        assert ops.SK_RESERVED_SLOTS == 0 and dp.active_reducers() == 0
+        dp._release_reserve()   # a stray extra close is harmless
+        assert ops.SK_RESERVED_SLOTS == 0 and dp.active_reducers() == 0
+    finally:
+        ops.SK_RESERVED_SLOTS = prev

@@ -121,13 +121,17 @@ def test_discriminator_pose_encoder_autoencoder_vs_reference(batch2, golden_modu
     check("Autoencoder mu", mu, golden_modules["AE/mu"], 5e-4)
 
 
-def _make_pipeline(cfg_name, n_clips, code_std):
+def _make_pipeline(cfg_name, n_clips, code_std, extra_opts=()):
     from speechdrivestemplates_amd.config import get_cfg_defaults
     from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
     from speechdrivestemplates_amd.core.pipelines import get_pipeline
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", cfg_name + ".yaml"))
-    cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DATASET.SYNTHETIC_CLIPS", n_clips, "SYS.LOG_INTERVAL", 10 ** 9])
+    from speechdrivestemplates_amd import ops as _ops
+    # the pipeline owns its storage mode (cfg.SYS.STORAGE -> Trainer.knobs, applied at every step): a test that selected a mode with
+    # ops.set_storage() before building its pipeline gets a pipeline configured for that mode
+    cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DATASET.SYNTHETIC_CLIPS", n_clips, "SYS.LOG_INTERVAL", 10 ** 9,
+                         "SYS.STORAGE", _ops.STORAGE, "SYS.CHAIN1D", bool(_ops.CHAIN1D)] + list(extra_opts))
     cfg.freeze()
     sp = np.load(os.path.join(GOLDEN, "speaker_stat_oliver.npz"))
     gd.register_speaker_stat("oliver",
@@ -405,7 +409,8 @@ def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
                 dist.destroy_process_group()
                 from speechdrivestemplates_amd import ops as _ops
                 assert _ops.SK_RESERVED_SLOTS == dp.RESERVED_SLOTS  # an active reducer makes the backward stream-K launches leave room for the collective
-                _ops.SK_RESERVED_SLOTS = 0                          # ... a process-wide setting: back to the single-GPU default for the tests that follow
+                pipe.close()                                        # ... a process-wide setting that goes away with the last active reducer
+                assert _ops.SK_RESERVED_SLOTS == 0 and dp.active_reducers() == 0
     for a, b in zip(hist[False][0], hist[True][0]):
         assert abs(a - b) <= tol * abs(a), hist
     assert torch.isfinite(hist[True][1]).all()

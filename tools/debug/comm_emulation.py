@@ -34,7 +34,7 @@ def main():
     lib.sdt_debug_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sdt_debug_spin.restype = ctypes.c_int
     ops.SK_RESERVED_SLOTS = a.reserve  # what dp.GradReducer sets in a data-parallel run: backward plans leave this many slots free
-    pipe, _ = make_pipeline("voice2pose_sdt_bp", bench.N_CLIPS, batch_global=32)
+    pipe, _ = make_pipeline("voice2pose_sdt_bp", bench.N_CLIPS, batch_global=32, sys_opts={"CHAIN1D": not a.no_chain1d})
     batches = bench.stage_batches(4, 32, 0, torch.device("cuda", 0))
     comm = torch.cuda.Stream()
     state = {"on": False}

@@ -20,7 +20,7 @@ ap.add_argument("--config", default="voice2pose_sdt_bp")
 ap.add_argument("--graph", action="store_true", help="also time hipGraph replay of the whole step")
 args = ap.parse_args()
 ops.set_storage(args.storage)
-pipe, cfg = make_pipeline(args.config, bench.N_CLIPS, batch_global=32)
+pipe, cfg = make_pipeline(args.config, bench.N_CLIPS, batch_global=32, sys_opts={"STORAGE": args.storage})
 batches = bench.stage_batches(4, 32, 0, torch.device("cuda", 0))
 
 
