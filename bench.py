@@ -223,6 +223,8 @@ def main(argv=None):
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
     ap.add_argument("--streamk-min-cout", type=int, default=None, help="experiment: GEMM width from which an input-gradient launch takes the stream-K kernel")
     ap.add_argument("--no-small1d", action="store_true", help="tuning library only (SDT_HIP_LIB): 1-D launches on conv_taps_kernel instead of conv1d_small_kernel (A/B)")
+    ap.add_argument("--dp-reserve", type=int, default=None, help="experiment (N > 1 / SDT_DP_FORCE): workgroup slots the backward stream-K plans leave free for the collective (default dp.RESERVED_SLOTS)")
+    ap.add_argument("--dp-no-overlap", action="store_true", help="experiment: no early bucket launches from the backward hooks -- one exchange per optimiser group after backward")
     ap.add_argument("--no-defer-dw", action="store_true", help="launch the 1-D stage's weight gradients inline (default: one batch on the side stream under the Conv2d backward)")
     args = ap.parse_args(argv)
 
@@ -297,11 +299,16 @@ def main(argv=None):
         ops.OVERLAP_AUX = not args.no_overlap_aux
         ops.set_conv_math(args.conv_math)
         ops.set_storage(args.storage)
+        if args.dp_reserve is not None:
+            from speechdrivestemplates_amd import dp as _dp
+            _dp.RESERVED_SLOTS = args.dp_reserve
         # every rank draws its own initial weights (nothing here seeds torch): setup_optimizer's dp.sync_replicas makes the
         # replicas identical, as DDP's constructor does in the reference
         pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world,
                                   sys_opts={"STORAGE": args.storage, "CHAIN1D": not args.no_chain1d, "DISTRIBUTED": world > 1 or forced_dp})
         batches = stage_batches(4, B, rank, dev)
+        if args.dp_no_overlap and getattr(pipe, "reducer", None) is not None:
+            pipe.reducer.launch_early = False
 
     def step(i):
         losses, _ = pipe.forward_backward(batches[i % len(batches)])

@@ -149,6 +149,8 @@ class GradReducer:
         # exchange to this callback -- it closes the graph segment, records the exchange as an eager item and opens the next segment -- and the
         # bucket hooks of the backward pass stay quiet (one exchange per optimiser group, issued between the segments at replay)
         self.capture_cut = None
+        self.launch_early = True  # False: the bucket hooks stay quiet, all_reduce() sends each group in one piece after backward (bench.py --dp-no-overlap)
+        self._in_all_reduce = False
         # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
         # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide
         self.exposed_events = None
@@ -184,6 +186,8 @@ class GradReducer:
         capturing = opt.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing()
         if capturing and self.capture_cut is not None:
             return  # split-graph capture: the whole group goes out in all_reduce(), between the graph segments
+        if not self.launch_early and not self._in_all_reduce:
+            return
         hi = opt.flat_grad.numel() if hi is None else hi
         if hi <= lo:
             return
@@ -223,6 +227,7 @@ class GradReducer:
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
+        self._in_all_reduce = True
         for opt in (opts if opts is not None else self.optimizers):
             early = sorted(self._launched.pop(id(opt), []))
             pos, n = 0, opt.flat_grad.numel()
@@ -231,6 +236,7 @@ class GradReducer:
                     self.launch(opt, pos, lo)
                 pos = max(pos, hi)
             self._launched.pop(id(opt), None)
+        self._in_all_reduce = False
         self.wait()
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)

@@ -112,15 +112,13 @@ class GraphedStep:
         reducer = getattr(self.pipe, "reducer", None)
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
-        state = {"g": None, "pool": None}
+        from . import ops
+        ops.prepare_capture_stream(torch.device('cuda', torch.cuda.current_device()), stream)  # error words must survive replays
+        state = {"g": None, "pool": torch.cuda.graph_pool_handle()}  # one private pool for all segments: a tensor allocated in one is read in the next
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            if state["pool"] is None:
-                g.capture_begin()
-                state["pool"] = g.pool()
-            else:
-                g.capture_begin(pool=state["pool"])
+            g.capture_begin(pool=state["pool"])
             state["g"] = g
 
         def end():

@@ -495,6 +495,10 @@ class _SKPlan:
 # data-parallel runs: a persistent launch that fills every slot cannot share the GPU with the long-lived workgroups of a collective -- they wait
 # for slots, or take them and strand the conv workgroups that find none (tools/debug/comm_emulation.py) -- and the gradient exchange overlaps backward
 SK_RESERVED_SLOTS = 0
+# ... and by FORWARD plans: 0 in every production setting (nothing is exchanged during the forward pass).  Two PROCESSES that share one GPU (the
+# 2-ranks-on-1-GPU tests) set both: two persistent grids of 512 workgroups cannot be co-resident, and owners that spin for partners the other
+# process's workgroups keep out starve each other until the spin limit poisons the tiles.
+SK_RESERVED_SLOTS_FWD = 0
 # Persistent workgroups per CU of the BACKWARD plans (fp32; experiment, bench.py --bwd-wpc): with ONE workgroup per CU (one wave per SIMD, half
 # of the register file) a weight-gradient launch on the side stream leaves room for the main stream's HBM-bound passes to run BESIDE it
 # instead of behind it.  Forward plans keep two.
@@ -520,7 +524,7 @@ def clear_plans():
 def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the stream-K plan or None when the pack does not qualify / is not
     wanted on that kernel (fp32 launches then take the 64x64 kernel of conv.hip)."""
-    reserve = 0 if forward else int(SK_RESERVED_SLOTS)
+    reserve = int(SK_RESERVED_SLOTS_FWD) if forward else int(SK_RESERVED_SLOTS)
     wpc = 2 if (forward or dtype != _lib.F32) else int(SK_WPC_DX)
     key = (_geom_key(garr), n, int(rpg), int(bwd_groups), dev.index, bool(forward), reserve, dtype,
            USE_STREAMK, STREAMK_MIN_STEPS, STREAMK_MIN_COUT, STREAMK_ALL_FORWARD, wpc)
@@ -646,6 +650,16 @@ def _sk_dw_workspace(dev, st):
     if ws is None:
         ws = _SK_DW_WS[key] = torch.empty(_lib.load().sdt_convsk_dw_workspace_bytes() // 4, device=dev, dtype=torch.float32)
     return ws
+
+
+def prepare_capture_stream(dev, stream):
+    """Workspaces of the persistent launches for ``stream`` allocated BEFORE a hipGraph capture on it starts (graph.GraphedStep): allocated inside
+    the capture they would come from the graph's private pool and their zero-fill would be a node of the graph -- every replay would wipe the
+    error word of the previous one before anybody could read it."""
+    st = int(stream.cuda_stream)
+    _sk_workspace(dev, st)
+    _sk_dw_workspace(dev, st)
+    _chain_ws(dev)
 
 
 def _sk_name(plan):

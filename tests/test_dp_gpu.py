@@ -183,7 +183,7 @@ def _case(tmp_path, tag, **kw):
         cmd += ["--" + k.replace("_", "-")] + ([] if v is True else [str(v)])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
-    info = json.loads(r.stdout.strip().splitlines()[-1])
+    info = json.loads(next(ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{")))  # (RCCL prints its library path to stdout)
     return info, dict(np.load(out))
 
 
@@ -225,6 +225,13 @@ def _run_modes(world, rank, storage, graph):
     from speechdrivestemplates_amd.graph import GraphedStep
     from test_model_gpu import _make_pipeline
     ops.set_storage(storage)
+    if world > 1:
+        # two PROCESSES on one GPU: their persistent stream-K grids (bf16 storage uses them at every size) must fit side by side -- 264 workgroup
+        # slots each instead of 512 -- or owners spinning for partners that the other process's workgroups keep out starve each other until the
+        # spin limit poisons tiles with NaN (seen: this test, before the reserve).  A production run has one process per GPU.
+        from speechdrivestemplates_amd import dp
+        dp.RESERVED_SLOTS = 248
+        ops.SK_RESERVED_SLOTS_FWD = 248
     pipe, _ = _make_pipeline(CFG, N_CLIPS, 0.0)
     dev = torch.device("cuda", 0)
     gs = GraphedStep(pipe, warmup=1) if graph else None
@@ -240,8 +247,8 @@ def _run_modes(world, rank, storage, graph):
             losses, _ = pipe.forward_backward(batch)
             pipe.optimizer_updates(losses)
         hist.append(float(losses["G_reg_loss"].detach()))
+        assert not ops.streamk_error_codes(), (step, ops.streamk_error_codes())
     torch.cuda.synchronize()
-    assert not ops.streamk_error_codes()
     sd = {k: v.detach().cpu() for k, v in pipe.model.netG.state_dict().items()}
     return sd, hist, (None if gs is None or gs.segments is None else [k for k, _ in gs.segments])
 
