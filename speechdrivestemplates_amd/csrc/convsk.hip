@@ -28,64 +28,8 @@
 
 #include <vector>
 
-#include "common.h"
+#include "convsk.h"
 
-#define SK_BK 32
-#define SK_LDP 36
-#define SK_MAXC 4
-#define SK_OOB 0x80000000u
-#define SK_CHUNK 8  // K steps per accumulation chunk (256 products)
-
-struct sk_class {
-    int Hi, Wi, Cin, Cout, ntaps, nkc;
-    int tile_begin, nmb, row_begin, mt_begin;
-    int Tw;
-    int ashift[SDT_MAX_TAPS];  // ((dy * Wi + dx) * Cin) * 4
-    int dyx[SDT_MAX_TAPS];     // (dy & 0xffff) | (dx << 16)
-    int bshift[SDT_MAX_TAPS];  // wt * Cin * 4
-};
-
-struct sk_args {
-    sk_class cls[SK_MAXC];
-    int ncls, nnb, T, G;
-    int ntmajor;            // one class only: tiles ordered n-tile major (tile = nt * nmb + mt), see plan_build
-    int S;                  // total live K steps of the launch
-    unsigned xbytes, wbytes, ybytes;
-    const int4* rowinfo;    // [rows padded to BM per class]
-    const int2* tileinfo;   // [m-tiles of all classes] {live-tap mask rotated by rot, rot}
-    const int* tilecum;     // [T + 1]
-    const int* range_tile;  // [G] first tile of each range
-    float* slabs;           // [G][BM * BN]
-    unsigned* flags;        // [G]
-    unsigned epoch;
-    unsigned* err;          // set to a non-zero code when a spin gives up
-    unsigned spin_limit;    // polls of a partner's flag before the owner declares the launch failed (sdt_convsk_set_spin_limit)
-};
-
-struct sk_norm_bwd {
-    const void* y;          // forward output of the block below, element type TX of the launch
-    const float* mean;
-    const float* rstd;
-    const float* gamma;
-    const float* beta;
-    double* sums;
-    float slope;
-    int groups;
-};
-
-typedef __attribute__((address_space(1))) unsigned gu32;
-typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 sk_bf16x2 __attribute__((ext_vector_type(2)));
-// Element type of the operands (TX: X, W and -- EPI 2 -- the forward output y of the block below) and of the output (TY): float, or
-// __bf16 for the bf16-storage path (BASELINE config 4): products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, tensors bf16 in HBM.
-// A K step is 128 BYTES of a row in both cases (32 fp32 / 64 bf16 channels), so the plan (byte offsets), the loader, the LDS tiles
-// ([row][128 B + 16 B pad]) and the 16-byte fragment reads are the same code; a fragment read feeds four fp32 MFMAs (k = 4 j' + e,
-// one product per lane) or ONE bf16 MFMA (k = 16 J + 8 (lane >> 5) + e, eight products per lane).
-template <typename T> struct sk_is_bf16 { static constexpr bool value = false; };
-template <> struct sk_is_bf16<__bf16> { static constexpr bool value = true; };
-__device__ __forceinline__ float sk_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-#define SK_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #if defined(SK_BF_ABL) && (SK_BF_ABL & 4)  // ablation (wrong results): no MFMAs in the bf16 K loop (the fragments stay live)
 #define SK_BF_MFMA(C, A, B) asm volatile("" : "+v"(C) : "v"(A), "v"(B))
 #else
@@ -261,26 +205,6 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                 }
             }
         }
-}
-
-// Scheduling hints of one bf16 K step before its barrier (sched_group_barrier wants literal counts, hence the recursion): a k-group is only
-// NM = TM * TN MFMAs of 32 cycles -- 3 NM MFMAs against 3 NF fragment reads, NL LDS stores and NL global loads.  Every MFMA of k-groups 0
-// and 1 is followed by its share of the next group's fragment reads, of one half of the stores and of the loads that re-fill the registers
-// just stored; every MFMA of k-group 2 by its share of k-group 3's reads.
-template <int G2, int Q, int NM, int NF, int NL>
-__device__ __forceinline__ void sk_bf_interleave() {
-    // the LDS stores of step s+1 and the global loads of step s+3 go with the FIRST k-group: the loads are issued as early in the step as
-    // their registers are free (a load lands two steps before it is staged: the L2 latency under load is about one bf16 step)
-    constexpr int lo = 0, hi = G2 == 0 ? NL : 0;
-    constexpr int nr = (NF + NM - 1 - Q) / NM, nw = (hi - lo + NM - 1 - Q) / NM;
-    SK_SGB(0x8, 1);
-    if constexpr (nr > 0) SK_SGB(0x100, nr);
-    if constexpr (nw > 0) {
-        SK_SGB(0x200, nw);
-        SK_SGB(0x20, nw);
-    }
-    if constexpr (Q + 1 < NM) sk_bf_interleave<G2, Q + 1, NM, NF, NL>();
-    else if constexpr (G2 + 1 < 3) sk_bf_interleave<G2 + 1, 0, NM, NF, NL>();
 }
 
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
@@ -1192,8 +1116,16 @@ static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, in
     return SK_HDR + rows * 4 + mts * 2 + (T + 1) + G + (int64_t)ncls * SK_CLS_INTS;
 }
 
-// tile and grid from the workgroups-per-CU setting
-static void plan_shape(const sdt_conv_geom& g, int& bm, int& bn, int& G) {
+// tile and grid from the workgroups-per-CU setting and the element size.  bf16 operands with ONE workgroup per CU: the bf16-shaped kernel of
+// convbf.hip -- 256-row tiles as wide as the layer (256 / 128 / 64 columns), 8 waves; a reserve of n slots leaves n / 2 of its CUs free.
+static bool is_bf2(int esz) { return esz == 2 && g_sk_wpc == 1; }
+static void plan_shape(const sdt_conv_geom& g, int esz, int& bm, int& bn, int& G) {
+    if (is_bf2(esz)) {
+        bm = 256;
+        bn = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
+        G = (256 - g_sk_reserve / 2) & ~7;
+        return;
+    }
     sk_tile_choice(g, bm, bn);
     G = 256 * g_sk_wpc - g_sk_reserve;
 }
@@ -1202,11 +1134,10 @@ static int dtype_bytes(int dtype) { return dtype == SDT_F32 ? 4 : (dtype == SDT_
 
 static int plan_supported(const sdt_conv_geom* geoms, int ncls, int esz) {
     if (!geoms || ncls < 1 || ncls > SK_MAXC || (esz != 4 && esz != 2)) return 0;
-    if (esz == 2 && g_sk_wpc != 2) return 0;  // the bf16 instantiations exist for two workgroups per CU only
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], bm, bn, G);
+    plan_shape(*gs[0], esz, bm, bn, G);
     return sk_supported(gs, ncls, bm, bn, esz) ? 1 : 0;
 }
 extern "C" int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls) { return plan_supported(geoms, ncls, 4); }
@@ -1220,7 +1151,7 @@ static int64_t plan_bytes(const sdt_conv_geom* geoms, int ncls, int esz) {
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], bm, bn, G);
+    plan_shape(*gs[0], esz, bm, bn, G);
     return sk_plan_ints(gs, ncls, bm, bn, G) * 4;
 }
 extern "C" int64_t sdt_convsk_plan_bytes(const sdt_conv_geom* geoms, int ncls) { return plan_bytes(geoms, ncls, 4); }
@@ -1228,7 +1159,9 @@ extern "C" int64_t sdt_convsk_plan_bytes_t(const sdt_conv_geom* geoms, int ncls,
 
 // workspace of a launch: slabs + flags + error word (bytes); the caller zero-fills it ONCE after allocation and hands the same
 // buffer to every launch of one stream with a strictly increasing epoch (>= 1)
-extern "C" int64_t sdt_convsk_workspace_bytes(void) { return (int64_t)512 * (128 * 128) * 4 + (int64_t)512 * 4 + 64; }
+// (slabs: 512 ranges x 128 x 128 fp32 or 256 ranges x 256 x 256 fp32 -- the bf16-shaped kernel's tiles)
+#define SK_SLAB_BYTES ((int64_t)256 * 256 * 256 * 4)
+extern "C" int64_t sdt_convsk_workspace_bytes(void) { return SK_SLAB_BYTES + (int64_t)512 * 4 + 64; }
 
 // Builds the plan into host memory `out` (sdt_convsk_plan_bytes bytes); the caller copies it to the device once per geometry.
 // rows_per_group > 0: statistics group of row m of class c = m / rows_per_group (forward statistics) -- for an input gradient with
@@ -1263,7 +1196,7 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     const sdt_conv_geom* gs[SK_MAXC];
     for (int c = 0; c < ncls; ++c) gs[c] = geoms + c;
     int bm, bn, G;
-    plan_shape(*gs[0], bm, bn, G);
+    plan_shape(*gs[0], esz, bm, bn, G);
     int* P = (int*)out;
     const int nnb = gs[0]->Cout / bn;
     int64_t rows = 0, mts = 0;
@@ -1430,7 +1363,9 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     // every range needs at least one step (an empty range between a tile's owner and its last contributor would be waited for and never
     // publish); fp32 launches below 4 steps per range go to the 64x64 kernel of conv.hip (faster there, and the B = 4 fixtures keep their
     // recorded LeakyReLU decisions), bf16 launches have no other kernel and take the persistent one down to one step per range
-    SDT_CHECK_ARG(S >= (esz == 2 ? 1 : 4) * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
+    // (the bf16-shaped kernel asks for 4 steps per range as well: below that the launch is latency-bound and the round-4 128-row kernel, whose
+    // plan the caller builds next, cuts it into twice as many ranges)
+    SDT_CHECK_ARG(S >= ((esz == 2 && !is_bf2(esz)) ? 1 : 4) * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
     SDT_CHECK_ARG(T < (1ll << 30), "too many tiles");
     // first tile of every range: the tile that contains step floor(r * S / G)
     int64_t tile = 0;
@@ -1489,7 +1424,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
     A.xbytes = (unsigned)xbytes, A.wbytes = (unsigned)wbytes, A.ybytes = (unsigned)ybytes;
     char* ws = (char*)workspace;
     A.slabs = (float*)ws;
-    A.flags = ws ? (unsigned*)(ws + (size_t)512 * (128 * 128) * 4) : nullptr;
+    A.flags = ws ? (unsigned*)(ws + (size_t)SK_SLAB_BYTES) : nullptr;
     A.err = ws ? A.flags + 512 : nullptr;
     A.epoch = epoch;
     A.spin_limit = g_sk_spin_limit;
@@ -1542,7 +1477,10 @@ static int sk_go(const void* x, const void* w, const float* bias, void* y, const
         else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(float, float, 128, 64, 2);
         else SDT_CHECK_ARG(false, "plan with an unknown tile shape");
     } else if (xbf && ybf) {
-        if (bm == 128 && bn == 128 && wpc == 2) SK_GO(__bf16, __bf16, 128, 128, 2);
+        if (bm == 256 && wpc == 1) {
+            rc = convbf2_launch(x, w, bias, y, A, stats, nb, bn, epi, s);
+            SDT_CHECK_ARG(rc == SDT_OK, "plan with a tile shape the bf16-shaped kernel is not built for");
+        } else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(__bf16, __bf16, 128, 128, 2);
         else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(__bf16, __bf16, 128, 64, 2);
         else SDT_CHECK_ARG(false, "plan with a tile shape the bf16 kernels are not built for");
     } else {

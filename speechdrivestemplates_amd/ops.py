@@ -521,11 +521,19 @@ def clear_plans():
     _SK_DW_PLANS.clear()
 
 
-def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0):
+BF16_SHAPED = True  # bf16 tensors: the 256-row / 8-wave kernel of csrc/convbf.hip (one workgroup per CU) wherever a launch has >= 4 K steps per range
+
+
+def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0, wpc=None):
     """garr: a ConvGeom (n == 1) or a ctypes array of n ConvGeoms; returns the stream-K plan or None when the pack does not qualify / is not
     wanted on that kernel (fp32 launches then take the 64x64 kernel of conv.hip)."""
     reserve = int(SK_RESERVED_SLOTS_FWD) if forward else int(SK_RESERVED_SLOTS)
-    wpc = 2 if (forward or dtype != _lib.F32) else int(SK_WPC_DX)
+    if dtype == _lib.BF16 and wpc is None:
+        # the bf16-shaped kernel first (plans with one workgroup per CU); small launches fall back to the round-4 128-row kernel (two per CU)
+        plan = _sk_plan(garr, n, rpg, bwd_groups, dev, forward, dtype, 1) if BF16_SHAPED else None
+        return plan if plan is not None else _sk_plan(garr, n, rpg, bwd_groups, dev, forward, dtype, 2)
+    if wpc is None:
+        wpc = 2 if forward else int(SK_WPC_DX)
     key = (_geom_key(garr), n, int(rpg), int(bwd_groups), dev.index, bool(forward), reserve, dtype,
            USE_STREAMK, STREAMK_MIN_STEPS, STREAMK_MIN_COUT, STREAMK_ALL_FORWARD, wpc)
     plan = _SK_PLANS.get(key, False)
@@ -553,7 +561,7 @@ def _sk_workspace(dev, st):
     return ws
 
 
-_SK_ERR_WORD = 512 * 128 * 128 + 512
+_SK_ERR_WORD = 256 * 256 * 256 + 512  # int32 index of the error word: behind the slabs (csrc/convsk.hip SK_SLAB_BYTES) and the 512 flags
 
 
 def streamk_error_codes():
@@ -663,6 +671,8 @@ def prepare_capture_stream(dev, stream):
 
 
 def _sk_name(plan):
+    if plan.host[1] == 256 and plan.dtype == _lib.BF16:
+        return "convbf2_kernel<%d>" % plan.host[2]
     return "convsk_kernel<%d, %d>" % (plan.host[1], plan.host[2])
 
 def _splitk_hint(lib, g):

@@ -16,16 +16,30 @@ LAYERS = [("L1", 80, 427, 64, 64, 4, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 3, 1,
 
 
 def timed(fn, rep):
+    """mean GPU time of one call: REP calls captured into a hipGraph and replayed (enqueued from Python a call costs the host ~100 us, more than
+    the kernels take), HIP events around the replays"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    ops.prepare_capture_stream(torch.device("cuda", 0), st)
+    with torch.cuda.stream(st):
+        g.capture_begin()
+        for _ in range(rep):
+            fn()
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(st)
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(rep):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / rep
+    return e0.elapsed_time(e1) * 1e3 / (3 * rep)
 
 
 def main():
@@ -34,8 +48,11 @@ def main():
     ap.add_argument("--rep", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-dw", action="store_true", help="skip the weight-gradient launches")
+    ap.add_argument("--old", action="store_true", help="the round-4 128-row bf16 kernels (ops.BF16_SHAPED = False) instead of the bf16-shaped ones")
     a = ap.parse_args()
     B, dev = a.batch, "cuda"
+    ops.BF16_SHAPED = not a.old
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tot = {"fwd": 0.0, "dX": 0.0, "dW": 0.0}
     print("%-4s %10s | %8s %8s | %8s %8s | %8s %8s   (us, TFLOP/s; %s tensors, B=%d)" % ("", "GFLOP", "fwd", "", "dX", "", "dW", "", a.dtype, B))
@@ -64,13 +81,13 @@ def main():
 
         def f_dw():
             ops.conv_weight_grad(x, gy, w, s, p)
-        t = {"fwd": timed(f_fwd, a.rep), "dX": timed(f_dx, a.rep), "dW": timed(f_dw, a.rep)}
+        t = {"fwd": timed(f_fwd, a.rep), "dX": timed(f_dx, a.rep), "dW": 1e-9 if a.no_dw else timed(f_dw, a.rep)}
         for k in tot:
             tot[k] += t[k]
         print("%-4s %10.2f | %8.1f %8.1f | %8.1f %8.1f | %8.1f %8.1f" % (tag, gflop, t["fwd"], gflop / t["fwd"] * 1e3, t["dX"], gflop / t["dX"] * 1e3,
                                                                   t["dW"], gflop / t["dW"] * 1e3))
     print("sum  fwd %.0f us  dX %.0f us  dW %.0f us  = %.3f ms" % (tot["fwd"], tot["dX"], tot["dW"], sum(tot.values()) / 1e3))
-    assert not ops.streamk_error_codes()
+    assert os.environ.get("SDT_ALLOW_NAN") or not ops.streamk_error_codes()
 
 
 if __name__ == "__main__":

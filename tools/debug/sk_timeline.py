@@ -24,11 +24,16 @@ def main():
     ap.add_argument("--roles", default="fwd,dX")
     ap.add_argument("--wpc", type=int, default=2)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: the bf16-storage kernels (forward with statistics, dX)")
+    ap.add_argument("--bf2", action="store_true", help="with --dtype bf16: the bf16-shaped kernel of convbf.hip (256-row tiles, one workgroup per CU) -- "
+                    "stamps: segment start, fill done, K loop done, next tile's set-up + first request issued, end phase done")
     a = ap.parse_args()
+    ops.BF16_SHAPED = bool(a.bf2)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     lib = _lib.load()
-    lib.sdt_debug_set_timeline_sk.argtypes = [ctypes.c_void_p]
-    _lib.check(lib.sdt_convsk_set_wg_per_cu(a.wpc))
+    set_tl = lib.sdt_debug_set_timeline_bf2 if a.bf2 else lib.sdt_debug_set_timeline_sk
+    set_tl.argtypes = [ctypes.c_void_p]
+    if not a.bf2:
+        _lib.check(lib.sdt_convsk_set_wg_per_cu(a.wpc))
     B = 32
     for name, Hi, Wi, Cin, Cout, kh, kw, s, p in LAYERS:
         if name not in a.only.split(",") or Hi == 1:
@@ -53,10 +58,10 @@ def main():
                 fns[role]()
             buf = torch.zeros((512 * 16, 8), dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
-            assert lib.sdt_debug_set_timeline_sk(ctypes.c_void_p(buf.data_ptr())) == 0
+            assert set_tl(ctypes.c_void_p(buf.data_ptr())) == 0
             fns[role]()
             torch.cuda.synchronize()
-            lib.sdt_debug_set_timeline_sk(ctypes.c_void_p(0))
+            set_tl(ctypes.c_void_p(0))
             tl = buf.cpu().numpy().astype(np.int64).reshape(512, 16, 8)
             np.save(os.path.join(REPO, "gpurun_out", "sk_tl_%s_%s.npy" % (name, role)), tl)
             used = tl[:, :, 0] != 0
@@ -65,8 +70,12 @@ def main():
             span = t[..., 4][used].max() - t0
             steps = tl[..., 5][used]
             kind = tl[..., 6][used]
-            ph = {"set-up": (t[..., 1] - t[..., 0])[used], "fill": (t[..., 2] - t[..., 1])[used], "K loop": (t[..., 3] - t[..., 2])[used],
-                  "end (publish / combine / epilogue)": (t[..., 4] - t[..., 3])[used]}
+            if a.bf2:
+                ph = {"fill": (t[..., 1] - t[..., 0])[used], "K loop": (t[..., 2] - t[..., 1])[used], "next tile's set-up + first request": (t[..., 3] - t[..., 2])[used],
+                      "end (publish / combine / epilogue)": (t[..., 4] - t[..., 3])[used]}
+            else:
+                ph = {"set-up": (t[..., 1] - t[..., 0])[used], "fill": (t[..., 2] - t[..., 1])[used], "K loop": (t[..., 3] - t[..., 2])[used],
+                      "end (publish / combine / epilogue)": (t[..., 4] - t[..., 3])[used]}
             nseg = used.sum(1)
             print("%s %s: span %.1f us; segments per workgroup %.1f (max %d, 16 recorded at most); K steps per segment median %d; kinds whole/owner/publish %d/%d/%d"
                   % (name, role, span, nseg[nseg > 0].mean(), nseg.max(), np.median(steps), (kind == 0).sum(), (kind == 1).sum(), (kind == 2).sum()))
@@ -78,6 +87,8 @@ def main():
                 sel = kind == kk
                 if sel.any():
                     print("    end phase of %-8s segments: median %.2f us  p90 %.2f" % (nm, np.median(ph["end (publish / combine / epilogue)"][sel]), np.percentile(ph["end (publish / combine / epilogue)"][sel], 90)))
+            first = np.array([t[i, :, 0][used[i]].min() for i in range(512) if used[i].any()]) - t0
+            print("    workgroup start times: median %.1f max %.1f us" % (np.median(first), first.max()))
             last = np.array([t[i, :, 4][used[i]].max() for i in range(512) if used[i].any()]) - t0
             print("    workgroup finish times: min %.1f median %.1f max %.1f us" % (last.min(), np.median(last), last.max()))
 
