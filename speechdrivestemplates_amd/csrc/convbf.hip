@@ -29,7 +29,7 @@
 #define BF_BM 256
 #define BF_NT 512
 // BF_ABL (tools/debug/r05_bf2_ablation.sh; ablation builds compute WRONG results by design): 1 no global loads in the K loop, 2 no LDS stores,
-// 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads
+// 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads, 32 no epilogue stores
 #ifndef BF_ABL
 #define BF_ABL 0
 #endif
@@ -54,14 +54,67 @@ extern "C" int sdt_debug_set_timeline_bf2(void* p) {
 #define BF_TL(slot, val) do { } while (0)
 #endif
 
+// Statistics of ONE 32 x 32 accumulator block (rows rb0 .. rb0 + 31 of the tile, this lane's column n): sum u and sum u * v over the block's rows with
+//   EPI 1: u = v = conv output;   EPI 2: v = yhat of the block below, u = dX * act'(yhat)   -- (s0, q0) for the rows of group `gfirst`, (s1, q1) for
+// the rows of a second group `glast` (groups ascend with the row; rows past the end of the tensor carry group -1 and come last).
+template <int EPI>
+__device__ __forceinline__ void bf2_block_stats(const f32x16& a, const float* yv, const int* sOut, const int* sGrp, const int rb0, const int lane, const float bv,
+                                                const int gfirst, const int glast, const float mu0, const float rs0, const float mu1, const float rs1,
+                                                const float ga, const float be, const float slope, float& s0, float& q0, float& s1, float& q1) {
+    if (gfirst == glast && gfirst >= 0) {  // wave-uniform fast path: one group, every row exists -- no per-element selects (the statistics were VALU-bound)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if constexpr (EPI == 1) {
+                const float u = a[q] + bv;
+                s0 += u;
+                q0 = fmaf(u, u, q0);
+            } else {
+                const float v = (yv[q] - mu0) * rs0;
+                const float u = a[q] * act_grad(v * ga + be, slope);
+                s0 += u;
+                q0 = fmaf(u, v, q0);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int4 o4 = *(const int4*)&sOut[rb0 + 8 * qq + 4 * (lane >> 5)];
+        const int4 g4 = *(const int4*)&sGrp[rb0 + 8 * qq + 4 * (lane >> 5)];
+        const int offs[4] = {o4.x, o4.y, o4.z, o4.w}, grps[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = offs[e] >= 0, second = grps[e] != gfirst;
+            float u, v;
+            if constexpr (EPI == 1) {
+                u = valid ? a[4 * qq + e] + bv : 0.f;
+                v = u;
+            } else {
+                v = (yv[4 * qq + e] - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
+                u = valid ? a[4 * qq + e] * act_grad(v * ga + be, slope) : 0.f;
+            }
+            if (!second) {
+                s0 += u;
+                q0 = fmaf(u, v, q0);
+            } else {
+                s1 += u;
+                q1 = fmaf(u, v, q1);
+            }
+        }
+    }
+}
+
 // Epilogue of accumulator rows [TMB, TME) x all TN column blocks of one wave: branch-free bf16 stores (pairs of columns as one dword, exchanged
 // between neighbouring lanes by DPP) and, EPI 1 / 2, the per-(group, channel) statistics from the fp32 accumulators.  sOut / sGrp: LDS, byte
 // offset of each tile row in Y (SK_OOB: none) and its statistics group.  row0: first tile row of the wave, ncol0: first output channel of the wave.
 template <int TM, int TN, int EPI, int TMB, int TME>
 __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* sOut, const int* sGrp, const int row0, const int ncol0, const int lane,
                                              const float* __restrict__ bias, const __amdgpu_buffer_rsrc_t rsY, const int Cout,
-                                             double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes) {
-    float yv[(TME - TMB) * TN * 16];
+                                             double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes, float* red) {
+    // red != nullptr: every row of the TILE belongs to one group -- the wave's column sums go to its LDS slice red[(tn * 32 + column) * 2 + {0, 1}]
+    // (first row-block pair: store, later ones: add) and the caller adds the waves' slices: one partial per column and TILE instead of one
+    // fp64 atomic per column and 64 rows (the atomics, not their arithmetic, were 2.4 us of a tile's end phase)
+    float yv[(TME - TMB) * TN][16];
     if constexpr (EPI == 2) {
         // the forward output y of the block below at every position of these rows: all loads before anything else (one exposed latency)
         const __amdgpu_buffer_rsrc_t rsNY = __builtin_amdgcn_make_buffer_rsrc((void*)nb.y, 0, (int)ybytes, 0x00020000);
@@ -76,18 +129,17 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
                     const int offs[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e] =
-                            sk_bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rsNY, (int)((unsigned)offs[e] + nb2), 0, 0));
+                        yv[(tm - TMB) * TN + tn][4 * qq + e] = sk_bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rsNY, (int)((unsigned)offs[e] + nb2), 0, 0));
                 }
             }
     }
+    const bool odd = lane & 1;
 #pragma unroll
     for (int tm = TMB; tm < TME; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = ncol0 + tn * 32 + (lane & 31);
             const float bv = bias != nullptr ? bias[n] : 0.f;
-            const bool odd = lane & 1;
             const unsigned nb2 = (unsigned)(n & ~1) * 2u;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
@@ -101,70 +153,95 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
                     pk[0] = (__bf16)(odd ? got : v0);
                     pk[1] = (__bf16)(odd ? v1 : got);
                     const int ro = odd ? (h ? o4.w : o4.y) : (h ? o4.z : o4.x);
+#if BF_ABL & 32  // ablation (wrong results): the epilogue's stores are not issued (the packing stays)
+                    asm volatile("" ::"v"(pk), "v"(ro));
+#else
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rsY, (int)((unsigned)ro + nb2), 0, 0);
+#endif
                 }
             }
-            if constexpr (EPI == 1 || EPI == 2) {
-                const int rb0 = row0 + tm * 32;
-                const int gfirst = sGrp[rb0], glast = sGrp[rb0 + 31];
-                const bool two = glast != gfirst && glast >= 0;
-                float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, ga = 1.f, be = 0.f;
-                if constexpr (EPI == 2) {
-                    if (gfirst >= 0) {
-                        mu0 = nb.mean[(size_t)gfirst * Cout + n];
-                        rs0 = nb.rstd[(size_t)gfirst * Cout + n];
-                    }
-                    if (two) {
-                        mu1 = nb.mean[(size_t)glast * Cout + n];
-                        rs1 = nb.rstd[(size_t)glast * Cout + n];
-                    }
-                    if (nb.gamma != nullptr) ga = nb.gamma[n];
-                    if (nb.beta != nullptr) be = nb.beta[n];
-                }
-                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        }
+    if constexpr (EPI == 1 || EPI == 2) {
+        double* acc_out = EPI == 1 ? stats : nb.sums;
+        constexpr int STEP = ((TME - TMB) % 2 == 0) ? 2 : 1;  // row blocks are taken in PAIRS: one partial sum of <= 64 rows per atomic (the fp32 kernels' bound)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int4 o4 = *(const int4*)&sOut[rb0 + 8 * qq + 4 * (lane >> 5)];
-                    const int4 g4 = *(const int4*)&sGrp[rb0 + 8 * qq + 4 * (lane >> 5)];
-                    const int offs[4] = {o4.x, o4.y, o4.z, o4.w}, grps[4] = {g4.x, g4.y, g4.z, g4.w};
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = ncol0 + tn * 32 + (lane & 31);
+            const float bv = bias != nullptr ? bias[n] : 0.f;
+            float ga = 1.f, be = 0.f;
+            if constexpr (EPI == 2) {
+                if (nb.gamma != nullptr) ga = nb.gamma[n];
+                if (nb.beta != nullptr) be = nb.beta[n];
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool valid = offs[e] >= 0, second = grps[e] != gfirst;
-                        float u, v;
-                        if constexpr (EPI == 1) {
-                            u = valid ? acc[tm][tn][4 * qq + e] + bv : 0.f;
-                            v = u;
-                        } else {
-                            const float yvv = yv[((tm - TMB) * TN + tn) * 16 + 4 * qq + e];
-                            v = (yvv - (second ? mu1 : mu0)) * (second ? rs1 : rs0);
-                            u = valid ? acc[tm][tn][4 * qq + e] * act_grad(v * ga + be, nb.slope) : 0.f;
+            for (int tm = TMB; tm < TME; tm += STEP) {
+                int gf[STEP], gl[STEP];
+                float s0[STEP], q0[STEP], s1[STEP], q1[STEP];
+#pragma unroll
+                for (int k = 0; k < STEP; ++k) {
+                    const int rb0 = row0 + (tm + k) * 32;
+                    gf[k] = sGrp[rb0], gl[k] = sGrp[rb0 + 31];
+                    const bool two = gl[k] != gf[k] && gl[k] >= 0;
+                    float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f;
+                    if constexpr (EPI == 2) {
+                        if (gf[k] >= 0) {
+                            mu0 = nb.mean[(size_t)gf[k] * Cout + n];
+                            rs0 = nb.rstd[(size_t)gf[k] * Cout + n];
                         }
-                        if (!second) {
-                            s0 += u;
-                            q0 = fmaf(u, v, q0);
-                        } else {
-                            s1 += u;
-                            q1 = fmaf(u, v, q1);
+                        if (two) {
+                            mu1 = nb.mean[(size_t)gl[k] * Cout + n];
+                            rs1 = nb.rstd[(size_t)gl[k] * Cout + n];
                         }
                     }
+                    s0[k] = q0[k] = s1[k] = q1[k] = 0.f;
+                    bf2_block_stats<EPI>(acc[tm + k][tn], yv[(tm + k - TMB) * TN + tn], sOut, sGrp, rb0, lane, bv, gf[k], gl[k], mu0, rs0, mu1, rs1, ga, be, nb.slope,
+                                         s0[k], q0[k], s1[k], q1[k]);
+                    s0[k] += __shfl_xor(s0[k], 32, 64);  // the two lane halves hold different rows of the same column
+                    q0[k] += __shfl_xor(q0[k], 32, 64);
                 }
-                s0 += __shfl_xor(s0, 32, 64);
-                q0 += __shfl_xor(q0, 32, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                q1 += __shfl_xor(q1, 32, 64);
-                double* acc_out = EPI == 1 ? stats : nb.sums;
-                if (lane < 32 && gfirst >= 0) {
-                    double* d = acc_out + ((size_t)gfirst * Cout + n) * 2;
-                    atomicAdd(d, (double)s0);
-                    atomicAdd(d + 1, (double)q0);
-                    if (two) {
-                        double* d1 = acc_out + ((size_t)glast * Cout + n) * 2;
-                        atomicAdd(d1, (double)s1);
-                        atomicAdd(d1 + 1, (double)q1);
+                // two blocks of one group: ONE partial sum (half the atomics); otherwise block by block
+                bool merged = false;
+                if constexpr (STEP == 2) merged = gf[0] == gl[0] && gf[1] == gl[1] && gf[0] == gf[1] && gf[0] >= 0;  // wave-uniform
+                if (merged && red != nullptr) {
+                    if (lane < 32) {
+                        float* d = red + (tn * 32 + lane) * 2;
+                        if (tm == 0) {
+                            d[0] = s0[0] + s0[1];
+                            d[1] = q0[0] + q0[1];
+                        } else {
+                            d[0] += s0[0] + s0[1];
+                            d[1] += q0[0] + q0[1];
+                        }
+                    }
+                } else if (merged) {
+                    if (lane < 32) {
+                        double* d = acc_out + ((size_t)gf[0] * Cout + n) * 2;
+                        atomicAdd(d, (double)(s0[0] + s0[1]));
+                        atomicAdd(d + 1, (double)(q0[0] + q0[1]));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < STEP; ++k) {
+                        const bool two = gl[k] != gf[k] && gl[k] >= 0;
+                        if (two) {
+                            s1[k] += __shfl_xor(s1[k], 32, 64);
+                            q1[k] += __shfl_xor(q1[k], 32, 64);
+                        }
+                        if (lane < 32 && gf[k] >= 0) {
+                            double* d = acc_out + ((size_t)gf[k] * Cout + n) * 2;
+                            atomicAdd(d, (double)s0[k]);
+                            atomicAdd(d + 1, (double)q0[k]);
+                            if (two) {
+                                double* d1 = acc_out + ((size_t)gl[k] * Cout + n) * 2;
+                                atomicAdd(d1, (double)s1[k]);
+                                atomicAdd(d1 + 1, (double)q1[k]);
+                            }
+                        }
                     }
                 }
             }
         }
+    }
 }
 
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
@@ -179,7 +256,8 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     float* sB = smem + 2 * BM * SK_LDP;        // [2][BN * LDP]
     int* sOutB = (int*)(sB + 2 * BN * SK_LDP);  // [2][BM] byte offset of the tile's output rows in Y (SK_OOB, negative as int: none)
     int* sGrpB = sOutB + 2 * BM;                // [2][BM] statistics group of each row (EPI 1 / 2)
-    int* sFlagOkp = sGrpB + 2 * BM;             // [4]
+    int2* sRowB = (int2*)(sGrpB + 2 * BM);      // [2][BM] {X byte offset of the row's (0,0) tap, mask of the taps outside X}: the loader's row table
+    int* sFlagOkp = (int*)(sRowB + 2 * BM);     // [4]
 #define sFlagOk (sFlagOkp[0])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,20 +278,40 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     const int fb = (col0 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
     const int wofs = r0 * SK_LDP + kv * 4;
 
-    // ---- the walk over the range's tiles
-    int tile = __builtin_amdgcn_readfirstlane(P.range_tile[r]);
-    int pos = s_begin;
-    int c = 0;
-    while (c + 1 < P.ncls && tile >= P.cls[c + 1].tile_begin) ++c;
-    int mt = (tile - P.cls[c].tile_begin) / P.nnb;
-    int nt = (tile - P.cls[c].tile_begin) - mt * P.nnb;
+    // ---- the walk over the range's tiles: cursor (tile, class c, m-tile mt, n-tile nt)
+    struct Cursor {
+        int tile, c, mt, nt;
+    };
+    Cursor cur;
+    cur.tile = __builtin_amdgcn_readfirstlane(P.range_tile[r]);
+    cur.c = 0;
+    while (cur.c + 1 < P.ncls && cur.tile >= P.cls[cur.c + 1].tile_begin) ++cur.c;
+    cur.mt = (cur.tile - P.cls[cur.c].tile_begin) / P.nnb;
+    cur.nt = (cur.tile - P.cls[cur.c].tile_begin) - cur.mt * P.nnb;
     if (P.ntmajor) {
-        nt = tile / P.cls[0].nmb;
-        mt = tile - nt * P.cls[0].nmb;
+        cur.nt = cur.tile / P.cls[0].nmb;
+        cur.mt = cur.tile - cur.nt * P.cls[0].nmb;
     }
+    auto advance = [&](Cursor k) -> Cursor {
+        ++k.tile;
+        if (P.ntmajor) {
+            if (++k.mt == P.cls[0].nmb) {
+                k.mt = 0;
+                ++k.nt;
+            }
+        } else if (++k.nt == P.nnb) {
+            k.nt = 0;
+            if (++k.mt == P.cls[k.c].nmb) {
+                k.mt = 0;
+                ++k.c;
+            }
+        }
+        return k;
+    };
+    int pos = s_begin;
 
     // ---- loader state of the tile whose operands are being fetched
-    int nkc = 1, ntaps = 1, rot = 0, kc = 0, left = 0, v_ash = 0, v_bsh = 0;
+    int nkc = 1, ntaps = 1, rot = 0, kc = 0, left = 0, v_ash = 0, v_bsh = 0, cls_loaded = -1, cls_cout = 0, cls_wrow = 0;
     unsigned rmask = 0u;
     unsigned abase[RA], inval[RA], bbase[RB];
     f32x4 ra[NSET][RA], rb[NSET][RB];
@@ -221,36 +319,60 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     struct TileFacts {
         int Cout, n0, a, b, tbeg, tend;
     };
-    auto load = [&](auto SI) {
-        constexpr int S_ = decltype(SI)::value;
+    // one K step's requests: load_prep() (wave-uniform scalars of the step at (tap, kc)), load_op(set, i) (operand row i: A rows first, then B rows),
+    // load_advance().  The K loop places the ops one by one between its MFMAs; `load` is all of them in a row (pipeline fill).
+    int ld_ash = 0, ld_cs = 0, ld_sh = 0;
+    unsigned ld_bsh = 0u;
+    auto load_prep = [&]() {
+        // past the end of the segment everything is masked (loads return zeros)
         const bool on = left > 0 && rmask != 0u;
         int t = (rmask != 0u ? __builtin_ctz(rmask) : 0) + rot;
         t = t >= ntaps ? t - ntaps : t;
         t = on ? t : 0;
-        const int ash = __builtin_amdgcn_readlane(v_ash, t), bsh = __builtin_amdgcn_readlane(v_bsh, t);
-        const int cs = kc * 128;  // a K step is 128 bytes of a row
-        const int sh = on ? 31 - t : 0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const unsigned o = ((abase[i] + (unsigned)ash) & 0x7fffffffu) | ((inval[i] << sh) & 0x80000000u);
+        ld_ash = __builtin_amdgcn_readlane(v_ash, t);
+        ld_bsh = (unsigned)__builtin_amdgcn_readlane(v_bsh, t) + (on ? 0u : SK_OOB);  // bbase + bshift < 2^31: the top bit pushes it out of range
+        ld_cs = kc * 128;  // a K step is 128 bytes of a row
+        // the row's invalid-tap bit moves to bit 31 of the offset: out of range, the load returns zeros.  Loader off: shift 0 brings the always-set bit 31 there
+        ld_sh = on ? 31 - t : 0;
+    };
+    auto load_op = [&](auto SI, const int i) {
+        constexpr int S_ = decltype(SI)::value;
+        if (i < RA) {
+            const unsigned o = ((abase[i] + (unsigned)ld_ash) & 0x7fffffffu) | ((inval[i] << ld_sh) & 0x80000000u);
 #if BF_ABL & 1
-            ra[S_][i][0] = __uint_as_float(o + (unsigned)cs);
+            ra[S_][i][0] = __uint_as_float(o + (unsigned)ld_cs);
 #else
-            ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, cs, 0));
+            ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, ld_cs, 0));
+#endif
+        } else if (i < RA + RB) {
+#if BF_ABL & 1
+            rb[S_][i - RA][0] = __uint_as_float(bbase[i - RA] + ld_bsh + (unsigned)ld_cs);
+#else
+            rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
 #endif
         }
-        const unsigned bsh_eff = (unsigned)bsh + (on ? 0u : SK_OOB);
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#if BF_ABL & 1
-            rb[S_][i][0] = __uint_as_float(bbase[i] + bsh_eff + (unsigned)cs);
-#else
-            rb[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i] + bsh_eff), cs, 0));
-#endif
+    };
+    auto load_advance = [&]() {
         --left;
         const bool wrap = kc + 1 == nkc;
         kc = wrap ? 0 : kc + 1;
         rmask = wrap ? (rmask & (rmask - 1u)) : rmask;
+    };
+    auto load = [&](auto SI) {
+        load_prep();
+#pragma unroll
+        for (int i = 0; i < RA + RB; ++i) load_op(SI, i);
+        load_advance();
+    };
+    auto stage_op = [&](auto SI, const int buf, const int i) {  // operand row i of the staged step: registers -> LDS[buf]
+        constexpr int S_ = decltype(SI)::value;
+#if BF_ABL & 2
+        if (i < RA) asm volatile("" ::"v"(ra[S_][i]));
+        else if (i < RA + RB) asm volatile("" ::"v"(rb[S_][i - RA]));
+#else
+        if (i < RA) *(f32x4*)&sA[buf * BM * SK_LDP + wofs + 64 * i * SK_LDP] = ra[S_][i];
+        else if (i < RA + RB) *(f32x4*)&sB[buf * BN * SK_LDP + wofs + 64 * (i - RA) * SK_LDP] = rb[S_][i - RA];
+#endif
     };
     auto stage = [&](auto SI, const int buf) {
         constexpr int S_ = decltype(SI)::value;
@@ -270,40 +392,71 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         for (int i = 0; i < RB; ++i) *(f32x4*)&wB[64 * i * SK_LDP] = rb[S_][i];
 #endif
     };
-    // set-up of tile (c, mt, nt) covering live steps from `pos`: loader state, and the rows' output offsets / groups into sOut / sGrp[sbuf]
-    auto setup = [&](const int sbuf) -> TileFacts {
-        const sk_class& cl = P.cls[c];
+    // LDS hand-over between waves WITHOUT draining the global loads in flight (__syncthreads() waits for vmcnt(0) as well)
+#define BF_LDS_BARRIER()                      \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+    // Tables of a tile, in two halves so that their latency hides under the PREVIOUS tile's K loop:
+    //   request(k): the row table entry of row `tid` (one 16-byte load: X offset, tap mask, Y offset, group) and the tile's scalars (live-step
+    //               prefix sums, live-tap mask) -- issued when the previous tile's K loop starts, 4 VGPRs + 4 SGPRs in flight;
+    //   commit(k):  after that K loop -- the rows' entries go to LDS (sRow / sOut / sGrp[sbuf]), one barrier, then every loader thread picks up
+    //               the rows it fetches and the class's tap tables: the loader state is the new tile's, nothing waited for.
+    struct TileTables {
+        int4 row;
+        int tbeg, tend, ti_mask, ti_rot;
+    };
+    auto request = [&](const Cursor& k) -> TileTables {
+        TileTables t;
+        const sk_class& cl = P.cls[k.c];
+        t.row = tid < BM ? P.rowinfo[cl.row_begin + k.mt * BM + tid] : int4{0, 0, 0, 0};
+        t.tbeg = P.tilecum[k.tile];
+        t.tend = P.tilecum[k.tile + 1];
+        const int2 ti = P.tileinfo[cl.mt_begin + k.mt];
+        t.ti_mask = ti.x, t.ti_rot = ti.y;
+        return t;
+    };
+    auto commit = [&](const Cursor& k, const TileTables& t, const int sbuf) -> TileFacts {
+        const sk_class& cl = P.cls[k.c];
         TileFacts f;
-        nkc = __builtin_amdgcn_readfirstlane(cl.nkc);
-        ntaps = __builtin_amdgcn_readfirstlane(cl.ntaps);
-        f.Cout = __builtin_amdgcn_readfirstlane(cl.Cout);
-        f.tbeg = __builtin_amdgcn_readfirstlane(P.tilecum[tile]);
-        f.tend = __builtin_amdgcn_readfirstlane(P.tilecum[tile + 1]);
+        if (tid < BM) {
+            sRowB[sbuf * BM + tid] = int2{t.row.x, t.row.y};
+            sOutB[sbuf * BM + tid] = t.row.z;
+            sGrpB[sbuf * BM + tid] = t.row.w;
+        }
+        if (k.c != cls_loaded) {  // the class's tables (kernel arguments: scalar loads, two vector loads) only when the class changes -- never, for most launches
+            cls_loaded = k.c;
+            nkc = __builtin_amdgcn_readfirstlane(cl.nkc);
+            ntaps = __builtin_amdgcn_readfirstlane(cl.ntaps);
+            cls_cout = __builtin_amdgcn_readfirstlane(cl.Cout);
+            cls_wrow = __builtin_amdgcn_readfirstlane(cl.Tw * cl.Cin);
+            v_ash = lane < SDT_MAX_TAPS ? cl.ashift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
+            v_bsh = lane < SDT_MAX_TAPS ? cl.bshift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
+        }
+        f.Cout = cls_cout;
+        f.tbeg = __builtin_amdgcn_readfirstlane(t.tbeg);
+        f.tend = __builtin_amdgcn_readfirstlane(t.tend);
         f.a = pos - f.tbeg;
         f.b = min(s_end, f.tend) - f.tbeg;
-        const int2 ti = P.tileinfo[cl.mt_begin + mt];
-        const int m0 = cl.row_begin + mt * BM;
-        f.n0 = nt * BN;
-        v_ash = lane < SDT_MAX_TAPS ? cl.ashift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
-        v_bsh = lane < SDT_MAX_TAPS ? cl.bshift[lane < SDT_MAX_TAPS ? lane : 0] : 0;
+        f.n0 = k.nt * BN;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int2 ri = ((const int2*)P.rowinfo)[2 * (m0 + r0 + 64 * i)];  // {X byte offset, invalid-tap mask}
-            abase[i] = (unsigned)ri.x + (unsigned)kv * 16u;
-            inval[i] = (unsigned)ri.y;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cl.Tw * cl.Cin) * 2u + (unsigned)kv * 16u;  // W is (N, Tw, Cin) bf16
-        if (tid < BM) {
-            const int2 ro = ((const int2*)P.rowinfo)[2 * (m0 + tid) + 1];  // {Y byte offset, statistics group}
-            sOutB[sbuf * BM + tid] = ro.x;
-            sGrpB[sbuf * BM + tid] = ro.y;
-        }
-        rmask = (unsigned)__builtin_amdgcn_readfirstlane(ti.x);
-        rot = __builtin_amdgcn_readfirstlane(ti.y);
+        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * 2u + (unsigned)kv * 16u;  // W is (N, Tw, Cin) bf16
+        rmask = (unsigned)__builtin_amdgcn_readfirstlane(t.ti_mask);
+        rot = __builtin_amdgcn_readfirstlane(t.ti_rot);
         for (int skip = f.a / nkc; skip > 0; --skip) rmask &= rmask - 1;
         kc = f.a - (f.a / nkc) * nkc;
         left = f.b - f.a;
+        BF_LDS_BARRIER();  // the rows' entries are in LDS
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int2 ri = sRowB[sbuf * BM + r0 + 64 * i];
+            abase[i] = (unsigned)ri.x + (unsigned)kv * 16u;
+            inval[i] = (unsigned)ri.y;
+        }
         return f;
     };
     typedef std::integral_constant<int, 0> I0;
@@ -323,50 +476,113 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
 #define BF_MFMAS(A, B)                                                                                                \
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) BF_MFMA(acc[tm][tn], A[tm], B[tn])
 
-    // one K step on LDS buffer `cur`: fragments of k-group 0 are in a0 / b0 on entry (and on exit, for the next step)
+    // One K step on LDS buffer `cur`; the fragments of k-group 0 are in a0 / b0 on entry (and on exit, for the next step).
+    // The instruction order is FIXED here, slot by slot (a sched_barrier after every slot): one MFMA, then its share of the next k-group's fragment
+    // reads, of the LDS stores of step s + 1 and of the requests that re-fill the registers just stored.  Left to itself hipcc chained the four
+    // k-groups of one accumulator back to back (dependent MFMAs) with an `s_waitcnt lgkmcnt(0)` in front of each: nothing overlapped, and the
+    // ablation was additive -- without MFMAs the loop got shorter by exactly the MFMAs' execution time (profiles/r05_bf2_ablation_v0.txt).
+    constexpr int NL = RA + RB;
+    constexpr int RPM = (NF + NM - 1) / NM;  // fragment reads per MFMA slot
+    // The L1 accepts 64 B per clock: the 48 (BN 128) / 64 / 40 KB that a workgroup requests per K step keep it busy for 768 / 1024 / 640 cycles, and
+    // a wave whose request is not accepted yet issues nothing else (in order) -- with all requests in the first half of the step the eight waves
+    // queued up behind each other and the step cost MFMA time PLUS request time (2105 cycles for 1024 of MFMA; without the requests 700 fewer).
+    // So the requests are spread over ALL slots of the step (the last ones behind the barrier: a request needs no barrier) and the LDS stores over
+    // the slots in front of the barrier; store i always precedes request i, which re-fills the registers store i has read.
+    auto stage_slot = [](const int i) constexpr { return i * 3 * NM / NL; };
+    auto load_slot = [](const int i) constexpr { return i * 4 * NM / NL; };
+    auto rd = [&](f32x4 (&A)[TM], f32x4 (&B)[TN], const float* pa, const float* pb, const int J, const int i) {
+#if BF_ABL & 16
+        if (i < TM) asm volatile("" : "+v"(A[i]) : "v"(pa));
+        else if (i < NF) asm volatile("" : "+v"(B[i - TM]) : "v"(pb));
+#else
+        if (i < TM) A[i] = *(const f32x4*)(pa + i * 32 * SK_LDP + J * 8);
+        else if (i < NF) B[i - TM] = *(const f32x4*)(pb + (i - TM) * 32 * SK_LDP + J * 8);
+#endif
+    };
     auto step = [&](auto CUR) {
         constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
         typedef std::integral_constant<int, (NSET == 2 ? nx : 0)> SETN;
         const float* pa = sA + cur * BM * SK_LDP + fa;
         const float* pb = sB + cur * BN * SK_LDP + fb;
-        BF_READ(a1, b1, pa, pb, 1);
-        stage(SETN{}, nx);  // step s + 1: registers -> LDS[next]
-        load(SETN{});       // step s + 1 + NSET -> the registers just staged
-        BF_MFMAS(a0, b0);
-        BF_READ(a0, b0, pa, pb, 2);
-        BF_MFMAS(a1, b1);
-        BF_READ(a1, b1, pa, pb, 3);
-        BF_MFMAS(a0, b0);
-        sk_bf_interleave<0, 0, NM, NF, RA + RB>();
+        const float* pan = sA + nx * BM * SK_LDP + fa;
+        const float* pbn = sB + nx * BN * SK_LDP + fb;
+        load_prep();
         __builtin_amdgcn_sched_barrier(0);
+        auto ops = [&](const int q) {  // the stores / requests that belong to slot q of the step
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                if (stage_slot(j) == q) stage_op(SETN{}, nx, j);
+                if (load_slot(j) == q) load_op(SETN{}, j);
+            }
+        };
+        // k-group 0 (a0 / b0) + fragments of k-group 1 -> a1 / b1
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            BF_MFMA(acc[i / TN][i % TN], a0[i / TN], b0[i % TN]);
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) rd(a1, b1, pa, pb, 1, i * RPM + j);
+            ops(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-group 1 (a1 / b1) + fragments of k-group 2 -> a0 / b0
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            BF_MFMA(acc[i / TN][i % TN], a1[i / TN], b1[i % TN]);
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) rd(a0, b0, pa, pb, 2, i * RPM + j);
+            ops(NM + i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-group 2 (a0 / b0) + fragments of k-group 3 -> a1 / b1
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            BF_MFMA(acc[i / TN][i % TN], a0[i / TN], b0[i % TN]);
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) rd(a1, b1, pa, pb, 3, i * RPM + j);
+            ops(2 * NM + i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my writes of LDS[next] are done
 #if !(BF_ABL & 8)
         __builtin_amdgcn_s_barrier();
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        BF_READ(a0, b0, sA + nx * BM * SK_LDP + fa, sB + nx * BN * SK_LDP + fb, 0);
-        BF_MFMAS(a1, b1);
+        // k-group 3 (a1 / b1) + fragments of the NEXT step's k-group 0 -> a0 / b0 + the last requests
 #pragma unroll
-        for (int q = 0; q < (NM < NF ? NM : NF); ++q) { SK_SGB(0x8, 1); SK_SGB(0x100, 1); }
-        if constexpr (NM > NF) SK_SGB(0x8, NM - NF);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NM; ++i) {
+            BF_MFMA(acc[i / TN][i % TN], a1[i / TN], b1[i % TN]);
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) rd(a0, b0, pan, pbn, 0, i * RPM + j);
+            ops(3 * NM + i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_advance();
     };
 
-    // LDS hand-over between waves WITHOUT draining the global loads in flight (__syncthreads() waits for vmcnt(0) as well)
-#define BF_LDS_BARRIER()                      \
-    do {                                      \
-        __builtin_amdgcn_sched_barrier(0);    \
-        __builtin_amdgcn_s_waitcnt(0xC07F);   \
-        __builtin_amdgcn_s_barrier();         \
-        __builtin_amdgcn_sched_barrier(0);    \
-    } while (0)
+    // running column statistics of this workgroup's range (threads tid < BN: column n0 + tid of group run_g)
+    int run_g = -1, run_n0 = 0, run_cout = 0;
+    float run_s = 0.f, run_q = 0.f;
+    auto flush_run = [&]() {
+        if constexpr (EPI != 0) {
+            if (run_g >= 0) {
+                double* d = (EPI == 1 ? stats : nb.sums) + ((size_t)run_g * run_cout + run_n0 + tid) * 2;
+                atomicAdd(d, (double)run_s);
+                atomicAdd(d + 1, (double)run_q);
+            }
+        }
+    };
 
-    // ------------------------------------------------------------------ first tile: set-up + the first requests
+    // ------------------------------------------------------------------ first tile: tables, loader state, the first request
     int sbuf = 0;
-    TileFacts F = setup(0);
+    TileFacts F = commit(cur, request(cur), 0);
     load(I0{});
     for (int seg = 0;; ++seg) {
         BF_TL(0, wall_clock64());
+        // ---- the NEXT tile's tables are requested now: they arrive while this tile's K loop runs
+        const bool more = F.tbeg + F.b < s_end;  // this range goes on behind this tile (the tile ends inside the range)
+        const Cursor nxt = more ? advance(cur) : cur;
+        TileTables NT;
+        if (more) NT = request(nxt);
         // ---- pipeline fill: step 0 -> LDS[0]; steps 1 (and 2) -> registers
         BF_LDS_BARRIER();  // the previous tile's LDS tiles are no longer read by anybody
         stage(I0{}, 0);
@@ -376,7 +592,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         } else {
             load(I0{});
         }
-        BF_LDS_BARRIER();  // LDS[0] and sOut / sGrp[sbuf] are written (the requests just issued stay in flight)
+        BF_LDS_BARRIER();  // LDS[0] is written (the requests just issued stay in flight)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -395,30 +611,16 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         if (s < nsteps) step(I0{});
         BF_TL(2, wall_clock64());
 
-        // ---- the tile's facts for the end phase; then the NEXT tile's set-up and first request, before the end phase
+        // ---- the tile's facts for the end phase; then the NEXT tile's loader state and first request, before the end phase
         const TileFacts E = F;
         const int ebuf = sbuf;
         const bool owner = E.a == 0, whole = owner && E.b == E.tend - E.tbeg;
-        const int ntile_pos = E.tbeg + E.b;
-        const bool more = ntile_pos < s_end;
         if (more) {
-            pos = ntile_pos;
-            ++tile;
-            if (P.ntmajor) {
-                if (++mt == P.cls[0].nmb) {
-                    mt = 0;
-                    ++nt;
-                }
-            } else if (++nt == P.nnb) {
-                nt = 0;
-                if (++mt == P.cls[c].nmb) {
-                    mt = 0;
-                    ++c;
-                }
-            }
+            pos = E.tbeg + E.b;
+            cur = nxt;
             sbuf ^= 1;
-            F = setup(sbuf);  // (writes sOut / sGrp[sbuf]: the other buffer than the one the end phase below reads)
-            load(I0{});       // first K step of the next tile: lands under the end phase
+            F = commit(cur, NT, sbuf);  // (writes sRow / sOut / sGrp[sbuf]: the other buffer than the one the end phase below reads)
+            load(I0{});                 // first K step of the next tile: lands under the end phase
         }
         BF_TL(3, wall_clock64());
         BF_TL(6, whole ? 0ull : (owner ? 1ull : 2ull));
@@ -495,16 +697,44 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
                             for (int q = 0; q < 16; ++q) acc[i][j][q] = __builtin_nanf("");
                 }
             }
+            // statistics of a tile whose 256 rows are ONE group (nearly all tiles): per-wave column sums -> LDS -> one partial per column, kept in
+            // registers across the tiles of this workgroup's range while group and column block stay the same (flushed with one fp64 atomic pair
+            // per column when they change and at the end of the range)
+            const int tgrp = sGrp[0];
+            const bool tile_uniform = EPI != 0 && TM % 2 == 0 && tgrp >= 0 && tgrp == sGrp[BM - 1];
+            float* red = tile_uniform ? sA + BM * SK_LDP + (wm * BN + col0) * 2 : nullptr;  // (LDS buffer 1 of A is idle until the next tile's first step)
             if constexpr (EPI == 2 && TM > 2) {  // the reads of y for half of the rows at a time: 64 instead of 128 registers
-                bf2_epilogue<TM, TN, EPI, 0, TM / 2>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes);
-                bf2_epilogue<TM, TN, EPI, TM / 2, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes);
+                bf2_epilogue<TM, TN, EPI, 0, TM / 2>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
+                bf2_epilogue<TM, TN, EPI, TM / 2, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
             } else {
-                bf2_epilogue<TM, TN, EPI, 0, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes);
+                bf2_epilogue<TM, TN, EPI, 0, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
+            }
+            if constexpr (EPI != 0) {
+                if (tile_uniform) {
+                    BF_LDS_BARRIER();
+                    if (tid < BN) {
+                        const float* rr = sA + BM * SK_LDP + tid * 2;
+                        float ts = 0.f, tq = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WGM; ++w) {  // fixed order
+                            ts += rr[w * BN * 2];
+                            tq += rr[w * BN * 2 + 1];
+                        }
+                        if (run_g == tgrp && run_n0 == E.n0) {
+                            run_s += ts;
+                            run_q += tq;
+                        } else {
+                            flush_run();
+                            run_g = tgrp, run_n0 = E.n0, run_cout = E.Cout, run_s = ts, run_q = tq;
+                        }
+                    }
+                }
             }
         }
         BF_TL(4, wall_clock64());
         if (!more) break;
     }
+    if (tid < BN) flush_run();
 #undef BF_LDS_BARRIER
 #undef BF_READ
 #undef BF_MFMAS
@@ -513,7 +743,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
 
 template <int BN, int WGM, int WGN, int EPI>
 static void bf2_launch_one(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (BF_BM + BN) * SK_LDP) * 4 + (size_t)4 * BF_BM * 4 + 16;
+    const size_t lds = (size_t)(2 * (BF_BM + BN) * SK_LDP) * 4 + (size_t)8 * BF_BM * 4 + 16;  // A / B tiles, sOut + sGrp + sRow (double-buffered), flag
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)convbf2_kernel<BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -158,6 +158,24 @@ __device__ __forceinline__ void sk_epilogue(f32x16 (&tot)[BM / 64][BN / 64], con
                     if (nb.beta != nullptr) be = nb.beta[n];
                 }
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+                // Fast path (wave-uniform): the 32 rows of the block are one group and all exist (groups ascend with the row, rows past the end of
+                // the tensor carry group -1 and come last) -- nearly every block.  Same sums in the same order as the general loop below, without
+                // its per-element selects: the statistics were VALU-bound (3.3 of a tile's 4.8 us end phase, profiles/r05_bf2_timeline_v0.txt).
+                if (gfirst == glast && gfirst >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if constexpr (EPI == 1) {
+                            const float u = tot[tm][tn][q] + bv;
+                            s0 += u;
+                            q0 = fmaf(u, u, q0);
+                        } else {
+                            const float v = (yv[((tm - TMB) * TN + tn) * 16 + q] - mu0) * rs0;
+                            const float u = tot[tm][tn][q] * act_grad(v * ga + be, nb.slope);
+                            s0 += u;
+                            q0 = fmaf(u, v, q0);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int4 o4 = *(const int4*)&sOut[rb0 + 8 * qq + 4 * (lane >> 5)];
@@ -1367,6 +1385,9 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     // plan the caller builds next, cuts it into twice as many ranges)
     SDT_CHECK_ARG(S >= ((esz == 2 && !is_bf2(esz)) ? 1 : 4) * (int64_t)G && S < (1ll << 31) / 2 / G, "step count out of range for the stream-K split (every range needs work)");
     SDT_CHECK_ARG(T < (1ll << 30), "too many tiles");
+    // the bf16-shaped kernel wants at least one 256-row tile per CU: with fewer, every tile is cut between several workgroups and the slab hand-offs
+    // of 256 x 256 partial tiles cost more than the K loops (L5 - L7 at 32 clips: 67 / 67 / 32 tiles; the 128-row kernel takes those)
+    SDT_CHECK_ARG(!is_bf2(esz) || T >= G, "too few tiles for one workgroup per CU");
     // first tile of every range: the tile that contains step floor(r * S / G)
     int64_t tile = 0;
     for (int r = 0; r < G; ++r) {

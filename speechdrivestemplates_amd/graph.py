@@ -118,7 +118,10 @@ class GraphedStep:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=state["pool"])
+            # thread_local: ProcessGroupNCCL's watchdog thread polls the events of earlier (eager) collectives with hipEventQuery; under the default
+            # global capture mode such a call from ANY thread fails ("operation not permitted when stream is capturing") and invalidates the capture
+            # -- seen as an intermittent abort of the data-parallel capture (one run in two).  Only this thread's calls need to be capture-safe.
+            g.capture_begin(pool=state["pool"], capture_error_mode="thread_local")
             state["g"] = g
 
         def end():
