@@ -419,6 +419,34 @@ def main(argv=None):
     final_loss = float(losses["G_loss" if "G_loss" in losses else "loss"].detach())
     assert final_loss == final_loss and final_loss < 10.0, "training diverged: G_loss=%r" % final_loss
 
+    def graph_leg_f32():
+        """N > 1 (or a forced 1-rank group), informational: the SAME fp32 step replayed from a hipGraph with its RCCL all-reduces captured
+        (graph.GraphedStep): enqueued launch by launch the data-parallel step pays ~0.4-0.6 ms of host work for the bucket launches on top of the
+        reserve (profiles/r05_dp_one_gpu_ab.txt: 7.80 vs 7.15 ms on one GPU; replayed 7.34).  `value` stays the eager step."""
+        from speechdrivestemplates_amd.graph import GraphedStep
+        try:
+            gs = GraphedStep(pipe, warmup=1)
+            base = args.warmup + args.steps
+            for i in range(4):
+                gs.run(batches[(base + i) % len(batches)])
+            sync()
+            if world > 1:
+                dist.barrier()
+            t0g = time.perf_counter()
+            n = 20
+            for i in range(n):
+                lg = gs.run(batches[(base + 4 + i) % len(batches)])
+            sync()
+            ms = (time.perf_counter() - t0g) * 1e3 / n
+            if world > 1 or forced_dp:
+                t = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            return {"value": world * B / (ms * 1e-3), "unit": "clips/s", "ms_per_step": ms, "steps": n, "graph_mode": gs.mode, "G_loss": float(lg["G_loss"].detach()),
+                    "note": "the timed fp32 step replayed from a hipGraph (SYS.HIP_GRAPH) with the gradient exchange captured; not `value`"}
+        except Exception as e:  # a capture that fails must not take the bench line with it
+            return {"error": repr(e)[:300]}
+
     def bf16_leg():
         """informational, OUTSIDE the timed region and not part of `value`: BASELINE config 4's arithmetic on this GPU (these GPUs: every rank runs
         it, the exchange included; the slowest rank's time counts) -- the same train step with the Conv2d chain's tensors stored as bf16 and its
@@ -505,6 +533,9 @@ def main(argv=None):
                         "neither -- LDS feeding and the per-tile epilogue of a persistent fp32-shaped tile (DESIGN.md section 2)" % BF16_MATRIX_PEAK_TFLOPS}
         return out.get("alt_conv_math")
 
+    dp_graph = None
+    if not stub and on_gpu and (world > 1 or forced_dp) and not args.graph and args.config == "voice2pose_sdt_bp" and not args.no_alt_mode:
+        dp_graph = graph_leg_f32()  # every rank (collectives inside)
     alt = None
     if not stub and not args.no_alt_mode and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
             and args.config == "voice2pose_sdt_bp":
@@ -623,6 +654,10 @@ def main(argv=None):
             hbs = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_hbm_kernels.txt")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
             if hbs:
                 out["hbm_kernels_table"] = "profiles/%s (tools/hbm_kernels.py over a rocprofv3 kernel trace of this command)" % hbs[-1]
+        if dp_graph is not None:
+            if "value" in dp_graph:
+                dp_graph["vs_default"] = dp_graph["value"] / out["value_uninstrumented"]
+            out["dp_graph_replay"] = dp_graph
         if alt is not None:
             alt["vs_default"] = alt["value"] / out["value_uninstrumented"]
             out["alt_conv_math"] = alt

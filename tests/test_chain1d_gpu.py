@@ -2,6 +2,8 @@
 replaces (ops.ConvRowNormFn + ops.UpsampleAddFn: conv -> split-K reduction + normalisation -> LeakyReLU per block), which are themselves held to
 the oracle by tests/test_ops_gpu.py and the trajectory tests.  Same seeded inputs, forward output, input gradient and all sixteen weight
 gradients; fp32 both sides, only the summation order differs (K split over 2 or 4 waves here, over 4 workgroups + slabs there)."""
+import os
+
 import pytest
 import torch
 
@@ -145,6 +147,114 @@ def test_chain_with_bf16_products_follows_the_per_block_kernels_in_bf16_math():
         ea, eb, eab = _rel(a, f), _rel(b, f), _rel(a, b)
         print("  %s: chain bf16 vs fp32 %.2e, per-block bf16 vs fp32 %.2e, chain vs per-block %.2e" % (name, ea, eb, eab))
         assert 1e-4 < ea <= 1.5 * eb + 1e-3 and eab <= 1.2 * max(ea, eb), (name, ea, eb, eab)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Directly against the float64 ORACLE (oracle.unet_1d + the four decoder blocks: generator.py:70-85, 96-103), with the REAL slope at B = 3 and 32
+# (the chain used to be compared with this repository's own per-block kernels only).  The network is piecewise linear: an
+# element whose normalised pre-activation sits within fp32 rounding of zero takes slope 1 in one fp32 implementation and 0.2 in another, and
+# each such decision moves the gradients of its clip by ~1e-2 of their scale.  Flip accounting: the float64 run records every pre-activation;
+# the few elements within DELTA of zero are "ambiguous", the float64 gradients are evaluated at the oracle's own decisions (base) and once more
+# per ambiguous element with that ONE decision flipped; the HIP gradients must equal base + (some subset of those flips) -- which subset is
+# read off the input gradient by least squares, and EVERY gradient tensor (input gradient, the sixteen weight gradients -- computed by the
+# grouped weight-gradient launch, as in a train step) is then held to the tight fp32 bar under that one assignment.
+DELTA = 2e-6  # |normalised pre-activation| below which a LeakyReLU decision is ambiguous between fp32 implementations (fp32 forward error: ~3e-7)
+
+
+def _oracle_chain(h64, ws64, flips, record):
+    """float64 oracle of the chain through oracle.unet_1d / oracle._block1d with F.leaky_relu replaced by a recording / overriding version:
+    decision = (x > 0) XOR (this element is in `flips`); returns z (B, 256, T)."""
+    import torch.nn.functional as F
+    from oracle import sdt_oracle as O
+    state = {}
+    names = [n for n, _ in O.UNET_ENC] + list(O.UNET_DEC)
+    for n, w in zip(names, ws64[:12]):
+        state["u.%s.conv.weight" % n] = w
+    for i in range(4):
+        state["dec.%d.conv.weight" % i] = ws64[12 + i]
+    calls = [0]
+    real = F.leaky_relu
+
+    def leaky(x, slope=0.01, inplace=False):
+        k = calls[0]
+        calls[0] += 1
+        if record is not None:
+            record.append(x.detach())
+        dec = (x.detach() > 0).contiguous()  # (logical order: the recorded indices are those of x.reshape(-1))
+        for (blk, idx) in flips:
+            if blk == k:
+                dec.view(-1)[idx] = ~dec.view(-1)[idx]
+        return x * torch.where(dec, torch.ones((), dtype=x.dtype), torch.full((), slope, dtype=x.dtype))
+
+    F.leaky_relu = leaky
+    try:
+        x = O.unet_1d(state, "u", h64, "IN", True, True)
+        for i in range(4):
+            x = O._block1d(x, state, "dec.%d" % i, False, "IN", True, True)
+    finally:
+        F.leaky_relu = real
+    assert calls[0] == 16
+    return x
+
+
+@pytest.mark.parametrize("B", [3, 32])
+def test_chain_and_grouped_weight_gradients_vs_float64_oracle(B):
+    from speechdrivestemplates_amd import ops
+    T, cin0 = 64, 288
+    torch.manual_seed(900 + B)
+    ws = _weights(cin0, 21)
+    h = torch.randn((B, T, cin0), device="cuda", requires_grad=True)
+    gz = torch.randn((B, T, 256), device="cuda")
+    ops.begin_step(torch.device("cuda", 0))
+    z = ops.Chain1dFn.apply(h, _wiring(), SLOPE, *ws)
+    ops.defer_small_dw(True)  # as Voice2Pose.forward_backward: the sixteen weight gradients in ONE grouped launch + one ordered reduce
+    try:
+        z.backward(gz)
+    finally:
+        ops.defer_small_dw(False)
+        ops.flush_deferred_dw()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert not ops.streamk_error_codes()
+    z_hip, dh_hip = z.detach().double().cpu(), h.grad.double().cpu()
+    dw_hip = [w.grad.detach().double().cpu() for w in ws]  # logical (Cout, Cin, k)
+
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    h64 = h.detach().double().cpu().permute(0, 2, 1).contiguous()   # the oracle is channels-first
+    gz64 = gz.double().cpu().permute(0, 2, 1).contiguous()
+
+    def grads(flips, record=None):
+        hh = h64.clone().requires_grad_(True)
+        ww = [w.detach().double().cpu().clone().requires_grad_(True) for w in ws]
+        out = _oracle_chain(hh, ww, flips, record)
+        (out * gz64).sum().backward()
+        return out.detach(), hh.grad.permute(0, 2, 1).contiguous(), [w.grad for w in ww]
+
+    rec = []
+    z64, dh0, dw0 = grads((), rec)
+    amb = [(k, int(i)) for k, x in enumerate(rec) for i in (x.reshape(-1).abs() < DELTA).nonzero().flatten().tolist()]
+    e_z = _rel(z_hip, z64.permute(0, 2, 1))
+    assert len(amb) <= 24, "too many ambiguous activation decisions for this seed (%d)" % len(amb)
+    deltas = []
+    for f in amb:
+        _, dh_f, dw_f = grads((f,))
+        deltas.append((dh_f - dh0, [a - b for a, b in zip(dw_f, dw0)]))
+    chosen = []
+    dh_ref, dw_ref = dh0, dw0
+    if deltas:
+        A = torch.stack([d[0].reshape(-1) for d in deltas], 1)
+        sol = torch.linalg.lstsq(A, (dh_hip - dh0).reshape(-1, 1)).solution.flatten()
+        chosen = [i for i, v in enumerate(sol.tolist()) if v > 0.5]
+        for i in chosen:
+            dh_ref = dh_ref + deltas[i][0]
+            dw_ref = [a + b for a, b in zip(dw_ref, deltas[i][1])]
+    e_dh = _rel(dh_hip, dh_ref)
+    e_dw = [_rel(a, b) for a, b in zip(dw_hip, dw_ref)]
+    print("  chain vs float64 oracle, B=%d: forward %.2e; %d ambiguous decisions, %d taken the other way by the HIP run; input gradient %.2e, "
+          "weight gradients worst %.2e" % (B, e_z, len(amb), len(chosen), e_dh, max(e_dw)))
+    assert e_z <= 1e-5, e_z
+    assert e_dh <= 3e-5, e_dh
+    assert max(e_dw) <= 3e-5, e_dw
 
 
 def test_chain_leaves_its_counters_at_zero_and_replays():
