@@ -26,7 +26,6 @@
 
 #include "convsk.h"
 
-#define BF_BM 256
 #define BF_NT 512
 // BF_ABL (tools/debug/r05_bf2_ablation.sh; ablation builds compute WRONG results by design): 1 no global loads in the K loop, 2 no LDS stores,
 // 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads, 32 no epilogue stores
@@ -245,10 +244,10 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
 }
 
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
-template <int BN, int WGM, int WGN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W, const float* __restrict__ bias,
                                                           __bf16* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
-    constexpr int BM = BF_BM, TM = BM / WGM / 32, TN = BN / WGN / 32, RA = BM / 64, RB = BN / 64, NM = TM * TN, NF = TM + TN;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32, RA = BM / 64, RB = BN / 64, NM = TM * TN, NF = TM + TN;
     constexpr int NSET = BN == 256 ? 1 : 2;  // staging register sets: two when the accumulators leave room (a load then has two steps to land)
     static_assert(WGM * WGN == 8 && TM >= 1 && TN >= 1 && RB >= 1, "wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -488,6 +487,8 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     // queued up behind each other and the step cost MFMA time PLUS request time (2105 cycles for 1024 of MFMA; without the requests 700 fewer).
     // So the requests are spread over ALL slots of the step (the last ones behind the barrier: a request needs no barrier) and the LDS stores over
     // the slots in front of the barrier; store i always precedes request i, which re-fills the registers store i has read.
+    // (Measured and rejected, profiles/r05_bf2_experiments.txt: a "ping-pong" step in which the waves w and w + 4 run the MFMA half and the store /
+    // request half of a step in opposite order -- 2094 -> 3247 cycles per step: clustered requests wait for each other.)
     auto stage_slot = [](const int i) constexpr { return i * 3 * NM / NL; };
     auto load_slot = [](const int i) constexpr { return i * 4 * NM / NL; };
     auto rd = [&](f32x4 (&A)[TM], f32x4 (&B)[TN], const float* pa, const float* pb, const int J, const int i) {
@@ -741,28 +742,29 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
 #undef sFlagOk
 }
 
-template <int BN, int WGM, int WGN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int EPI>
 static void bf2_launch_one(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (BF_BM + BN) * SK_LDP) * 4 + (size_t)8 * BF_BM * 4 + 16;  // A / B tiles, sOut + sGrp + sRow (double-buffered), flag
+    const size_t lds = (size_t)(2 * (BM + BN) * SK_LDP) * 4 + (size_t)8 * BM * 4 + 16;  // A / B tiles, sOut + sGrp + sRow (double-buffered), flag
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)convbf2_kernel<BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)convbf2_kernel<BM, BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((convbf2_kernel<BN, WGM, WGN, EPI>), dim3(A.G), dim3(BF_NT), lds, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, A, stats, nb);
+    hipLaunchKernelGGL((convbf2_kernel<BM, BN, WGM, WGN, EPI>), dim3(A.G), dim3(BF_NT), lds, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, A, stats, nb);
 }
 
-int convbf2_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bn, int epi,
+int convbf2_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
                    hipStream_t s) {
-#define BF2_GO(BN_, WGM_, WGN_)                                                              \
-    do {                                                                                      \
-        if (epi == 0) bf2_launch_one<BN_, WGM_, WGN_, 0>(x, w, bias, y, A, stats, nb, s);     \
-        else if (epi == 1) bf2_launch_one<BN_, WGM_, WGN_, 1>(x, w, bias, y, A, stats, nb, s); \
-        else bf2_launch_one<BN_, WGM_, WGN_, 2>(x, w, bias, y, A, stats, nb, s);              \
+#define BF2_GO(BM_, BN_, WGM_, WGN_)                                                              \
+    do {                                                                                           \
+        if (epi == 0) bf2_launch_one<BM_, BN_, WGM_, WGN_, 0>(x, w, bias, y, A, stats, nb, s);     \
+        else if (epi == 1) bf2_launch_one<BM_, BN_, WGM_, WGN_, 1>(x, w, bias, y, A, stats, nb, s); \
+        else bf2_launch_one<BM_, BN_, WGM_, WGN_, 2>(x, w, bias, y, A, stats, nb, s);              \
     } while (0)
-    if (bn == 256) BF2_GO(256, 2, 4);
-    else if (bn == 128) BF2_GO(128, 4, 2);
-    else if (bn == 64) BF2_GO(64, 4, 2);
+    if (bm == 256 && bn == 256) BF2_GO(256, 256, 2, 4);
+    else if (bm == 256 && bn == 128) BF2_GO(256, 128, 4, 2);
+    else if (bm == 256 && bn == 64) BF2_GO(256, 64, 4, 2);
+    else if (bm == 128 && bn == 128) BF2_GO(128, 128, 2, 4);  // few-row layers (L5 - L7 at 32 clips): 64 x 32 per wave, about one tile per CU
     else return SDT_ERR_ARG;
 #undef BF2_GO
     return SDT_OK;

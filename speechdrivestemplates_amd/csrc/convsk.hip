@@ -1139,9 +1139,13 @@ static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, in
 static bool is_bf2(int esz) { return esz == 2 && g_sk_wpc == 1; }
 static void plan_shape(const sdt_conv_geom& g, int esz, int& bm, int& bn, int& G) {
     if (is_bf2(esz)) {
+        G = (256 - g_sk_reserve / 2) & ~7;
         bm = 256;
         bn = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
-        G = (256 - g_sk_reserve / 2) & ~7;
+        // few rows (L5 - L7 at 32 clips: 16960 / 16960 / 8160): 256-row tiles would be fewer than CUs and every one of them cut between several
+        // workgroups -- 128 x 128 tiles instead (about one whole tile per CU: no slab hand-off for most of them)
+        const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+        if (cdiv64(M, 256) * (g.Cout / bn) < G && g.Cout % 128 == 0) bm = 128, bn = 128;
         return;
     }
     sk_tile_choice(g, bm, bn);
@@ -1387,7 +1391,7 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
     SDT_CHECK_ARG(T < (1ll << 30), "too many tiles");
     // the bf16-shaped kernel wants at least one 256-row tile per CU: with fewer, every tile is cut between several workgroups and the slab hand-offs
     // of 256 x 256 partial tiles cost more than the K loops (L5 - L7 at 32 clips: 67 / 67 / 32 tiles; the 128-row kernel takes those)
-    SDT_CHECK_ARG(!is_bf2(esz) || T >= G, "too few tiles for one workgroup per CU");
+    SDT_CHECK_ARG(!is_bf2(esz) || 2 * T >= G, "too few tiles for one workgroup per CU");
     // first tile of every range: the tile that contains step floor(r * S / G)
     int64_t tile = 0;
     for (int r = 0; r < G; ++r) {
@@ -1498,8 +1502,8 @@ static int sk_go(const void* x, const void* w, const float* bias, void* y, const
         else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(float, float, 128, 64, 2);
         else SDT_CHECK_ARG(false, "plan with an unknown tile shape");
     } else if (xbf && ybf) {
-        if (bm == 256 && wpc == 1) {
-            rc = convbf2_launch(x, w, bias, y, A, stats, nb, bn, epi, s);
+        if (wpc == 1) {
+            rc = convbf2_launch(x, w, bias, y, A, stats, nb, bm, bn, epi, s);
             SDT_CHECK_ARG(rc == SDT_OK, "plan with a tile shape the bf16-shaped kernel is not built for");
         } else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(__bf16, __bf16, 128, 128, 2);
         else if (bm == 128 && bn == 64 && wpc == 2) SK_GO(__bf16, __bf16, 128, 64, 2);

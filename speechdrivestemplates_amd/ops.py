@@ -671,8 +671,8 @@ def prepare_capture_stream(dev, stream):
 
 
 def _sk_name(plan):
-    if plan.host[1] == 256 and plan.dtype == _lib.BF16:
-        return "convbf2_kernel<%d>" % plan.host[2]
+    if plan.dtype == _lib.BF16 and (plan.host[3] >> 16) & 0xff == 1:  # one workgroup per CU: the bf16-shaped kernel
+        return "convbf2_kernel<%d, %d>" % (plan.host[1], plan.host[2])
     return "convsk_kernel<%d, %d>" % (plan.host[1], plan.host[2])
 
 def _splitk_hint(lib, g):
