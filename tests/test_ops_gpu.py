@@ -905,7 +905,8 @@ def test_streamk_plans_with_reserved_slots(ops):
         ops.SK_RESERVED_SLOTS = prev
     assert grids and all(v == 480 for v in grids.values()), grids       # backward plans: 512 - 32 workgroups
     assert dw_grids and all(v == 480 for v in dw_grids), dw_grids
-    fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if plan is not None and key[5] and key[6] == 0]
+    # (fp32 plans: key[7] is the element type -- bf16 plans of other tests in this process may be the one-workgroup-per-CU kind, 256 ranges)
+    fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if plan is not None and key[5] and key[6] == 0 and key[7] == 0]
     assert fwd and all(v == 512 for v in fwd), fwd                       # forward plans keep every slot
     check("reserve fwd", ops.cf_view(yd), y, 3e-6)
     check("reserve dX", ops.cf_view(dx), xr.grad, 3e-6)
