@@ -248,7 +248,11 @@ template <int BM, int BN, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W, const float* __restrict__ bias,
                                                           __bf16* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32, RA = BM / 64, RB = BN / 64, NM = TM * TN, NF = TM + TN;
-    constexpr int NSET = BN == 256 ? 1 : 2;  // staging register sets: two when the accumulators leave room (a load then has two steps to land)
+    // Staging register sets = how many K steps a request has to land before its data is stored to LDS: two when the accumulators leave room.
+    // (Three / four sets were measured, profiles/r05_bf2_experiments.txt: no gain -- the waves wait for their operands at ANY prefetch depth, the
+    // delivery RATE of ~24 B/clk per CU is what a step waits for, not the latency of one request.)
+    constexpr int NSET = BN == 256 ? 1 : 2;
+    constexpr int UNR = (NSET % 2 == 0) ? (NSET < 2 ? 2 : NSET) : 2 * NSET;  // period of (LDS buffer parity, staging set)
     static_assert(WGM * WGN == 8 && TM >= 1 && TN >= 1 && RB >= 1, "wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                          // [2][BM * LDP]
@@ -321,6 +325,9 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     // one K step's requests: load_prep() (wave-uniform scalars of the step at (tap, kc)), load_op(set, i) (operand row i: A rows first, then B rows),
     // load_advance().  The K loop places the ops one by one between its MFMAs; `load` is all of them in a row (pipeline fill).
     int ld_ash = 0, ld_cs = 0, ld_sh = 0;
+#if BF_ABL & 64
+    f32x4 abl_sink[RA + RB];
+#endif
     unsigned ld_bsh = 0u;
     auto load_prep = [&]() {
         // past the end of the segment everything is masked (loads return zeros)
@@ -340,12 +347,16 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
             const unsigned o = ((abase[i] + (unsigned)ld_ash) & 0x7fffffffu) | ((inval[i] << ld_sh) & 0x80000000u);
 #if BF_ABL & 1
             ra[S_][i][0] = __uint_as_float(o + (unsigned)ld_cs);
+#elif BF_ABL & 64  // the request is issued but nobody waits for it (the LDS stores take stale registers): the cost of ISSUING requests vs WAITING for them
+            abl_sink[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, ld_cs, 0));
 #else
             ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, ld_cs, 0));
 #endif
         } else if (i < RA + RB) {
 #if BF_ABL & 1
             rb[S_][i - RA][0] = __uint_as_float(bbase[i - RA] + ld_bsh + (unsigned)ld_cs);
+#elif BF_ABL & 64
+            abl_sink[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
 #else
             rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
 #endif
@@ -459,7 +470,6 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         return f;
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
 
     f32x16 acc[TM][TN];
     f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
@@ -500,9 +510,9 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         else if (i < NF) B[i - TM] = *(const f32x4*)(pb + (i - TM) * 32 * SK_LDP + J * 8);
 #endif
     };
-    auto step = [&](auto CUR) {
+    auto step = [&](auto CUR, auto SETI) __attribute__((always_inline)) {
         constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
-        typedef std::integral_constant<int, (NSET == 2 ? nx : 0)> SETN;
+        typedef decltype(SETI) SETN;
         const float* pa = sA + cur * BM * SK_LDP + fa;
         const float* pb = sB + cur * BN * SK_LDP + fb;
         const float* pan = sA + nx * BM * SK_LDP + fa;
@@ -560,6 +570,21 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         load_advance();
     };
 
+    // `n` (<= UNR) consecutive steps starting at period position U (compile-time recursion: buffer parity and staging set are template constants)
+    auto steps_unrolled = [&](auto self_u, const int n) __attribute__((always_inline)) {
+        (void)self_u;
+        auto rec = [&](auto&& rec_, auto U_) __attribute__((always_inline)) -> void {
+            constexpr int u = decltype(U_)::value;
+            if constexpr (u < UNR) {
+                if (u < n) {
+                    step(std::integral_constant<int, (u & 1)>{}, std::integral_constant<int, ((u + 1) % NSET)>{});
+                    rec_(rec_, std::integral_constant<int, u + 1>{});
+                }
+            }
+        };
+        rec(rec, std::integral_constant<int, 0>{});
+    };
+
     // running column statistics of this workgroup's range (threads tid < BN: column n0 + tid of group run_g)
     int run_g = -1, run_n0 = 0, run_cout = 0;
     float run_s = 0.f, run_q = 0.f;
@@ -587,12 +612,11 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         // ---- pipeline fill: step 0 -> LDS[0]; steps 1 (and 2) -> registers
         BF_LDS_BARRIER();  // the previous tile's LDS tiles are no longer read by anybody
         stage(I0{}, 0);
-        if constexpr (NSET == 2) {
-            load(I1{});
-            load(I0{});
-        } else {
-            load(I0{});
-        }
+        // steps 1 .. NSET - 1 -> sets 1 .. NSET - 1, step NSET -> set 0 (just stored)
+        if constexpr (NSET >= 2) load(std::integral_constant<int, 1>{});
+        if constexpr (NSET >= 3) load(std::integral_constant<int, 2>{});
+        if constexpr (NSET >= 4) load(std::integral_constant<int, 3>{});
+        load(I0{});
         BF_LDS_BARRIER();  // LDS[0] is written (the requests just issued stay in flight)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -605,12 +629,16 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         BF_TL(1, wall_clock64());
         BF_TL(5, (unsigned long long)nsteps);
         int s = 0;
-        for (; s + 1 < nsteps; s += 2) {
-            step(I0{});
-            step(I1{});
+        // the K loop, unrolled over the period of (LDS buffer, staging set): step u of a period reads LDS[u & 1] and stores / re-requests set (u + 1) % NSET
+        for (; s + UNR <= nsteps; s += UNR) {
+            steps_unrolled(std::integral_constant<int, 0>{}, UNR);
         }
-        if (s < nsteps) step(I0{});
+        steps_unrolled(std::integral_constant<int, 0>{}, nsteps - s);
         BF_TL(2, wall_clock64());
+#if BF_ABL & 64
+#pragma unroll
+        for (int i = 0; i < RA + RB; ++i) asm volatile("" ::"v"(abl_sink[i]));
+#endif
 
         // ---- the tile's facts for the end phase; then the NEXT tile's loader state and first request, before the end phase
         const TileFacts E = F;
