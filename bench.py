@@ -41,6 +41,13 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+# the split-fp32 conv kernel (csrc/convbf.hip, ET = float): every fp32 product = six bf16 MFMA products, so its matrix roofline in ALGORITHMIC
+# (fp32) FLOP/s is a sixth of the dense bf16 peak
+SPLIT_F32_PEAK_TFLOPS = BF16_MATRIX_PEAK_TFLOPS / 6.0
+
+
+def matrix_peak_tflops(kernel_name):
+    return SPLIT_F32_PEAK_TFLOPS if kernel_name.startswith("convbf2_kernel<float") else FP32_MATRIX_PEAK_TFLOPS
 HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 N_CLIPS = 4096
 # Algorithmic work of the Conv1d stacks per 32-clip step (weights counted once per step): generator U-Net + decoder
@@ -218,6 +225,7 @@ def main(argv=None):
     ap.add_argument("--atomic-dw", action="store_true",
                     help="weight gradients with fp32 atomics (the round-2 default) instead of the ordered, bit-reproducible reductions")
     ap.add_argument("--bwd-wpc", default=None, help="experiment: persistent workgroups per CU of the backward stream-K plans, 'DX,DW' (e.g. 1,1 or 2,1)")
+    ap.add_argument("--no-f32-split", action="store_true", help="Conv2d forward / input gradient on the fp32-MFMA kernels of rounds 3-4 (A/B of the split-fp32 kernel)")
     ap.add_argument("--no-streamk", action="store_true", help="all Conv2d launches on the 64x64 kernel of conv.hip (A/B of the persistent stream-K kernel)")
     ap.add_argument("--no-streamk-dw", action="store_true", help="weight gradients on the atomics kernel of conv.hip (A/B of the deterministic stream-K weight gradient)")
     ap.add_argument("--streamk-min-steps", type=int, default=None, help="experiment: K steps per tile from which a launch takes the stream-K kernel")
@@ -275,6 +283,7 @@ def main(argv=None):
         from speechdrivestemplates_amd import ops
         ops.OVERLAP_DW = not args.no_overlap_dw
         ops.USE_STREAMK = not args.no_streamk
+        ops.F32_SPLIT = not args.no_f32_split
         ops.USE_STREAMK_DW = not args.no_streamk and not args.no_streamk_dw
         if args.streamk_min_steps is not None:
             ops.STREAMK_MIN_STEPS = args.streamk_min_steps
@@ -548,7 +557,9 @@ def main(argv=None):
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16 (Conv2d chain: bf16 tensors in HBM, bf16 MFMA products, fp32 accumulation / statistics / master weights / gradients; "
                       "generator Conv1d chain: fp32 tensors, bf16 MFMA products; 1-D weight gradients, head, losses fp32)" if args.storage == "bf16" else
-                      ("f32" if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math)),
+                      (("f32 (Conv2d forward / input gradient: each fp32 operand split exactly into three bf16 numbers, six bf16 MFMA products per fp32 product, "
+                        "fp32 accumulation -- products exact to 2^-23; everything else fp32 arithmetic)" if (ops is not None and getattr(ops, "F32_SPLIT", False)) else "f32")
+                       if args.conv_math == "f32" else "f32 storage/accumulate, %s conv products (fwd+dX)" % args.conv_math)),
             "data": "synthetic",
             "config": {"workload": "%s: %d clips/GPU x %d GPU, 64 frames, 121-kpt network I/O (137-kpt clips), L=68266 audio, "
                                    "N=%d clip codes; full train_step (mel+G fwd/bwd+L1+KL+pose-encoder x2+f64 metrics+Adam)"
@@ -592,10 +603,13 @@ def main(argv=None):
             # accounting guard: an event window contains the launch, so algorithmic FLOPs / window can never exceed
             # the matrix peak -- if it does, the FLOP numerator counts work that does not exist (e.g. culled structural zeros)
             for kname, kd in summ.items():
-                assert kd["max_launch_tflops"] <= FP32_MATRIX_PEAK_TFLOPS or args.conv_math != "f32", \
-                    "%s: a launch 'achieved' %.1f TFLOP/s > fp32 matrix peak: FLOP accounting is wrong" % (kname, kd["max_launch_tflops"])
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                assert kd["max_launch_tflops"] <= matrix_peak_tflops(kname) or args.conv_math != "f32", \
+                    "%s: a launch 'achieved' %.1f TFLOP/s > its matrix peak: FLOP accounting is wrong" % (kname, kd["max_launch_tflops"])
+            peak = matrix_peak_tflops(name)
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
+                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                               "peak_is": ("dense bf16 MFMA peak (%.0f TFLOP/s) / 6: the split-fp32 kernel spends six bf16 MFMA products on every fp32 product"
+                                           % BF16_MATRIX_PEAK_TFLOPS) if peak != FP32_MATRIX_PEAK_TFLOPS else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                                "launches_per_step": d["launches"] / dom_steps, "avg_launch_us": avg_us,
                                "event_sampled_steps": dom_steps, "event_sampled_steps_all_kernels": prof_steps,
                                "measured": "HIP events on the launching stream, sampled steps of the timed region with the "
@@ -607,12 +621,13 @@ def main(argv=None):
             # the average above mixes them, the split shows each (role = forward / input gradient, 2-D / 1-D stage)
             out["roofline"]["by_role"] = {
                 r: {"launches_per_step": v[0] / dom_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
-                    "frac": v[2] / (v[1] * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS} for r, v in sorted(d["roles"].items())}
+                    "frac": v[2] / (v[1] * 1e-6) / 1e12 / peak} for r, v in sorted(d["roles"].items())}
             out["roofline"].update(cited_traffic(name))
             # the whole step against the fp32-MFMA floor of its convolutions: algorithmic conv FLOPs of a step / matrix peak / step time
             step_gflop = sum(v["flops"] for v in summ.values()) / prof_steps / 1e9
             out["roofline"]["step_gflop"] = step_gflop
-            out["roofline"]["step_frac"] = step_gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) / (clean_mean_ms * 1e-3)
+            out["roofline"]["step_frac"] = step_gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) / (clean_mean_ms * 1e-3)  # against the fp32-MFMA floor of rounds 1-4
+            out["conv_kernels_peak_tflops"] = {k: matrix_peak_tflops(k) for k in sorted(summ)}
             out["roofline"]["trace_based"] = cited_trace_fraction(name)
             if prof_ovl is not None and n_ovl > 0:
                 do = prof_ovl.summary()[name]

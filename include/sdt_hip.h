@@ -115,6 +115,9 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
 int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls);
 int sdt_convsk_grid(void);
 int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for plans built afterwards (default 2) */
+/* fp32 plans built afterwards with ONE workgroup per CU: the split-fp32 form of the 8-wave kernel (csrc/convbf.hip: each fp32 operand = three bf16
+ * planes made by the loader, six bf16 MFMAs per fragment pair -- products exact to 2^-23, fp32 accumulation).  Default 0. */
+int sdt_convsk_set_f32_split(int on);
 /* Workgroup slots (multiple of 8, < 256) that plans built afterwards leave free: a persistent launch that fills the GPU cannot share it with another
  * long-lived kernel (a collective's); data-parallel runs plan their backward launches with a reserve.  Default 0. */
 int sdt_convsk_set_reserved_slots(int n);

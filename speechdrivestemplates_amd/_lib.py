@@ -101,6 +101,7 @@ SIGNATURES = {
     "sdt_convsk_supported": [_G, _i],
     "sdt_convsk_grid": [],
     "sdt_convsk_set_wg_per_cu": [_i],
+    "sdt_convsk_set_f32_split": [_i],
     "sdt_convsk_set_reserved_slots": [_i],
     "sdt_convsk_plan_build": [_G, _i, _i, _i, _p, _i64],
     "sdt_convsk_dw_supported": [_G],

@@ -106,7 +106,7 @@ __device__ __forceinline__ void bf2_block_stats(const f32x16& a, const float* yv
 // Epilogue of accumulator rows [TMB, TME) x all TN column blocks of one wave: branch-free bf16 stores (pairs of columns as one dword, exchanged
 // between neighbouring lanes by DPP) and, EPI 1 / 2, the per-(group, channel) statistics from the fp32 accumulators.  sOut / sGrp: LDS, byte
 // offset of each tile row in Y (SK_OOB: none) and its statistics group.  row0: first tile row of the wave, ncol0: first output channel of the wave.
-template <int TM, int TN, int EPI, int TMB, int TME>
+template <typename OT, int TM, int TN, int EPI, int TMB, int TME>
 __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* sOut, const int* sGrp, const int row0, const int ncol0, const int lane,
                                              const float* __restrict__ bias, const __amdgpu_buffer_rsrc_t rsY, const int Cout,
                                              double* __restrict__ stats, const sk_norm_bwd& nb, const unsigned ybytes, float* red) {
@@ -121,14 +121,18 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
         for (int tm = TMB; tm < TME; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const unsigned nb2 = (unsigned)(ncol0 + tn * 32 + (lane & 31)) * 2u;
+                const unsigned nb2 = (unsigned)(ncol0 + tn * 32 + (lane & 31)) * (unsigned)sizeof(OT);
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int4 o4 = *(const int4*)&sOut[row0 + tm * 32 + 8 * qq + 4 * (lane >> 5)];
                     const int offs[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        yv[(tm - TMB) * TN + tn][4 * qq + e] = sk_bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rsNY, (int)((unsigned)offs[e] + nb2), 0, 0));
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (sizeof(OT) == 2)
+                            yv[(tm - TMB) * TN + tn][4 * qq + e] = sk_bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rsNY, (int)((unsigned)offs[e] + nb2), 0, 0));
+                        else
+                            yv[(tm - TMB) * TN + tn][4 * qq + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsNY, (int)((unsigned)offs[e] + nb2), 0, 0));
+                    }
                 }
             }
     }
@@ -143,6 +147,18 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int4 o4 = *(const int4*)&sOut[row0 + tm * 32 + 8 * qq + 4 * (lane >> 5)];
+                if constexpr (sizeof(OT) == 4) {  // fp32 output: a lane stores its own column, 32 lanes = 128 contiguous bytes of a row
+                    const int offs[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#if BF_ABL & 32
+                        asm volatile("" ::"v"(acc[tm][tn][4 * qq + e]), "v"(offs[e]));
+#else
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm][tn][4 * qq + e] + bv), rsY, (int)((unsigned)offs[e] + (unsigned)n * 4u), 0, 0);
+#endif
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float v0 = acc[tm][tn][4 * qq + 2 * h] + bv, v1 = acc[tm][tn][4 * qq + 2 * h + 1] + bv;
@@ -243,11 +259,72 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
     }
 }
 
+// ---- The SPLIT-fp32 form (X3; fp32 tensors in HBM, fp32-grade results at the bf16 matrix rate).
+// A fp32 number is the exact sum of three bf16 numbers: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (8 + 8 + 8 significand bits;
+// both differences are exact in fp32).  A product a * b is then nine bf16 x bf16 products, each EXACT in the fp32 accumulator; the kernel adds six
+// of them -- lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi -- and drops mid*lo, lo*mid, lo*lo, at most 2^-24 + 2^-24 + 2^-32 of |a b|: less than the
+// rounding of ONE fp32 addition (2^-24 of the running sum), of which a dot product of K terms makes K.  Six v_mfma_f32_32x32x16_bf16 do the
+// work of eight v_mfma_f32_32x32x2_f32 in 6 / 64 of the matrix-pipe time... (16x the rate, 6x the instructions: 2.7x faster at the pipe's peak).
+// The split is made ONCE per loaded element, by the loader thread between its global load and its LDS store (11 VALU instructions per pair of
+// elements), not per MFMA: LDS holds the three planes, a K step is 32 channels = 128 bytes of a fp32 row (the fp32 plan's step) = two k-groups
+// of 6 NM MFMAs.  Bytes per MFMA cycle are a third of the bf16 kernel's, which is what that kernel was short of (profiles/r05_bf2_experiments.txt).
+// Inf operands turn into NaN (inf - inf in the split), as they would after one more layer in fp32.
+#define X3_ROW 16  // floats per LDS row of one plane: 32 bf16 channels
+__device__ __forceinline__ void x3_stage(float* dst, const int plane_stride, const f32x4 v) {
+    unsigned h[2], m[2], l[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float x0 = v[2 * p], x1 = v[2 * p + 1];
+        sk_bf16x2 pk;
+        pk[0] = (__bf16)x0, pk[1] = (__bf16)x1;
+        h[p] = __builtin_bit_cast(unsigned, pk);
+        const float r0 = x0 - __uint_as_float(h[p] << 16), r1 = x1 - __uint_as_float(h[p] & 0xffff0000u);
+        pk[0] = (__bf16)r0, pk[1] = (__bf16)r1;
+        m[p] = __builtin_bit_cast(unsigned, pk);
+        const float s0 = r0 - __uint_as_float(m[p] << 16), s1 = r1 - __uint_as_float(m[p] & 0xffff0000u);
+        pk[0] = (__bf16)s0, pk[1] = (__bf16)s1;
+        l[p] = __builtin_bit_cast(unsigned, pk);
+    }
+    *(uint2*)dst = uint2{h[0], h[1]};
+    *(uint2*)(dst + plane_stride) = uint2{m[0], m[1]};
+    *(uint2*)(dst + 2 * plane_stride) = uint2{l[0], l[1]};
+}
+
+// sched_group_barrier templates of an X3 K step (literal counts, hence the recursion).  Region 1, per MFMA q of NQ: one fragment read while any are
+// left, the VALU share of the splits (NL x 24 instructions over the first NQ - 2 MFMAs), one LDS store every other MFMA, one request every NQ / NL.
+template <int Q, int NQ, int NR, int NL>
+__device__ __forceinline__ void x3_pattern() {
+    if constexpr (Q < NQ) {
+        SK_SGB(0x8, 1);
+        if constexpr (Q < NR) SK_SGB(0x100, 1);
+        constexpr int NV = NL * 24, per = (NV + NQ - 3) / (NQ - 2);
+        if constexpr (Q * per < NV) SK_SGB(0x2, per);
+        constexpr int NW = NL * 3, w0 = Q * NW / NQ, w1 = (Q + 1) * NW / NQ;
+        if constexpr (Q >= 2 && w1 > w0) SK_SGB(0x200, w1 - w0);
+        constexpr int l0 = Q * NL / NQ, l1 = (Q + 1) * NL / NQ;
+        if constexpr (Q >= 3 && l1 > l0) SK_SGB(0x20, l1 - l0);
+        x3_pattern<Q + 1, NQ, NR, NL>();
+    }
+}
+template <int Q, int NQ, int NR>
+__device__ __forceinline__ void x3_pattern2() {
+    if constexpr (Q < NQ) {
+        SK_SGB(0x8, 1);
+        constexpr int r0 = Q * NR / NQ, r1 = (Q + 1) * NR / NQ;
+        if constexpr (r1 > r0) SK_SGB(0x100, r1 - r0);
+        x3_pattern2<Q + 1, NQ, NR>();
+    }
+}
+
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
-template <int BM, int BN, int WGM, int WGN, int EPI>
-__global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W, const float* __restrict__ bias,
-                                                          __bf16* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
+// ET = __bf16: bf16 tensors, one MFMA per fragment pair.   ET = float: the SPLIT-fp32 form (X3) -- see the note above x3_split.
+template <typename ET, int BM, int BN, int WGM, int WGN, int EPI>
+__global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict__ X, const ET* __restrict__ W, const float* __restrict__ bias,
+                                                          ET* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
+    constexpr bool X3 = sizeof(ET) == 4;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32, RA = BM / 64, RB = BN / 64, NM = TM * TN, NF = TM + TN;
+    // LDS floats per buffer of A / B.  bf16: [row][128 B + 16 B pad].  X3: [plane hi / mid / lo][row][64 B], 16-byte chunks XOR-swizzled by (row >> 2) & 3
+    constexpr int A_BUF = X3 ? 3 * BM * X3_ROW : BM * SK_LDP, B_BUF = X3 ? 3 * BN * X3_ROW : BN * SK_LDP;
     // Staging register sets = how many K steps a request has to land before its data is stored to LDS: two when the accumulators leave room.
     // (Three / four sets were measured, profiles/r05_bf2_experiments.txt: no gain -- the waves wait for their operands at ANY prefetch depth, the
     // delivery RATE of ~24 B/clk per CU is what a step waits for, not the latency of one request.)
@@ -255,9 +332,9 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     constexpr int UNR = (NSET % 2 == 0) ? (NSET < 2 ? 2 : NSET) : 2 * NSET;  // period of (LDS buffer parity, staging set)
     static_assert(WGM * WGN == 8 && TM >= 1 && TN >= 1 && RB >= 1, "wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                          // [2][BM * LDP]
-    float* sB = smem + 2 * BM * SK_LDP;        // [2][BN * LDP]
-    int* sOutB = (int*)(sB + 2 * BN * SK_LDP);  // [2][BM] byte offset of the tile's output rows in Y (SK_OOB, negative as int: none)
+    float* sA = smem;                          // [2][A_BUF]
+    float* sB = smem + 2 * A_BUF;              // [2][B_BUF]
+    int* sOutB = (int*)(sB + 2 * B_BUF);        // [2][BM] byte offset of the tile's output rows in Y (SK_OOB, negative as int: none)
     int* sGrpB = sOutB + 2 * BM;                // [2][BM] statistics group of each row (EPI 1 / 2)
     int2* sRowB = (int2*)(sGrpB + 2 * BM);      // [2][BM] {X byte offset of the row's (0,0) tap, mask of the taps outside X}: the loader's row table
     int* sFlagOkp = (int*)(sRowB + 2 * BM);     // [4]
@@ -277,9 +354,13 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)P.ybytes, 0x00020000);
 
     const int row0 = wm * (TM * 32), col0 = wn * (TN * 32);
-    const int fa = (row0 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
-    const int fb = (col0 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
-    const int wofs = r0 * SK_LDP + kv * 4;
+    // fragment of k-group J: bf16 -- 16 bytes at J * 32 + (lane >> 5) * 16 of the lane's row;  X3 -- chunk (2 J + (lane >> 5)) ^ swizzle of the lane's row
+    const int fsw = (lane >> 2) & 3;  // (row0, col0 and the 32-row blocks are multiples of 32: the swizzle of a lane's row is the lane's)
+    const int fa = X3 ? (row0 + (lane & 31)) * X3_ROW : (row0 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    const int fb = X3 ? (col0 + (lane & 31)) * X3_ROW : (col0 + (lane & 31)) * SK_LDP + (lane >> 5) * 4;
+    const int fk0 = (((lane >> 5)) ^ fsw) * 4, fk1 = ((2 + (lane >> 5)) ^ fsw) * 4;  // X3: float offset of the lane's chunk of k-group 0 / 1
+    // loader thread (r0, kv): 16 bytes = 8 bf16 channels (bf16) / 4 fp32 channels that become 8 bytes per plane (X3)
+    const int wofs = X3 ? r0 * X3_ROW + ((((kv >> 1) ^ ((r0 >> 2) & 3)) * 4) + (kv & 1) * 2) : r0 * SK_LDP + kv * 4;
 
     // ---- the walk over the range's tiles: cursor (tile, class c, m-tile mt, n-tile nt)
     struct Cursor {
@@ -380,14 +461,24 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         if (i < RA) asm volatile("" ::"v"(ra[S_][i]));
         else if (i < RA + RB) asm volatile("" ::"v"(rb[S_][i - RA]));
 #else
-        if (i < RA) *(f32x4*)&sA[buf * BM * SK_LDP + wofs + 64 * i * SK_LDP] = ra[S_][i];
-        else if (i < RA + RB) *(f32x4*)&sB[buf * BN * SK_LDP + wofs + 64 * (i - RA) * SK_LDP] = rb[S_][i - RA];
+        if constexpr (X3) {
+            if (i < RA) x3_stage(sA + buf * A_BUF + wofs + 64 * i * X3_ROW, BM * X3_ROW, ra[S_][i]);
+            else if (i < RA + RB) x3_stage(sB + buf * B_BUF + wofs + 64 * (i - RA) * X3_ROW, BN * X3_ROW, rb[S_][i - RA]);
+        } else {
+            if (i < RA) *(f32x4*)&sA[buf * A_BUF + wofs + 64 * i * SK_LDP] = ra[S_][i];
+            else if (i < RA + RB) *(f32x4*)&sB[buf * B_BUF + wofs + 64 * (i - RA) * SK_LDP] = rb[S_][i - RA];
+        }
 #endif
     };
     auto stage = [&](auto SI, const int buf) {
         constexpr int S_ = decltype(SI)::value;
-        float* wA = sA + buf * BM * SK_LDP + wofs;
-        float* wB = sB + buf * BN * SK_LDP + wofs;
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < RA + RB; ++i) stage_op(SI, buf, i);
+            return;
+        }
+        float* wA = sA + buf * A_BUF + wofs;
+        float* wB = sB + buf * B_BUF + wofs;
 #if BF_ABL & 2
 #pragma unroll
         for (int i = 0; i < RA; ++i) asm volatile("" ::"v"(ra[S_][i]));
@@ -454,7 +545,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         f.b = min(s_end, f.tend) - f.tbeg;
         f.n0 = k.nt * BN;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * 2u + (unsigned)kv * 16u;  // W is (N, Tw, Cin) bf16
+        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * (unsigned)sizeof(ET) + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
         rmask = (unsigned)__builtin_amdgcn_readfirstlane(t.ti_mask);
         rot = __builtin_amdgcn_readfirstlane(t.ti_rot);
         for (int skip = f.a / nkc; skip > 0; --skip) rmask &= rmask - 1;
@@ -472,7 +563,8 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     typedef std::integral_constant<int, 0> I0;
 
     f32x16 acc[TM][TN];
-    f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+    f32x4 a0[X3 ? 1 : TM], b0[X3 ? 1 : TN], a1[X3 ? 1 : TM], b1[X3 ? 1 : TN];
+    f32x4 xa[X3 ? 2 : 1][X3 ? 3 : 1][X3 ? TM : 1], xb[X3 ? 2 : 1][X3 ? 3 : 1][X3 ? TN : 1];  // X3: [k-group parity][plane hi / mid / lo][32-row block]
 #if BF_ABL & 16
 #define BF_READ(A, B, PA, PB, J)                                                                        \
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(A[tm]) : "v"(PA));           \
@@ -501,7 +593,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
     // request half of a step in opposite order -- 2094 -> 3247 cycles per step: clustered requests wait for each other.)
     auto stage_slot = [](const int i) constexpr { return i * 3 * NM / NL; };
     auto load_slot = [](const int i) constexpr { return i * 4 * NM / NL; };
-    auto rd = [&](f32x4 (&A)[TM], f32x4 (&B)[TN], const float* pa, const float* pb, const int J, const int i) {
+    auto rd = [&](auto& A, auto& B, const float* pa, const float* pb, const int J, const int i) {
 #if BF_ABL & 16
         if (i < TM) asm volatile("" : "+v"(A[i]) : "v"(pa));
         else if (i < NF) asm volatile("" : "+v"(B[i - TM]) : "v"(pb));
@@ -510,13 +602,92 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         else if (i < NF) B[i - TM] = *(const f32x4*)(pb + (i - TM) * 32 * SK_LDP + J * 8);
 #endif
     };
+    // ---- X3: fragment i of a k-group's 3 NF fragments, in the order the MFMAs want them: A lo, B hi, A hi, B lo, A mid, B mid
+    auto x3_rd = [&](const int set, const float* pa, const float* pb, const int fk, const int i) {
+        if constexpr (X3) {
+            constexpr int PL[6] = {2, 0, 0, 2, 1, 1};
+            int seg = 0, k = i;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int len = (g & 1) ? TN : TM;
+                if (k >= len && seg == g) {
+                    k -= len;
+                    ++seg;
+                }
+            }
+            if (seg >= 6) return;
+            const int pl = PL[seg];
+#if BF_ABL & 16
+            if (!(seg & 1)) asm volatile("" : "+v"(xa[set][pl][k]) : "v"(pa));
+            else asm volatile("" : "+v"(xb[set][pl][k]) : "v"(pb));
+#else
+            if (!(seg & 1)) xa[set][pl][k] = *(const f32x4*)(pa + pl * BM * X3_ROW + k * 32 * X3_ROW + fk);
+            else xb[set][pl][k] = *(const f32x4*)(pb + pl * BN * X3_ROW + k * 32 * X3_ROW + fk);
+#endif
+        }
+    };
+    // One X3 K step (32 channels = two k-groups of 6 NM MFMAs) on LDS buffer `cur`; the fragments of k-group 0 are in set 0 on entry and on exit.
+    // Two scheduling regions around the step's one barrier (after MFMA 9 NM of 12 NM):
+    //   region 1: the other k-group's 3 NF fragment reads, the split + LDS stores of step s + 1 (NL x (22 VALU + 3 ds_write_b64)), the requests of
+    //             step s + 2 -- spread over the 9 NM MFMAs by sched_group_barrier: the split's VALU chains must run UNDER the MFMAs (a whole
+    //             operand's 25 instructions between two MFMAs left the matrix pipe idle for 70 of every 100 cycles: 40-50 % of the peak in the loop)
+    //   region 2: the NEXT step's k-group-0 fragments (LDS[next] is complete behind the barrier) under the last 3 NM MFMAs.
+    auto step3 = [&](auto CUR, auto SETN) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small products first
+            constexpr int NS = 12 * NM, NR = 3 * NF, BAR = 9 * NM;
+            const float* pa = sA + cur * A_BUF + fa;
+            const float* pb = sB + cur * B_BUF + fb;
+            const float* pan = sA + nx * A_BUF + fa;
+            const float* pbn = sB + nx * B_BUF + fb;
+            load_prep();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 1
+#pragma unroll
+            for (int i = 0; i < NR; ++i) x3_rd(1, pa, pb, fk1, i);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                stage_op(SETN, nx, j);
+                load_op(SETN, j);
+            }
+#pragma unroll
+            for (int q = 0; q < BAR; ++q) {
+                const int J = q / (6 * NM), pr = (q % (6 * NM)) / NM, t = q % NM;
+                BF_MFMA(acc[t / TN][t % TN], xa[J][PA[pr]][t / TN], xb[J][PB[pr]][t % TN]);
+            }
+            x3_pattern<0, BAR, NR, NL>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my stores to LDS[next] are done
+#if !(BF_ABL & 8)
+            __builtin_amdgcn_s_barrier();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 2
+#pragma unroll
+            for (int i = 0; i < NR; ++i) x3_rd(0, pan, pbn, fk0, i);
+#pragma unroll
+            for (int q = BAR; q < NS; ++q) {
+                const int J = q / (6 * NM), pr = (q % (6 * NM)) / NM, t = q % NM;
+                BF_MFMA(acc[t / TN][t % TN], xa[J][PA[pr]][t / TN], xb[J][PB[pr]][t % TN]);
+            }
+            x3_pattern2<0, NS - BAR, NR>();
+            __builtin_amdgcn_sched_barrier(0);
+            load_advance();
+        }
+    };
+
     auto step = [&](auto CUR, auto SETI) __attribute__((always_inline)) {
         constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
         typedef decltype(SETI) SETN;
-        const float* pa = sA + cur * BM * SK_LDP + fa;
-        const float* pb = sB + cur * BN * SK_LDP + fb;
-        const float* pan = sA + nx * BM * SK_LDP + fa;
-        const float* pbn = sB + nx * BN * SK_LDP + fb;
+        if constexpr (X3) {
+            step3(CUR, SETI);
+            return;
+        }
+        const float* pa = sA + cur * A_BUF + fa;
+        const float* pb = sB + cur * B_BUF + fb;
+        const float* pan = sA + nx * A_BUF + fa;
+        const float* pbn = sB + nx * B_BUF + fb;
         load_prep();
         __builtin_amdgcn_sched_barrier(0);
         auto ops = [&](const int q) {  // the stores / requests that belong to slot q of the step
@@ -585,6 +756,27 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
         rec(rec, std::integral_constant<int, 0>{});
     };
 
+    f32x16 tot[X3 ? TM : 1][X3 ? TN : 1];  // X3: the sum of the finished accumulation chunks
+    auto x3_flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    tot[X3 ? i : 0][X3 ? j : 0][q] += acc[i][j][q];
+                    acc[i][j][q] = 0.f;
+                }
+    };
+    auto x3_flush_final = [&]() {  // acc = the tile's (partial) sum, where the end phase expects it
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] += tot[X3 ? i : 0][X3 ? j : 0][q];
+    };
+
     // running column statistics of this workgroup's range (threads tid < BN: column n0 + tid of group run_g)
     int run_g = -1, run_n0 = 0, run_cout = 0;
     float run_s = 0.f, run_q = 0.f;
@@ -623,17 +815,36 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-        BF_READ(a0, b0, sA + fa, sB + fb, 0);
+                for (int q = 0; q < 16; ++q) {
+                    acc[i][j][q] = 0.f;
+                    if constexpr (X3) tot[i][j][q] = 0.f;
+                }
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < 3 * NF; ++i) x3_rd(0, sA + fa, sB + fb, fk0, i);
+        } else {
+            BF_READ(a0, b0, sA + fa, sB + fb, 0);
+        }
         const int nsteps = F.b - F.a;
         BF_TL(1, wall_clock64());
         BF_TL(5, (unsigned long long)nsteps);
         int s = 0;
         // the K loop, unrolled over the period of (LDS buffer, staging set): step u of a period reads LDS[u & 1] and stores / re-requests set (u + 1) % NSET
+        if constexpr (X3) {
+            // fp32-grade sums: the accumulators are added to `tot` and cleared every SK_CHUNK steps (256 channels x taps), as the fp32 kernel does --
+            // a running fp32 sum over a whole 4096-term K loop carries 1.5x the rounding error of the blocked one (tools/debug/x3_check.py)
+            static_assert(SK_CHUNK % UNR == 0, "chunks are whole periods");
+            for (; s + SK_CHUNK <= nsteps; s += SK_CHUNK) {
+#pragma unroll 1
+                for (int u = 0; u < SK_CHUNK; u += UNR) steps_unrolled(std::integral_constant<int, 0>{}, UNR);
+                x3_flush();
+            }
+        }
         for (; s + UNR <= nsteps; s += UNR) {
             steps_unrolled(std::integral_constant<int, 0>{}, UNR);
         }
         steps_unrolled(std::integral_constant<int, 0>{}, nsteps - s);
+        if constexpr (X3) x3_flush_final();
         BF_TL(2, wall_clock64());
 #if BF_ABL & 64
 #pragma unroll
@@ -731,18 +942,18 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
             // per column when they change and at the end of the range)
             const int tgrp = sGrp[0];
             const bool tile_uniform = EPI != 0 && TM % 2 == 0 && tgrp >= 0 && tgrp == sGrp[BM - 1];
-            float* red = tile_uniform ? sA + BM * SK_LDP + (wm * BN + col0) * 2 : nullptr;  // (LDS buffer 1 of A is idle until the next tile's first step)
+            float* red = tile_uniform ? sA + A_BUF + (wm * BN + col0) * 2 : nullptr;  // (LDS buffer 1 of A is idle until the next tile's first step)
             if constexpr (EPI == 2 && TM > 2) {  // the reads of y for half of the rows at a time: 64 instead of 128 registers
-                bf2_epilogue<TM, TN, EPI, 0, TM / 2>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
-                bf2_epilogue<TM, TN, EPI, TM / 2, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
+                bf2_epilogue<ET, TM, TN, EPI, 0, TM / 2>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
+                bf2_epilogue<ET, TM, TN, EPI, TM / 2, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
             } else {
-                bf2_epilogue<TM, TN, EPI, 0, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
+                bf2_epilogue<ET, TM, TN, EPI, 0, TM>(acc, sOut, sGrp, row0, E.n0 + col0, lane, bias, rsY, E.Cout, stats, nb, P.ybytes, red);
             }
             if constexpr (EPI != 0) {
                 if (tile_uniform) {
                     BF_LDS_BARRIER();
                     if (tid < BN) {
-                        const float* rr = sA + BM * SK_LDP + tid * 2;
+                        const float* rr = sA + A_BUF + tid * 2;
                         float ts = 0.f, tq = 0.f;
 #pragma unroll
                         for (int w = 0; w < WGM; ++w) {  // fixed order
@@ -770,30 +981,43 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const __bf16* __restr
 #undef sFlagOk
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI>
+template <typename ET, int BM, int BN, int WGM, int WGN, int EPI>
 static void bf2_launch_one(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (BM + BN) * SK_LDP) * 4 + (size_t)8 * BM * 4 + 16;  // A / B tiles, sOut + sGrp + sRow (double-buffered), flag
+    // A / B tiles (double-buffered; X3: three planes of 64 B per row), sOut + sGrp + sRow (double-buffered), flag
+    const size_t tiles = sizeof(ET) == 4 ? (size_t)(2 * 3 * (BM + BN) * X3_ROW) * 4 : (size_t)(2 * (BM + BN) * SK_LDP) * 4;
+    const size_t lds = tiles + (size_t)8 * BM * 4 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)convbf2_kernel<BM, BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)convbf2_kernel<ET, BM, BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((convbf2_kernel<BM, BN, WGM, WGN, EPI>), dim3(A.G), dim3(BF_NT), lds, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, A, stats, nb);
+    hipLaunchKernelGGL((convbf2_kernel<ET, BM, BN, WGM, WGN, EPI>), dim3(A.G), dim3(BF_NT), lds, s, (const ET*)x, (const ET*)w, bias, (ET*)y, A, stats, nb);
 }
+
+#define BF2_GO(ET_, BM_, BN_, WGM_, WGN_)                                                              \
+    do {                                                                                                \
+        if (epi == 0) bf2_launch_one<ET_, BM_, BN_, WGM_, WGN_, 0>(x, w, bias, y, A, stats, nb, s);     \
+        else if (epi == 1) bf2_launch_one<ET_, BM_, BN_, WGM_, WGN_, 1>(x, w, bias, y, A, stats, nb, s); \
+        else bf2_launch_one<ET_, BM_, BN_, WGM_, WGN_, 2>(x, w, bias, y, A, stats, nb, s);              \
+    } while (0)
 
 int convbf2_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
                    hipStream_t s) {
-#define BF2_GO(BM_, BN_, WGM_, WGN_)                                                              \
-    do {                                                                                           \
-        if (epi == 0) bf2_launch_one<BM_, BN_, WGM_, WGN_, 0>(x, w, bias, y, A, stats, nb, s);     \
-        else if (epi == 1) bf2_launch_one<BM_, BN_, WGM_, WGN_, 1>(x, w, bias, y, A, stats, nb, s); \
-        else bf2_launch_one<BM_, BN_, WGM_, WGN_, 2>(x, w, bias, y, A, stats, nb, s);              \
-    } while (0)
-    if (bm == 256 && bn == 256) BF2_GO(256, 256, 2, 4);
-    else if (bm == 256 && bn == 128) BF2_GO(256, 128, 4, 2);
-    else if (bm == 256 && bn == 64) BF2_GO(256, 64, 4, 2);
-    else if (bm == 128 && bn == 128) BF2_GO(128, 128, 2, 4);  // few-row layers (L5 - L7 at 32 clips): 64 x 32 per wave, about one tile per CU
+    if (bm == 256 && bn == 256) BF2_GO(__bf16, 256, 256, 2, 4);
+    else if (bm == 256 && bn == 128) BF2_GO(__bf16, 256, 128, 4, 2);
+    else if (bm == 256 && bn == 64) BF2_GO(__bf16, 256, 64, 4, 2);
+    else if (bm == 128 && bn == 128) BF2_GO(__bf16, 128, 128, 2, 4);  // few-row layers (L5 - L7 at 32 clips): 64 x 32 per wave, about one tile per CU
     else return SDT_ERR_ARG;
-#undef BF2_GO
     return SDT_OK;
 }
+
+// fp32 tensors, split-fp32 products (plans built with sdt_convsk_set_f32_split(1)): 128 x 128 tiles, 256 x 64 for the 64-channel outputs -- 64 x 32
+// per wave: two accumulator sets (running chunk + chunk sums) and two fragment sets of three planes fit 256 registers; 64 x 64 per wave does not
+int convx3_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
+                  hipStream_t s) {
+    if (bm == 256 && bn == 64) BF2_GO(float, 256, 64, 4, 2);
+    else if (bm == 128 && bn == 128) BF2_GO(float, 128, 128, 2, 4);
+    else return SDT_ERR_ARG;
+    return SDT_OK;
+}
+#undef BF2_GO

@@ -83,3 +83,6 @@ __device__ __forceinline__ void sk_bf_interleave() {
 // convbf.hip: launch of the bf16-shaped kernel (256-row tiles, 8 waves, one workgroup per CU) for a plan built with one workgroup per CU (256 x {256,128,64} or 128 x 128 tiles)
 int convbf2_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
                    hipStream_t s);
+// ... and of its split-fp32 form (fp32 tensors; three bf16 planes made by the loader, six bf16 MFMAs per fragment pair): 256 x {128,64} or 128 x 128 tiles
+int convx3_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
+                  hipStream_t s);

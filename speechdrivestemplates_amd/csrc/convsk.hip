@@ -1136,12 +1136,24 @@ static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, in
 
 // tile and grid from the workgroups-per-CU setting and the element size.  bf16 operands with ONE workgroup per CU: the bf16-shaped kernel of
 // convbf.hip -- 256-row tiles as wide as the layer (256 / 128 / 64 columns), 8 waves; a reserve of n slots leaves n / 2 of its CUs free.
-static bool is_bf2(int esz) { return esz == 2 && g_sk_wpc == 1; }
+// fp32 operands with ONE workgroup per CU and sdt_convsk_set_f32_split(1): the same kernel in its split-fp32 form (three bf16 planes per operand
+// made by the loader, six bf16 MFMAs per fragment pair; 128 x 128 / 256 x 64 tiles: see convx3_launch).
+static int g_sk_split = 0;
+extern "C" int sdt_convsk_set_f32_split(int on) {
+    g_sk_split = on ? 1 : 0;
+    return SDT_OK;
+}
+static bool is_x3(int esz) { return esz == 4 && g_sk_wpc == 1 && g_sk_split; }
+static bool is_bf2(int esz) { return (esz == 2 && g_sk_wpc == 1) || is_x3(esz); }  // "one 8-wave workgroup per CU" plans
 static void plan_shape(const sdt_conv_geom& g, int esz, int& bm, int& bn, int& G) {
     if (is_bf2(esz)) {
         G = (256 - g_sk_reserve / 2) & ~7;
         bm = 256;
-        bn = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
+        bn = (g.Cout % 256 == 0 && esz == 2) ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
+        if (esz == 4) {  // split-fp32 form: 64 x 32 per wave (128 x 128, or 256 x 64 for the 64-channel outputs)
+            bm = bn == 128 ? 128 : 256;
+            return;
+        }
         // few rows (L5 - L7 at 32 clips: 16960 / 16960 / 8160): 256-row tiles would be fewer than CUs and every one of them cut between several
         // workgroups -- 128 x 128 tiles instead (about one whole tile per CU: no slab hand-off for most of them)
         const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
@@ -1400,7 +1412,7 @@ static int plan_build(const sdt_conv_geom* geoms, int ncls, int rows_per_group, 
         range_tile[r] = (int)tile;
     }
     // P[3]: grid | workgroups per CU << 16 | (X / W are bf16) << 24 | (Y is bf16) << 25
-    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24) | ((ysz == 2) << 25), P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
+    P[0] = SK_MAGIC, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24) | ((ysz == 2) << 25) | ((int)is_x3(esz) << 26), P[4] = ncls, P[5] = nnb | ((int)ntmajor << 16), P[6] = (int)T, P[7] = (int)S, P[8] = (int)rows, P[9] = (int)mts;
     P[10] = (int)o_row, P[11] = (int)o_ti, P[12] = (int)o_cum, P[13] = (int)o_rt, P[14] = (int)o_cls, P[15] = (int)(o_cls + (int64_t)ncls * SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1495,7 +1507,10 @@ static int sk_go(const void* x, const void* w, const float* bias, void* y, const
         else if (epi == 1) sk_launch<TX_, TY_, BM_, BN_, 1, WPC_>(x, w, bias, y, A, stats, 0, nb, s); \
         else sk_launch<TX_, TY_, BM_, BN_, 2, WPC_>(x, w, bias, y, A, stats, 0, nb, s);               \
     } while (0)
-    if (!xbf && !ybf) {
+    if (!xbf && !ybf && ((P[3] >> 26) & 1)) {
+        rc = convx3_launch(x, w, bias, y, A, stats, nb, bm, bn, epi, s);
+        SDT_CHECK_ARG(rc == SDT_OK, "plan with a tile shape the split-fp32 kernel is not built for");
+    } else if (!xbf && !ybf) {
         if (bm == 128 && bn == 128 && wpc == 1) SK_GO(float, float, 128, 128, 1);
         else if (bm == 128 && bn == 128 && wpc == 2) SK_GO(float, float, 128, 128, 2);
         else if (bm == 256 && bn == 64 && wpc == 1) SK_GO(float, float, 256, 64, 1);

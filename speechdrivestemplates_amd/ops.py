@@ -472,7 +472,8 @@ class _SKPlan:
         lib = _lib.load()
         self.kind, self.dtype = "sk", dtype
         check(lib.sdt_convsk_set_reserved_slots(int(reserve)))  # process-wide knobs of the plan builder: set, build, reset
-        check(lib.sdt_convsk_set_wg_per_cu(int(wpc)))
+        check(lib.sdt_convsk_set_wg_per_cu(1 if int(wpc) == 3 else int(wpc)))  # wpc 3: one workgroup per CU, the split-fp32 form (fp32 tensors)
+        check(lib.sdt_convsk_set_f32_split(1 if int(wpc) == 3 else 0))
         try:
             nbytes = lib.sdt_convsk_plan_bytes_t(garr, n, dtype)
             if nbytes <= 0:
@@ -482,6 +483,7 @@ class _SKPlan:
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
             check(lib.sdt_convsk_set_wg_per_cu(2))
+            check(lib.sdt_convsk_set_f32_split(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
 
 
@@ -521,6 +523,9 @@ def clear_plans():
     _SK_DW_PLANS.clear()
 
 
+# fp32 tensors: the split-fp32 form of that kernel (three bf16 planes per operand made by the loader, six bf16 MFMAs per fragment pair, fp32-grade
+# products at 2.7x the fp32 matrix rate) wherever it plans; False: the fp32-MFMA kernels of rounds 3-4 everywhere (SYS.CONV_F32_SPLIT)
+F32_SPLIT = True
 BF16_SHAPED = True  # bf16 tensors: the 256-row / 8-wave kernel of csrc/convbf.hip (one workgroup per CU) wherever a launch has >= 4 K steps per range
 
 
@@ -532,6 +537,10 @@ def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0, wpc=None):
         # the bf16-shaped kernel first (plans with one workgroup per CU); small launches fall back to the round-4 128-row kernel (two per CU)
         plan = _sk_plan(garr, n, rpg, bwd_groups, dev, forward, dtype, 1) if BF16_SHAPED else None
         return plan if plan is not None else _sk_plan(garr, n, rpg, bwd_groups, dev, forward, dtype, 2)
+    if dtype == _lib.F32 and wpc is None and F32_SPLIT and USE_STREAMK:
+        plan = _sk_plan(garr, n, rpg, bwd_groups, dev, forward, dtype, 3)
+        if plan is not None:
+            return plan
     if wpc is None:
         wpc = 2 if forward else int(SK_WPC_DX)
     key = (_geom_key(garr), n, int(rpg), int(bwd_groups), dev.index, bool(forward), reserve, dtype,
@@ -541,7 +550,7 @@ def _sk_plan(garr, n, rpg, bwd_groups, dev, forward=False, dtype=0, wpc=None):
         lib = _lib.load()
         plan = None
         g0 = garr if isinstance(garr, ConvGeom) else garr[0]
-        want = lib.sdt_convsk_supported_t(garr, n, dtype) and (dtype == _lib.BF16 or (USE_STREAMK and _sk_wanted(g0, forward)))
+        want = lib.sdt_convsk_supported_t(garr, n, dtype) and (dtype == _lib.BF16 or wpc == 3 or (USE_STREAMK and _sk_wanted(g0, forward)))
         if want:
             try:
                 plan = _SKPlan(garr, n, rpg, bwd_groups, dev, dtype, reserve, wpc)
@@ -673,6 +682,8 @@ def prepare_capture_stream(dev, stream):
 def _sk_name(plan):
     if plan.dtype == _lib.BF16 and (plan.host[3] >> 16) & 0xff == 1:  # one workgroup per CU: the bf16-shaped kernel
         return "convbf2_kernel<%d, %d>" % (plan.host[1], plan.host[2])
+    if (plan.host[3] >> 26) & 1:  # ... in its split-fp32 form
+        return "convbf2_kernel<float, %d, %d>" % (plan.host[1], plan.host[2])
     return "convsk_kernel<%d, %d>" % (plan.host[1], plan.host[2])
 
 def _splitk_hint(lib, g):

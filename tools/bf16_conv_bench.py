@@ -49,10 +49,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-dw", action="store_true", help="skip the weight-gradient launches")
+    ap.add_argument("--split", type=int, default=1, help="--dtype f32: 1 = the split-fp32 form of the 8-wave kernel (ops.F32_SPLIT), 0 = the fp32-MFMA kernels")
     ap.add_argument("--old", action="store_true", help="the round-4 128-row bf16 kernels (ops.BF16_SHAPED = False) instead of the bf16-shaped ones")
     a = ap.parse_args()
     B, dev = a.batch, "cuda"
     ops.BF16_SHAPED = not a.old
+    ops.F32_SPLIT = bool(a.split)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tot = {"fwd": 0.0, "dX": 0.0, "dW": 0.0}
     print("%-4s %10s | %8s %8s | %8s %8s | %8s %8s   (us, TFLOP/s; %s tensors, B=%d)" % ("", "GFLOP", "fwd", "", "dX", "", "dW", "", a.dtype, B))

@@ -28,6 +28,7 @@ def main():
                     "stamps: segment start, fill done, K loop done, next tile's set-up + first request issued, end phase done")
     a = ap.parse_args()
     ops.BF16_SHAPED = bool(a.bf2)
+    ops.F32_SPLIT = bool(a.bf2) and a.dtype == "f32"  # --dtype f32 --bf2: the split-fp32 form of the 8-wave kernel
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     lib = _lib.load()
     set_tl = lib.sdt_debug_set_timeline_bf2 if a.bf2 else lib.sdt_debug_set_timeline_sk
@@ -82,7 +83,8 @@ def main():
             for k, v in ph.items():
                 print("    %-36s median %6.2f us  p90 %6.2f  max %6.2f   sum per workgroup %.1f us" % (k, np.median(v), np.percentile(v, 90), v.max(), v.sum() / (nseg > 0).sum()))
             per_step = ph["K loop"] / np.maximum(steps, 1)
-            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles)" % (np.median(per_step), np.median(per_step) * 2380, 512 if a.dtype == "bf16" else 4096))
+            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles per SIMD)" % (np.median(per_step), np.median(per_step) * 2380,
+                                                                                                         (1024 if a.dtype == "bf16" else 3072) if a.bf2 else (512 if a.dtype == "bf16" else 4096)))
             for kk, nm in ((0, "whole"), (1, "owner"), (2, "publish")):
                 sel = kind == kk
                 if sel.any():
