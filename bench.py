@@ -47,7 +47,7 @@ SPLIT_F32_PEAK_TFLOPS = BF16_MATRIX_PEAK_TFLOPS / 6.0
 
 
 def matrix_peak_tflops(kernel_name):
-    return SPLIT_F32_PEAK_TFLOPS if kernel_name.startswith("convbf2_kernel<float") else FP32_MATRIX_PEAK_TFLOPS
+    return SPLIT_F32_PEAK_TFLOPS if kernel_name.startswith(("convbf2_kernel<float", "convx3_dw_kernel")) else FP32_MATRIX_PEAK_TFLOPS
 HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 N_CLIPS = 4096
 # Algorithmic work of the Conv1d stacks per 32-clip step (weights counted once per step): generator U-Net + decoder

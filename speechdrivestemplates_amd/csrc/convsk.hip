@@ -1037,6 +1037,190 @@ __global__ __launch_bounds__(256, 2) void convbf_dw_kernel(const __bf16* __restr
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-fp32 weight gradient (fp32 tensors, fp32-grade products at the bf16 matrix rate; see x3_stage in convbf.hip for the arithmetic): the
+// decomposition, slabs and ordered reduce of convsk_dw_kernel and its plan (32 rows m per plan step), the transposed-fragment LDS layout of
+// convbf_dw_kernel per bf16 PLANE.  A sub-step is 16 rows m = one k16 block: a thread loads 16 bytes = 4 fp32 columns of one row, splits them into
+// three 4 x bf16 pieces and stores each to its plane ([16][W] bf16, 64-byte segments XOR-swizzled with the row); fragments by ds_read_b64_tr_b16,
+// six MFMAs per fragment pair (small products first), the accumulators flushed into `tot` every SK_CHUNK plan steps as the fp32 kernel does.
+// Two workgroups of 4 waves per CU (2 x 48 KB of LDS), not in step with each other: one's split / store phase runs under the other's MFMAs.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void convx3_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY, const sk_args P, const int K,
+                                                           const int ncol, const int nchunk, float* __restrict__ slabs) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int SUB = 16;                          // rows per sub-step
+    constexpr int CA = BM / 4, CB = BN / 4;          // 16-byte chunks (4 fp32 columns) per tile row
+    constexpr int RPA = 256 / CA, RPB = 256 / CB;    // tile rows covered by one pass of the 256 threads
+    constexpr int LA = SUB / RPA, LB = SUB / RPB;    // loads per thread and sub-step
+    static_assert(LA >= 1 && LB >= 1, "tile width");
+    extern __shared__ __attribute__((aligned(16))) short smem_h[];
+    short* sA = smem_h;                           // [2][3][16][BM]
+    short* sB = smem_h + 2 * 3 * SUB * BM;        // [2][3][16][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cqa = tid % CA, rra = tid / CA, cqb = tid % CB, rrb = tid / CB;
+    const int G = P.G, T = P.T;
+    const int bid = blockIdx.x;
+    const int u = (bid & 7) * (G >> 3) + (bid >> 3);
+    if (u >= T * nchunk) return;
+    const int chunk = u / T, tile = u - chunk * T;
+    const sk_class& cl = P.cls[0];
+    const int Cin = __builtin_amdgcn_readfirstlane(cl.Cin);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)P.ybytes, 0x00020000);
+    const int a = (int)((long)chunk * K / nchunk), b = (int)((long)(chunk + 1) * K / nchunk);  // plan steps of 32 rows
+    const int nt = tile / ncol, ct = tile - nt * ncol;
+    const int n0 = nt * BM, j0 = ct * BN;
+    const int j = j0 + cqb * 4;  // this thread's B columns: 4 consecutive channels of ONE tap
+    const int t = j / Cin, c = j - t * Cin;
+    const unsigned acol = (unsigned)(n0 + cqa * 4) * 4u;
+    const unsigned bcol = (unsigned)cl.ashift[t] + (unsigned)c * 4u;
+    const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
+    int ya[LA];
+    int2 xb[LB];
+    f32x4 ra[2][LA], rb[2][LB];  // two register sets: a load is issued two sub-steps before its data is split and stored
+    int mrow = a * 32;           // first row of the next table read
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ya[i] = ((const int*)P.rowinfo)[4 * (mrow + rra + RPA * i) + 2];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) xb[i] = ((const int2*)P.rowinfo)[2 * (mrow + rrb + RPB * i)];
+        mrow += SUB;
+    };
+    int left = 2 * (b - a);
+    auto load = [&](auto SI) {
+        constexpr int S_ = decltype(SI)::value;
+        const unsigned off_mask = left > 0 ? 0u : SK_OOB;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const unsigned oa = ((unsigned)ya[i] + acol) | off_mask;  // rows past M carry SK_OOB already
+            ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)oa, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask;
+            rb[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
+        }
+        --left;
+    };
+    auto split_store = [&](short* base, const int plane_stride, const f32x4 v) {  // (as x3_stage of convbf.hip: 4 fp32 -> 3 x 4 bf16, exact)
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x0 = v[2 * q], x1 = v[2 * q + 1];
+            sk_bf16x2 pk;
+            pk[0] = (__bf16)x0, pk[1] = (__bf16)x1;
+            h[q] = __builtin_bit_cast(unsigned, pk);
+            const float r0 = x0 - __uint_as_float(h[q] << 16), r1 = x1 - __uint_as_float(h[q] & 0xffff0000u);
+            pk[0] = (__bf16)r0, pk[1] = (__bf16)r1;
+            m[q] = __builtin_bit_cast(unsigned, pk);
+            const float s0 = r0 - __uint_as_float(m[q] << 16), s1 = r1 - __uint_as_float(m[q] & 0xffff0000u);
+            pk[0] = (__bf16)s0, pk[1] = (__bf16)s1;
+            l[q] = __builtin_bit_cast(unsigned, pk);
+        }
+        *(uint2*)base = uint2{h[0], h[1]};
+        *(uint2*)(base + plane_stride) = uint2{m[0], m[1]};
+        *(uint2*)(base + 2 * plane_stride) = uint2{l[0], l[1]};
+    };
+    auto stage = [&](auto SI, const int buf) {
+        constexpr int S_ = decltype(SI)::value;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) split_store(sA + buf * 3 * SUB * BM + bfdw_off<BM>(rra + RPA * i, cqa * 4), SUB * BM, ra[S_][i]);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) split_store(sB + buf * 3 * SUB * BN + bfdw_off<BN>(rrb + RPB * i, cqb * 4), SUB * BN, rb[S_][i]);
+    };
+    f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][jj][q] = 0.f, tot[i][jj][q] = 0.f;
+    // fragment addressing as in convbf_dw_kernel: lane = 16 g + p reads rows 8 (g >> 1) + (p >> 2) (+ 4), columns 16 (g & 1) + 4 (p & 3) of its 32-column block
+    const int g4 = lane >> 4, p4 = lane & 15;
+    const int frow = 8 * (g4 >> 1) + (p4 >> 2), fcol = 16 * (g4 & 1) + 4 * (p4 & 3);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    load_rows();
+    load(I0{});     // sub-step 0 -> set 0
+    load_rows();
+    stage(I0{}, 0);
+    load(I1{});     // sub-step 1 -> set 1
+    load_rows();
+    load(I0{});     // sub-step 2 -> set 0
+    load_rows();    // tables of sub-step 3
+    __syncthreads();
+    const int nsub = 2 * (b - a);
+    auto step = [&](auto CUR) {
+        constexpr int cur = decltype(CUR)::value, nx = cur ^ 1;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // planes hi / mid / lo = 0 / 1 / 2: small products first
+        const short* pa = sA + cur * 3 * SUB * BM;
+        const short* pb = sB + cur * 3 * SUB * BN;
+        sk_s16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int col = wm * (BM / 2) + tm * 32 + fcol;
+                const sk_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pa + pl * SUB * BM + bfdw_off<BM>(frow, col)));
+                const sk_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pa + pl * SUB * BM + bfdw_off<BM>(frow + 4, col)));
+                fa[pl][tm] = (sk_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = wn * (BN / 2) + tn * 32 + fcol;
+                const sk_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pb + pl * SUB * BN + bfdw_off<BN>(frow, col)));
+                const sk_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sk_lds_s16x4*)(pb + pl * SUB * BN + bfdw_off<BN>(frow + 4, col)));
+                fb[pl][tn] = (sk_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+        stage(std::integral_constant<int, nx>{}, nx);  // sub-step s + 1: registers (loaded two sub-steps ago) -> split -> LDS[next]
+        load(std::integral_constant<int, nx>{});       // sub-step s + 3 -> the registers just stored
+        load_rows();                                   // tables of sub-step s + 4
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, fa[PA[pr]][tm]), __builtin_bit_cast(sk_bf16x8, fb[PB[pr]][tn]),
+                                                                          acc[tm][tn], 0, 0, 0);
+        // everybody has read LDS[cur] and written LDS[cur ^ 1]; the global loads stay in flight across the barrier (no vmcnt drain)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    tot[i][jj][q] += acc[i][jj][q];
+                    acc[i][jj][q] = 0.f;
+                }
+    };
+    for (int s = 0; s < nsub; s += 2) {  // (nsub is even: a plan step is two sub-steps)
+        if (s > 0 && ((a + s / 2) % SK_CHUNK) == 0) flush();  // chunks aligned to the tile's own step index, as in convsk_dw_kernel
+        step(I0{});
+        step(I1{});
+    }
+    flush();
+    float* slab = slabs + (size_t)u * (BM * BN);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nl = wm * (BM / 2) + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const int jl = wn * (BN / 2) + tn * 32 + (lane & 31);
+                slab[nl * BN + jl] = tot[tm][tn][q];
+            }
+}
+
 // dw[n, wt(t), c] += the slabs of tile (nt, ct).  Q lanes per 4 consecutive columns of a tile row: lane q adds the chunks
 // [q * nchunk / Q, (q + 1) * nchunk / Q) in order, then the Q sums are added in order q = 0 .. Q-1 -- a fixed tree, no atomics.  Every
 // launch reads the same 33.5 MB of slabs (T * nchunk = 512 units of 64 KB), so the few-tile layers are short of workgroups, not of
@@ -1613,7 +1797,7 @@ static int dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes, 
         cp[11 + SDT_MAX_TAPS + t] = on ? g.wt[t] : 0;  // the weight-gradient kernels read wt[t] here
         cp[11 + 2 * SDT_MAX_TAPS + t] = 0;
     }
-    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24), P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
+    P[0] = SK_MAGIC + 1, P[1] = bm, P[2] = bn, P[3] = G | (g_sk_wpc << 16) | ((esz == 2) << 24) | ((int)(esz == 4 && g_sk_split && g_sk_wpc == 2) << 26), P[4] = 1, P[5] = ncol, P[6] = (int)T, P[7] = (int)(T * K), P[8] = (int)rows, P[9] = (int)K;
     P[10] = SK_HDR, P[11] = 0, P[12] = 0, P[13] = 0, P[14] = (int)(SK_HDR + rows * 4), P[15] = (int)(SK_HDR + rows * 4 + SK_CLS_INTS);
     return SDT_OK;
 }
@@ -1679,6 +1863,23 @@ static int dw_go(const void* xv, const void* dyv, float* dw, const void* plan_ho
         else if (bm == 64 && bn == 128) DWB_GO(64, 128);
         else DWB_GO(64, 64);
 #undef DWB_GO
+    } else if ((P[3] >> 26) & 1) {  // plan built with sdt_convsk_set_f32_split(1): split-fp32 products
+        const size_t ldsx = (size_t)2 * 3 * 16 * (bm + bn) * 2;
+#define DWX_GO(BM_, BN_)                                                                                                       \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)convx3_dw_kernel<BM_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((convx3_dw_kernel<BM_, BN_>), dim3(A.G), dim3(256), ldsx, s, x, dy, A, K, ncol, nchunk, (float*)workspace); \
+    } while (0)
+        SDT_CHECK_ARG(wpc == 2, "the split-fp32 weight gradient is built for two workgroups per CU");
+        if (bm == 128 && bn == 128) DWX_GO(128, 128);
+        else if (bm == 128 && bn == 64) DWX_GO(128, 64);
+        else if (bm == 64 && bn == 128) DWX_GO(64, 128);
+        else DWX_GO(64, 64);
+#undef DWX_GO
     } else if (bm == 128 && bn == 128 && wpc == 2) DW_GO(128, 128, 2);
     else if (bm == 128 && bn == 128) DW_GO(128, 128, 1);
     else if (bm == 128 && bn == 64 && wpc == 2) DW_GO(128, 64, 2);

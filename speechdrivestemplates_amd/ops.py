@@ -626,12 +626,13 @@ USE_STREAMK_DW = True  # weight gradients of the 2-D layers with Cout % 128 == 0
 class _SKDwPlan:
     __slots__ = ("host", "dev", "dtype")
 
-    def __init__(self, g, dev, dtype=0, reserve=0, wpc=2):
+    def __init__(self, g, dev, dtype=0, reserve=0, wpc=2, split=False):
         import ctypes as C
         lib = _lib.load()
         self.dtype = dtype
         check(lib.sdt_convsk_set_reserved_slots(int(reserve)))
         check(lib.sdt_convsk_set_wg_per_cu(int(wpc)))
+        check(lib.sdt_convsk_set_f32_split(1 if split else 0))  # fp32 tensors, two workgroups per CU: the split-fp32 weight-gradient kernel
         try:
             nbytes = lib.sdt_convsk_dw_plan_bytes_t(g, dtype)
             self.host = (C.c_int32 * (nbytes // 4))()
@@ -639,13 +640,15 @@ class _SKDwPlan:
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
             check(lib.sdt_convsk_set_wg_per_cu(2))
+            check(lib.sdt_convsk_set_f32_split(0))
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
 
 
 def _sk_dw_plan(g, dev, dtype=0):
     reserve = int(SK_RESERVED_SLOTS)
     wpc = 2 if dtype != _lib.F32 else int(SK_WPC_DW)
-    key = (_geom_key(g), dev.index, reserve, dtype, wpc)
+    split = bool(F32_SPLIT) and dtype == _lib.F32 and wpc == 2
+    key = (_geom_key(g), dev.index, reserve, dtype, wpc, split)
     plan = _SK_DW_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
@@ -656,7 +659,7 @@ def _sk_dw_plan(g, dev, dtype=0):
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
             check(lib.sdt_convsk_set_wg_per_cu(2))
-        plan = _SKDwPlan(g, dev, dtype, reserve, wpc) if ok else None
+        plan = _SKDwPlan(g, dev, dtype, reserve, wpc, split) if ok else None
         _SK_DW_PLANS[key] = plan
     return plan
 
@@ -982,7 +985,8 @@ def conv_weight_grad(x_cl, gy_cl, w, stride, pad):
         if plan is not None:
             ws = _sk_dw_workspace(x4.device, st)
             _conv_launch("dW", True, g, lambda: lib.sdt_convsk_dw_f32(_p(x4), _p(gy4), _p(gws), plan.host, _p(plan.dev), _p(ws),
-                                                                      x4.numel() * 4, gy4.numel() * 4, st), name="convsk_dw_kernel")
+                                                                      x4.numel() * 4, gy4.numel() * 4, st),
+                         name="convx3_dw_kernel" if (plan.host[3] >> 26) & 1 else "convsk_dw_kernel")
             return
     if DETERMINISTIC_DW and _CONV_MATH_NOW[0] == 0 and g.ntaps == g.Tw:  # (the bf16 modes have no ordered variant: atomics)
         nbytes = lib.sdt_conv_dw_workspace_bytes(g)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence, run on the MI355X box: bash tools/collect_profiles.sh r03   (writes gpurun_out/<tag>_final/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_final
@@ -16,7 +16,12 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 python tools/trace_summary.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 60 > "$OUT/trace_by_launch_shape.txt" 2>&1
 # trace-based fraction of the dominant kernel (bench.py cites it beside its event-based figure): algorithmic GFLOP per launch from the bench line
 GF=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['roofline']['algorithmic_gflop_per_launch'])")
-python tools/trace_fraction.py "$OUT/trace_noovl/b_kernel_trace.csv" "convsk_kernel<float, float, 128, 128" "convsk_kernel<128, 128>" "$GF" 157.3 "$OUT/trace_fraction.json" > "$OUT/trace_fraction.log" 2>&1
+# (the dominant kernel and its matrix peak as the bench line names them; "name<a, b>" of the bench = "name<a, b, ..." of the trace)
+KN=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['roofline']['kernel'])")
+PK=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['roofline']['peak'])")
+RX=$(python -c "import re,sys; k=sys.argv[1]; print(re.escape(k[:-1]) + '[,>]' if k.endswith('>') else re.escape(k))" "$KN")
+case "$KN" in "convsk_kernel<"*) RX="convsk_kernel<float, float, ${KN#convsk_kernel<}"; RX="${RX%>}";; esac
+python tools/trace_fraction.py "$OUT/trace_noovl/b_kernel_trace.csv" "$RX" "$KN" "$GF" "$PK" "$OUT/trace_fraction.json" > "$OUT/trace_fraction.log" 2>&1
 python tools/stream_summary.py "$OUT/trace/b_kernel_trace.csv" 35 14 > "$OUT/streams.txt" 2>&1
 python tools/hbm_kernels.py "$OUT/trace_noovl/b_kernel_trace.csv" 35 > "$OUT/hbm_kernels.txt" 2>&1
 # (3a) the bf16-storage step (BASELINE config 4's arithmetic): every kernel alone, and as run
@@ -29,7 +34,7 @@ bash tools/debug/pmc_conv.sh L1,L2,L3,L4,L5,L6,L7 fwd,dX,dW > "$OUT/pmc_conv.txt
 # (4) fabric-side traffic: two PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_fetch.log" 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o b -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode > "$OUT/pmc_write.log" 2>&1
-python tools/hbm_traffic.py "$OUT/pmc_fetch/b_counter_collection.csv" "$OUT/pmc_write/b_counter_collection.csv" "$OUT/hbm_traffic_bench.json" "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode" > "$OUT/hbm_traffic.log" 2>&1
+python tools/hbm_traffic.py "$OUT/pmc_fetch/b_counter_collection.csv" "$OUT/pmc_write/b_counter_collection.csv" "$OUT/hbm_traffic_bench.json" "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-events --no-alt-mode" "$KN" > "$OUT/hbm_traffic.log" 2>&1
 # keep the merged payload small: drop the raw traces / databases, keep the stats
 for d in trace trace_noovl; do cp "$OUT/$d/b_kernel_stats.csv" "$OUT/${d}_kernel_stats.csv" 2>/dev/null; done
 rm -rf "$OUT/trace" "$OUT/trace_noovl" "$OUT/pmc_fetch" "$OUT/pmc_write"

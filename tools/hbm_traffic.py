@@ -33,6 +33,9 @@ def per_kernel(path, counter):
         # <TX, TY, BM, BN, EPI, workgroups per CU> -> bench.py's name (the bf16 instantiations stay mangled: the demangler does not know DF16b)
         name = re.sub(r"^convsk_kernel<float, float, (\d+, \d+), \d+, \d+>", r"convsk_kernel<\1>", name)
         name = re.sub(r"^_Z13convsk_kernelIDF16bDF16bLi(\d+)ELi(\d+)E.*", r"convsk_kernel<\1, \2> bf16", name)
+        # <ET, BM, BN, WGM, WGN, EPI> of the 8-wave kernel (csrc/convbf.hip): float = the split-fp32 form, mangled = bf16 tensors
+        name = re.sub(r"^convbf2_kernel<float, (\d+, \d+), \d+, \d+, \d+>", r"convbf2_kernel<float, \1>", name)
+        name = re.sub(r"^_Z14convbf2_kernelIDF16bLi(\d+)ELi(\d+)E.*", r"convbf2_kernel<\1, \2>", name)
         tot[name] += float(r["Counter_Value"]) * 1024.0
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
@@ -52,7 +55,8 @@ def main():
                       "write_mb_per_launch": w[k] / nw[k] / 1e6}
     total = {k: (v["fetch_x2_mb_per_launch"] + v["write_mb_per_launch"]) * v["launches"] for k, v in kernels.items()}
     order = sorted(kernels, key=lambda k: -total[k])
-    dom = next(k for k in order if k.startswith(("convsk_kernel", "conv_taps_kernel")))
+    want = sys.argv[5] if len(sys.argv) > 5 else None  # bench.py's roofline.kernel: the traffic of THAT kernel is what the bench line cites
+    dom = want if want in kernels else next(k for k in order if k.startswith(("convbf2_kernel<float", "convsk_kernel", "conv_taps_kernel")))
     from bench import kernel_source_digest
     try:
         head = subprocess.run(["git", "-C", REPO, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
