@@ -83,7 +83,7 @@ def main():
             for k, v in ph.items():
                 print("    %-36s median %6.2f us  p90 %6.2f  max %6.2f   sum per workgroup %.1f us" % (k, np.median(v), np.percentile(v, 90), v.max(), v.sum() / (nseg > 0).sum()))
             per_step = ph["K loop"] / np.maximum(steps, 1)
-            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles per SIMD)" % (np.median(per_step), np.median(per_step) * 2380,
+            print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles per SIMD at 32 per MFMA, 256 x 128 tile; half of that for 128 x 128 and 256 x 64)" % (np.median(per_step), np.median(per_step) * 2380,
                                                                                                          (1024 if a.dtype == "bf16" else 3072) if a.bf2 else (512 if a.dtype == "bf16" else 4096)))
             for kk, nm in ((0, "whole"), (1, "owner"), (2, "publish")):
                 sel = kind == kk
