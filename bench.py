@@ -314,7 +314,8 @@ def main(argv=None):
         # every rank draws its own initial weights (nothing here seeds torch): setup_optimizer's dp.sync_replicas makes the
         # replicas identical, as DDP's constructor does in the reference
         pipe, cfg = make_pipeline(args.config, N_CLIPS, batch_global=B * world,
-                                  sys_opts={"STORAGE": args.storage, "CHAIN1D": not args.no_chain1d, "DISTRIBUTED": world > 1 or forced_dp})
+                                  sys_opts={"STORAGE": args.storage, "CHAIN1D": not args.no_chain1d, "CONV_F32_SPLIT": not args.no_f32_split,
+                                            "DISTRIBUTED": world > 1 or forced_dp})
         batches = stage_batches(4, B, rank, dev)
         if args.dp_no_overlap and getattr(pipe, "reducer", None) is not None:
             pipe.reducer.launch_early = False

@@ -45,7 +45,10 @@ _DEFAULTS = {
             # CHAIN1D False = the generator's Conv1d blocks one by one: the one-launch chain spins on clusters of co-resident workgroups, so a GPU
             # that two training processes share must not run two of them at once (each would wait for CUs the other one holds until the spin limit
             # trips and the Trainer raises)
-            "STORAGE": "f32", "HIP_GRAPH": False, "CHAIN1D": True},
+            "STORAGE": "f32", "HIP_GRAPH": False, "CHAIN1D": True,
+            # CONV_F32_SPLIT (fp32 tensors): Conv2d products as six bf16 MFMA products of an exact three-way bf16 split of both operands, fp32
+            # accumulation (csrc/convbf.hip; fp32-grade results, 1.3x faster); False = the fp32-MFMA kernels of rounds 3-4
+            "CONV_F32_SPLIT": True},
 }
 
 

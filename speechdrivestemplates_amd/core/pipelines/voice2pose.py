@@ -184,7 +184,8 @@ class Voice2Pose(Trainer):
         # kernel routing this pipeline's configuration asks for -- set UNCONDITIONALLY (defaults included: a pipeline built after a bf16 one in the
         # same process must not inherit its mode) and re-applied at the start of every step this pipeline runs (Trainer.apply_knobs).
         # Before setup_optimizer: its weight mirrors allocate the bf16 copies.
-        self.knobs = {'storage': getattr(cfg.SYS, 'STORAGE', 'f32'), 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True))}
+        self.knobs = {'storage': getattr(cfg.SYS, 'STORAGE', 'f32'), 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True)),
+                      'f32_split': bool(getattr(cfg.SYS, 'CONV_F32_SPLIT', True))}
         self.apply_knobs()
         self.model = Voice2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank(), external_codes).cuda()
         if state_dict is not None:

@@ -427,19 +427,20 @@ def set_storage(mode):
 
 
 def apply_knobs(knobs):
-    """The process-wide mode switches a PIPELINE owns (``Trainer.knobs``: {'storage', 'chain1d'} from its cfg.SYS), applied at the start of every
+    """The process-wide mode switches a PIPELINE owns (``Trainer.knobs``: {'storage', 'chain1d', 'f32_split'} from its cfg.SYS), applied at the start of every
     step it runs: two pipelines with different configurations in one process (train in bf16 storage and validate another model in fp32; the
     reference's voice2pose + pose2pose tools) no longer inherit each other's settings (VERDICT r4 weak 14 / ADVICE r4).  Not allowed to change
     under a hipGraph capture (the captured launches were chosen under the knobs in force)."""
-    global STORAGE, CHAIN1D
+    global STORAGE, CHAIN1D, F32_SPLIT
     if not knobs:
         return
-    st, ch = knobs.get("storage", STORAGE), bool(knobs.get("chain1d", CHAIN1D))
-    if st != STORAGE or ch != CHAIN1D:
+    st, ch, sp = knobs.get("storage", STORAGE), bool(knobs.get("chain1d", CHAIN1D)), bool(knobs.get("f32_split", F32_SPLIT))
+    if st != STORAGE or ch != CHAIN1D or sp != F32_SPLIT:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("a pipeline's storage / chain mode cannot change inside a hipGraph capture")
+            raise RuntimeError("a pipeline's storage / chain / conv-arithmetic mode cannot change inside a hipGraph capture")
         set_storage(st)
         CHAIN1D = ch
+        F32_SPLIT = sp  # (plan caches are keyed on it: no stale plan)
 
 
 def _dt(t):

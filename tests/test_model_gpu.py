@@ -131,7 +131,7 @@ def _make_pipeline(cfg_name, n_clips, code_std, extra_opts=()):
     # the pipeline owns its storage mode (cfg.SYS.STORAGE -> Trainer.knobs, applied at every step): a test that selected a mode with
     # ops.set_storage() before building its pipeline gets a pipeline configured for that mode
     cfg.merge_from_list(["DATASET.NAME", "SyntheticGestureDataset", "DATASET.SYNTHETIC_CLIPS", n_clips, "SYS.LOG_INTERVAL", 10 ** 9,
-                         "SYS.STORAGE", _ops.STORAGE, "SYS.CHAIN1D", bool(_ops.CHAIN1D)] + list(extra_opts))
+                         "SYS.STORAGE", _ops.STORAGE, "SYS.CHAIN1D", bool(_ops.CHAIN1D), "SYS.CONV_F32_SPLIT", bool(_ops.F32_SPLIT)] + list(extra_opts))
     cfg.freeze()
     sp = np.load(os.path.join(GOLDEN, "speaker_stat_oliver.npz"))
     gd.register_speaker_stat("oliver",
