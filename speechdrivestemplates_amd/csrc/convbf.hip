@@ -49,8 +49,16 @@ extern "C" int sdt_debug_set_timeline_bf2(void* p) {
     do {                                                                                                                   \
         if (threadIdx.x == 0 && bf2_dbg_tl != nullptr && seg < 16) bf2_dbg_tl[((size_t)r * 16 + seg) * 8 + (slot)] = (val); \
     } while (0)
+// fault injection (tests/test_ops_gpu.py::test_streamk_lost_partner_is_loud): range `bf2_dbg_mute_range` computes its partial tile but never raises its flag
+__device__ int bf2_dbg_mute_range = -1;
+int convbf2_debug_mute_range(int r) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(bf2_dbg_mute_range), &r, sizeof(r));
+    return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
+}
+#define BF_MUTED(r) ((r) == bf2_dbg_mute_range)
 #else
 #define BF_TL(slot, val) do { } while (0)
+#define BF_MUTED(r) false
 #endif
 
 // Statistics of ONE 32 x 32 accumulator block (rows rb0 .. rb0 + 31 of the tile, this lane's column n): sum u and sum u * v over the block's rows with
@@ -270,6 +278,9 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
 // of 6 NM MFMAs.  Bytes per MFMA cycle are a third of the bf16 kernel's, which is what that kernel was short of (profiles/r05_bf2_experiments.txt).
 // Inf operands turn into NaN (inf - inf in the split), as they would after one more layer in fp32.
 #define X3_ROW 16  // floats per LDS row of one plane: 32 bf16 channels
+#ifndef X3_NSET
+#define X3_NSET 2  // staging register sets of the split form
+#endif
 __device__ __forceinline__ void x3_stage(float* dst, const int plane_stride, const f32x4 v) {
     unsigned h[2], m[2], l[2];
 #pragma unroll
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     // Staging register sets = how many K steps a request has to land before its data is stored to LDS: two when the accumulators leave room.
     // (Three / four sets were measured, profiles/r05_bf2_experiments.txt: no gain -- the waves wait for their operands at ANY prefetch depth, the
     // delivery RATE of ~24 B/clk per CU is what a step waits for, not the latency of one request.)
-    constexpr int NSET = BN == 256 ? 1 : 2;
+    constexpr int NSET = BN == 256 ? 1 : (X3 ? X3_NSET : 2);
     constexpr int UNR = (NSET % 2 == 0) ? (NSET < 2 ? 2 : NSET) : 2 * NSET;  // period of (LDS buffer parity, staging set)
     static_assert(WGM * WGN == 8 && TM >= 1 && TN >= 1 && RB >= 1, "wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -833,10 +844,10 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         if constexpr (X3) {
             // fp32-grade sums: the accumulators are added to `tot` and cleared every SK_CHUNK steps (256 channels x taps), as the fp32 kernel does --
             // a running fp32 sum over a whole 4096-term K loop carries 1.5x the rounding error of the blocked one (tools/debug/x3_check.py)
-            static_assert(SK_CHUNK % UNR == 0, "chunks are whole periods");
-            for (; s + SK_CHUNK <= nsteps; s += SK_CHUNK) {
+            constexpr int CH = SK_CHUNK % UNR == 0 ? SK_CHUNK : UNR;  // chunks are whole periods (three staging sets: 6 steps)
+            for (; s + CH <= nsteps; s += CH) {
 #pragma unroll 1
-                for (int u = 0; u < SK_CHUNK; u += UNR) steps_unrolled(std::integral_constant<int, 0>{}, UNR);
+                for (int u = 0; u < CH; u += UNR) steps_unrolled(std::integral_constant<int, 0>{}, UNR);
                 x3_flush();
             }
         }
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
             // (the next tile's first loads are in flight too: vmcnt(0) waits for them as well -- once per split tile)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store((gu32*)(P.flags + r), P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !BF_MUTED(r)) __hip_atomic_store((gu32*)(P.flags + r), P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (!whole) {
                 const int r_last = (int)((((long)E.tend) * G - 1) / P.S);

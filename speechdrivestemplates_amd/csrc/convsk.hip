@@ -53,6 +53,7 @@ extern "C" int sdt_debug_set_timeline_sk(void* p) {
 __device__ int sk_dbg_mute_range = -1;
 extern "C" int sdt_debug_convsk_mute_range(int r) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sk_dbg_mute_range), &r, sizeof(r));
+    if (e == hipSuccess && convbf2_debug_mute_range(r) != SDT_OK) return SDT_ERR_LAUNCH;  // the 8-wave kernels (convbf.hip) as well
     return e == hipSuccess ? SDT_OK : SDT_ERR_LAUNCH;
 }
 #define SK_MUTED(r) ((r) == sk_dbg_mute_range)
