@@ -172,11 +172,44 @@ def _norm(y, state, prefix, norm, training, momentum=0.1, eps=1e-5):
     raise NotImplementedError(norm)
 
 
-def conv_norm_act(x, state, prefix, stride, pad, norm, leaky, training):
+# bf16-STORAGE emulation (tests only).  The engine's bf16-storage mode (BASELINE config 4's arithmetic) keeps the
+# audio encoder's activations, conv outputs and conv-operand weight copies as bf16 in HBM.  With BF16_EMULATION set, the float64 oracle rounds (to
+# nearest even, as v_cvt_pk_bf16_f32 does) exactly where that path rounds -- and nowhere else -- so that what is left between the two is fp32
+# summation order, not bf16 rounding:
+#   block 0 (1 -> 64 channels, fused conv + norm + activation kernel): the block's OUTPUT;
+#   blocks 1..7: the weights (the bf16 copy of the fp32 master), the conv output y as stored (the statistics come from the UNROUNDED accumulators),
+#                the normalised + activated output (bf16; the last block writes fp32 for the fp32 1-D stage).
+# Backward passes straight through the roundings (the gradient tensors' own bf16 storage is not emulated).
+BF16_EMULATION = None
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _rb(x):
+    return _RoundBF16.apply(x)
+
+
+def conv_norm_act(x, state, prefix, stride, pad, norm, leaky, training, emu=None):
     w = state[prefix + ".conv.weight"]
+    if emu in ("2d", "2d_last"):
+        assert norm == "IN" and w.dim() == 4, "the bf16-storage emulation covers the InstanceNorm audio encoder"
+        y = F.conv2d(x, _rb(w), None, stride, pad)
+        mean, var = y.mean((2, 3), keepdim=True), y.var((2, 3), unbiased=False, keepdim=True)  # statistics of the unrounded outputs
+        y = (_rb(y) - mean) / torch.sqrt(var + 1e-5)
+        y = F.leaky_relu(y, 0.2) if leaky else F.relu(y)
+        return y if emu == "2d_last" else _rb(y)
     y = F.conv2d(x, w, None, stride, pad) if w.dim() == 4 else F.conv1d(x, w, None, stride, pad)
     y = _norm(y, state, prefix, norm, training)
-    return F.leaky_relu(y, 0.2) if leaky else F.relu(y)
+    y = F.leaky_relu(y, 0.2) if leaky else F.relu(y)
+    return _rb(y) if emu == "l0" else y
 
 
 def _block1d(x, state, prefix, down, norm, leaky, training):
@@ -189,8 +222,10 @@ def _block1d(x, state, prefix, down, norm, leaky, training):
 def audio_encoder(state, prefix, mel, num_frames, norm, leaky, training):
     """generator.py:39-43 -- mel (B,80,F) -> (B,256,num_frames)."""
     x = mel.unsqueeze(1)
+    last = len(AUDIO_ENCODER_2D) - 1
     for i, (_, _, _, s, p) in enumerate(AUDIO_ENCODER_2D):
-        x = conv_norm_act(x, state, f"{prefix}.specgram_encoder_2d.{i // 2}.{i % 2}", s, p, norm, leaky, training)
+        emu = None if not BF16_EMULATION else ("l0" if i == 0 else ("2d_last" if i == last else "2d"))
+        x = conv_norm_act(x, state, f"{prefix}.specgram_encoder_2d.{i // 2}.{i % 2}", s, p, norm, leaky, training, emu)
     x = F.interpolate(x, (1, num_frames), mode="bilinear")
     return x.squeeze(2)
 

@@ -260,3 +260,58 @@ def test_bf16_storage_train_steps_track_the_fp32_run(ops):
     for (a, b), (c, d) in zip(hf, h1):
         assert abs(a - c) <= 2e-2 * abs(a) and abs(b - d) <= 2e-2 * abs(b), (hf, h1)
     assert h1 == h2 and torch.equal(w1, w2), "the bf16-storage path is not run-to-run deterministic"
+
+
+def test_bf16_storage_blocks_round_where_the_emulating_oracle_rounds(ops):
+    """VERDICT r4 item 6c.  The bars of test_b32_bf16_storage_vs_oracle (prediction 4e-2, gradients 40 %) are set by bf16 rounding itself: the float64
+    oracle they compare with rounds nothing.  oracle.sdt_oracle.BF16_EMULATION rounds EXACTLY where the bf16-storage path rounds (block 0: its output;
+    blocks 1-7: the weights, the conv output as stored -- statistics from the unrounded accumulators --, the activated output; the last block writes
+    fp32).  Rounding is a discontinuity, so two computations that agree to fp32 precision decorrelate within three or four layers (a difference eps in
+    a value flips its rounding with probability eps / ulp: 4e-5 -> 2e-4 -> 7e-4 -> 2e-3 along the encoder, tools/debug/bf16_emu_model.py) -- an
+    end-to-end comparison cannot be tightened this way.  What CAN be checked tightly is every block on ITS OWN input: the engine's eight encoder blocks
+    run in bf16 storage on the real mel and weights of the B = 8 batch, and each block's output is compared with the emulating oracle block applied to
+    the engine's input of that block.  Bars (4 x measured): relative RMS difference <= 1.5e-4 (measured 1.6e-5 .. 3.5e-5: 4e-5 .. 9e-5 of the stored values
+    land on the other side of a rounding boundary, by one ulp) AND at most a twentieth of the distance to the oracle that does not round (1.7e-3 .. 3.1e-3)."""
+    from test_model_gpu import _make_pipeline
+    B, N, cfg_name = 8, 64, "voice2pose_sdt_bp"
+    ocfg = O.cfg_named(cfg_name)
+    state = O.make_voice2pose_state(ocfg, N, seed=0, code_std=0.5)
+    batch = O.make_batch(B, N, step=3, seed=11)
+    st64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+
+    def rms(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    ops.set_storage("bf16")
+    try:
+        pipe, _ = _make_pipeline(cfg_name, N, 0.5)
+        net = pipe.model.netG
+        with torch.no_grad():
+            x = pipe.model.mel_transfm(batch["audio"].to(DEV)).unsqueeze(-1)  # (B, H, W, 1) channels-last
+            rows, i = [], 0
+            for stage in net.audio_encoder.specgram_encoder_2d:
+                for block in stage:
+                    y = block.forward_cl(x, None, None, out_f32=(i == 7))
+                    assert y.dtype == (torch.float32 if i == 7 else torch.bfloat16), (i, y.dtype)
+                    xin = x.float().double().cpu().permute(0, 3, 1, 2)  # exactly the values the engine's block read
+                    s_, p_ = O.AUDIO_ENCODER_2D[i][3], O.AUDIO_ENCODER_2D[i][4]
+                    prefix = "netG.audio_encoder.specgram_encoder_2d.%d.%d" % (i // 2, i % 2)
+                    emu = "l0" if i == 0 else ("2d_last" if i == 7 else "2d")
+                    o_emu = O.conv_norm_act(xin, st64, prefix, s_, p_, "IN", True, True, emu)
+                    o_plain = O.conv_norm_act(xin, st64, prefix, s_, p_, "IN", True, True, None)
+                    got = y.float().permute(0, 3, 1, 2)
+                    differing = (got.double().cpu() != o_emu).double().mean().item()
+                    rows.append((i, rms(got, o_emu), rms(got, o_plain), differing))
+                    x, i = y, i + 1
+    finally:
+        ops.set_storage("f32")
+    for i, e_emu, e_plain, frac in rows:
+        print("  encoder block %d in bf16 storage on its own input: rms difference to the emulating oracle %.2e (fraction of differing values %.1e), "
+              "to the oracle that does not round %.2e" % (i, e_emu, frac, e_plain))
+    for i, e_emu, e_plain, frac in rows:
+        if i == 7:  # fp32 output: nothing is rounded after the normalisation; what is left is the stored conv output's rounding flips
+            assert e_emu <= 1.5e-4, (i, e_emu)
+            continue
+        assert e_emu <= 1.5e-4 and e_emu <= 0.05 * e_plain, (i, e_emu, e_plain)
+        assert frac <= 5e-4, (i, frac)
