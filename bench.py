@@ -14,9 +14,10 @@ Timing: W untimed warm-up steps, then exactly K steps between barrier + synchron
 slowest rank's wall time (the driver's contract).  Every step is also bracketed by one HIP event on the main stream, so the
 line carries the MEDIAN step time (SURVEY.md 8d's definition) and the mean over the steps that carried no per-kernel events.
 
-`roofline`        : the dominant kernel (the fp32-MFMA implicit-GEMM conv): algorithmic FLOPs per launch / mean launch
-                    duration from HIP events on the launching stream over sampled steps of the timed region, against the
-                    157.3 TFLOP/s fp32 matrix peak.  `traffic` is NOT measured in this process (PMC counters need rocprofv3):
+`roofline`        : the dominant kernel (the split-fp32 implicit-GEMM conv; with --no-f32-split the fp32-MFMA one): algorithmic FLOPs
+                    per launch / mean launch duration from HIP events on the launching stream over sampled steps of the timed
+                    region, against ITS matrix peak -- six bf16 MFMA products per fp32 product: the dense bf16 peak / 6 = 416.7
+                    TFLOP/s of algorithmic fp32 FLOPs (fp32-MFMA kernels: 157.3).  `traffic` is NOT measured in this process (PMC counters need rocprofv3):
                     the line cites the committed measurement and says which source revision it was taken at, or null when the
                     kernel source has changed since.
 `roofline_conv1d` : the Conv1d stacks (U-Net + decoder forward/backward, the two pose-encoder passes, their weight

@@ -165,22 +165,22 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm][tn][4 * qq + e] + bv), rsY, (int)((unsigned)offs[e] + (unsigned)n * 4u), 0, 0);
 #endif
                     }
-                    continue;
-                }
+                } else {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float v0 = acc[tm][tn][4 * qq + 2 * h] + bv, v1 = acc[tm][tn][4 * qq + 2 * h + 1] + bv;
-                    const float give = odd ? v0 : v1;
-                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
-                    sk_bf16x2 pk;
-                    pk[0] = (__bf16)(odd ? got : v0);
-                    pk[1] = (__bf16)(odd ? v1 : got);
-                    const int ro = odd ? (h ? o4.w : o4.y) : (h ? o4.z : o4.x);
+                    for (int h = 0; h < 2; ++h) {
+                        const float v0 = acc[tm][tn][4 * qq + 2 * h] + bv, v1 = acc[tm][tn][4 * qq + 2 * h + 1] + bv;
+                        const float give = odd ? v0 : v1;
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+                        sk_bf16x2 pk;
+                        pk[0] = (__bf16)(odd ? got : v0);
+                        pk[1] = (__bf16)(odd ? v1 : got);
+                        const int ro = odd ? (h ? o4.w : o4.y) : (h ? o4.z : o4.x);
 #if BF_ABL & 32  // ablation (wrong results): the epilogue's stores are not issued (the packing stays)
-                    asm volatile("" ::"v"(pk), "v"(ro));
+                        asm volatile("" ::"v"(pk), "v"(ro));
 #else
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rsY, (int)((unsigned)ro + nb2), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rsY, (int)((unsigned)ro + nb2), 0, 0);
 #endif
+                    }
                 }
             }
         }
@@ -613,20 +613,17 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         else if (i < NF) B[i - TM] = *(const f32x4*)(pb + (i - TM) * 32 * SK_LDP + J * 8);
 #endif
     };
+#ifdef SDT_TUNING
+    long long bar_wait = 0;  // clock64 ticks this wave spent in the K steps' barriers since the last stamp (slot 7 of the timeline: summed over the 8 waves)
+#endif
     // ---- X3: fragment i of a k-group's 3 NF fragments, in the order the MFMAs want them: A lo, B hi, A hi, B lo, A mid, B mid
     auto x3_rd = [&](const int set, const float* pa, const float* pb, const int fk, const int i) {
         if constexpr (X3) {
+            // segments of TM / TN fragments: (A, lo) (B, hi) (A, hi) (B, lo) (A, mid) (B, mid); i is a constant after unrolling
             constexpr int PL[6] = {2, 0, 0, 2, 1, 1};
-            int seg = 0, k = i;
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const int len = (g & 1) ? TN : TM;
-                if (k >= len && seg == g) {
-                    k -= len;
-                    ++seg;
-                }
-            }
-            if (seg >= 6) return;
+            const int pair = i / NF, in_pair = i - pair * NF;
+            if (pair >= 3) return;
+            const int seg = 2 * pair + (in_pair >= TM ? 1 : 0), k = in_pair >= TM ? in_pair - TM : in_pair;
             const int pl = PL[seg];
 #if BF_ABL & 16
             if (!(seg & 1)) asm volatile("" : "+v"(xa[set][pl][k]) : "v"(pa));
@@ -670,8 +667,14 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
             x3_pattern<0, BAR, NR, NL>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my stores to LDS[next] are done
+#ifdef SDT_TUNING
+            const long long tb0 = bf2_dbg_tl != nullptr ? clock64() : 0;  // (timeline runs only: how long does a wave wait at the step's barrier?)
+#endif
 #if !(BF_ABL & 8)
             __builtin_amdgcn_s_barrier();
+#endif
+#ifdef SDT_TUNING
+            if (bf2_dbg_tl != nullptr) bar_wait += clock64() - tb0;
 #endif
             __builtin_amdgcn_sched_barrier(0);
             // ---- region 2
@@ -753,8 +756,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     };
 
     // `n` (<= UNR) consecutive steps starting at period position U (compile-time recursion: buffer parity and staging set are template constants)
-    auto steps_unrolled = [&](auto self_u, const int n) __attribute__((always_inline)) {
-        (void)self_u;
+    auto steps_unrolled = [&](const int n) __attribute__((always_inline)) {
         auto rec = [&](auto&& rec_, auto U_) __attribute__((always_inline)) -> void {
             constexpr int u = decltype(U_)::value;
             if constexpr (u < UNR) {
@@ -847,16 +849,20 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
             constexpr int CH = SK_CHUNK % UNR == 0 ? SK_CHUNK : UNR;  // chunks are whole periods (three staging sets: 6 steps)
             for (; s + CH <= nsteps; s += CH) {
 #pragma unroll 1
-                for (int u = 0; u < CH; u += UNR) steps_unrolled(std::integral_constant<int, 0>{}, UNR);
+                for (int u = 0; u < CH; u += UNR) steps_unrolled(UNR);
                 x3_flush();
             }
         }
         for (; s + UNR <= nsteps; s += UNR) {
-            steps_unrolled(std::integral_constant<int, 0>{}, UNR);
+            steps_unrolled(UNR);
         }
-        steps_unrolled(std::integral_constant<int, 0>{}, nsteps - s);
+        steps_unrolled(nsteps - s);
         if constexpr (X3) x3_flush_final();
         BF_TL(2, wall_clock64());
+#ifdef SDT_TUNING
+        if (lane == 0 && bf2_dbg_tl != nullptr && seg < 16) atomicAdd(&bf2_dbg_tl[((size_t)r * 16 + seg) * 8 + 7], (unsigned long long)bar_wait);
+        bar_wait = 0;
+#endif
 #if BF_ABL & 64
 #pragma unroll
         for (int i = 0; i < RA + RB; ++i) asm volatile("" ::"v"(abl_sink[i]));

@@ -85,6 +85,10 @@ def main():
             per_step = ph["K loop"] / np.maximum(steps, 1)
             print("    K loop per step: median %.3f us = %.0f cycles at 2.38 GHz (%d MFMA cycles per SIMD at 32 per MFMA, 256 x 128 tile; half of that for 128 x 128 and 256 x 64)" % (np.median(per_step), np.median(per_step) * 2380,
                                                                                                          (1024 if a.dtype == "bf16" else 3072) if a.bf2 else (512 if a.dtype == "bf16" else 4096)))
+            if a.bf2 and a.dtype == "f32":
+                bw = tl[..., 7][used].astype(np.float64) / 8.0 / np.maximum(steps, 1)  # clock64 ticks per step and wave
+                print("    barrier wait per K step and wave: median %.0f clock64 ticks (p90 %.0f) = %.0f %% of a step at the shader clock"
+                      % (np.median(bw), np.percentile(bw, 90), 100.0 * np.median(bw) / (np.median(per_step) * 1950.0)))
             for kk, nm in ((0, "whole"), (1, "owner"), (2, "publish")):
                 sel = kind == kk
                 if sel.any():
