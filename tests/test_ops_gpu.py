@@ -1165,7 +1165,10 @@ def test_input_gradient_with_unreachable_rows(ops):
     assert float(dx[2:].abs().max()) == 0.0 and float(dx[:, Hi - 1].abs().max()) <= float(xr.grad[:, :, Hi - 1].abs().max()) + 1e-6
 
 
-SPLIT_CASES = [("L1", 80, 427, 64, 64, 4, 2, 1), ("L2", 40, 213, 64, 128, 3, 1, 1), ("L3", 40, 213, 128, 128, 4, 2, 1), ("L4", 20, 106, 128, 256, 3, 1, 1)]
+# (tag, Hi, Wi, Cin, Cout, k, stride, pad, B): the last three have 530 / 255 output rows per clip -- 128-row tiles straddle clips (two statistics groups in a tile,
+# partial last tile), odd batch sizes
+SPLIT_CASES = [("L1", 80, 427, 64, 64, 4, 2, 1, 8), ("L2", 40, 213, 64, 128, 3, 1, 1, 8), ("L3", 40, 213, 128, 128, 4, 2, 1, 8), ("L4", 20, 106, 128, 256, 3, 1, 1, 8),
+               ("L5", 20, 106, 256, 256, 4, 2, 1, 23), ("L6", 10, 53, 256, 256, 3, 1, 1, 27), ("L7", 10, 53, 256, 256, (6, 3), 1, 0, 49)]
 
 
 @pytest.mark.parametrize("case", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
@@ -1175,11 +1178,11 @@ def test_split_f32_conv_vs_float64_and_the_fp32_mfma_kernels(ops, case):
     gradient.  Bar: the RMS error against float64 is at most 1.25 x that of the fp32-MFMA kernels of rounds 3-4 on the same tensors (measured: 0.6-1.0 x,
     tools/debug/x3_check.py), the maximum error inside the per-layer fp32 bar of the other conv tests (3e-6 of the output's maximum), and the
     (clip, channel) sums / sums of squares within 2e-7 of float64's."""
-    tag, Hi, Wi, Cin, Cout, k, s, p = case
-    B = 8
+    tag, Hi, Wi, Cin, Cout, k, s, p, B = case
+    kh, kw = k if isinstance(k, tuple) else (k, k)
     g = torch.Generator().manual_seed(3 + Hi)
     x = torch.randn(B, Hi, Wi, Cin, generator=g)
-    wl = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    wl = torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wl.double(), None, s, p).permute(0, 2, 3, 1).contiguous()
     gy = torch.randn(ref.shape, generator=g)
     ref_dx = torch.nn.grad.conv2d_input((B, Cin, Hi, Wi), wl.double(), gy.permute(0, 3, 1, 2).double(), s, p).permute(0, 2, 3, 1).contiguous()
