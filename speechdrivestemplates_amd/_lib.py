@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDT_HIP_LIB: developer tools only (tools/conv_bench.py points it at the -DSDT_TUNING build); the package itself never sets it
 LIB_PATH = os.environ.get("SDT_HIP_LIB") or os.path.join(_HERE, "lib", "libsdt_hip.so")
 MAX_TAPS = 20
-ABI_VERSION = 3  # sdt_abi_version() of the library this binding was written against
+ABI_VERSION = 4  # sdt_abi_version() of the library this binding was written against
 
 
 class ConvGeom(C.Structure):
