@@ -283,18 +283,15 @@ __device__ __forceinline__ void bf2_epilogue(f32x16 (&acc)[TM][TN], const int* s
 #endif
 __device__ __forceinline__ void x3_stage(float* dst, const int plane_stride, const f32x4 v) {
     unsigned h[2], m[2], l[2];
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float x0 = v[2 * p], x1 = v[2 * p + 1];
-        sk_bf16x2 pk;
-        pk[0] = (__bf16)x0, pk[1] = (__bf16)x1;
-        h[p] = __builtin_bit_cast(unsigned, pk);
-        const float r0 = x0 - __uint_as_float(h[p] << 16), r1 = x1 - __uint_as_float(h[p] & 0xffff0000u);
-        pk[0] = (__bf16)r0, pk[1] = (__bf16)r1;
-        m[p] = __builtin_bit_cast(unsigned, pk);
-        const float s0 = r0 - __uint_as_float(m[p] << 16), s1 = r1 - __uint_as_float(m[p] & 0xffff0000u);
-        pk[0] = (__bf16)s0, pk[1] = (__bf16)s1;
-        l[p] = __builtin_bit_cast(unsigned, pk);
+    for (int p = 0; p < 2; ++p) {  // (vector conversions: ONE v_cvt_pk_bf16_f32 per pair and plane; element-wise casts cost hipcc two)
+        const f32x2_ x = {v[2 * p], v[2 * p + 1]};
+        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, sk_bf16x2));
+        const f32x2_ r = x - f32x2_{__uint_as_float(h[p] << 16), __uint_as_float(h[p] & 0xffff0000u)};
+        m[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sk_bf16x2));
+        const f32x2_ t = r - f32x2_{__uint_as_float(m[p] << 16), __uint_as_float(m[p] & 0xffff0000u)};
+        l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, sk_bf16x2));
     }
     *(uint2*)dst = uint2{h[0], h[1]};
     *(uint2*)(dst + plane_stride) = uint2{m[0], m[1]};

@@ -1106,18 +1106,15 @@ __global__ __launch_bounds__(256, 2) void convx3_dw_kernel(const float* __restri
     };
     auto split_store = [&](short* base, const int plane_stride, const f32x4 v) {  // (as x3_stage of convbf.hip: 4 fp32 -> 3 x 4 bf16, exact)
         unsigned h[2], m[2], l[2];
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float x0 = v[2 * q], x1 = v[2 * q + 1];
-            sk_bf16x2 pk;
-            pk[0] = (__bf16)x0, pk[1] = (__bf16)x1;
-            h[q] = __builtin_bit_cast(unsigned, pk);
-            const float r0 = x0 - __uint_as_float(h[q] << 16), r1 = x1 - __uint_as_float(h[q] & 0xffff0000u);
-            pk[0] = (__bf16)r0, pk[1] = (__bf16)r1;
-            m[q] = __builtin_bit_cast(unsigned, pk);
-            const float s0 = r0 - __uint_as_float(m[q] << 16), s1 = r1 - __uint_as_float(m[q] & 0xffff0000u);
-            pk[0] = (__bf16)s0, pk[1] = (__bf16)s1;
-            l[q] = __builtin_bit_cast(unsigned, pk);
+            const f32x2_ x = {v[2 * q], v[2 * q + 1]};
+            h[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, sk_bf16x2));
+            const f32x2_ r = x - f32x2_{__uint_as_float(h[q] << 16), __uint_as_float(h[q] & 0xffff0000u)};
+            m[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sk_bf16x2));
+            const f32x2_ t = r - f32x2_{__uint_as_float(m[q] << 16), __uint_as_float(m[q] & 0xffff0000u)};
+            l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, sk_bf16x2));
         }
         *(uint2*)base = uint2{h[0], h[1]};
         *(uint2*)(base + plane_stride) = uint2{m[0], m[1]};
