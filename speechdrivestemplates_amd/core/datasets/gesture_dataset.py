@@ -20,23 +20,50 @@ SPEAKERS_STAT_121_parted = {}  # same for hierarchical ("parted") poses
 
 def register_speaker_stat(name, parted=None, global_=None):
     """Make a speaker's normalisation constants available to ``get_speaker_stat`` (the reference hard-codes
-    them in core/datasets/speakers_stat.py; here they are data supplied by the caller / a checkpoint)."""
-    if parted is not None:
-        SPEAKERS_STAT_121_parted[name] = parted
-    if global_ is not None:
-        SPEAKERS_STAT_121[name] = global_
-    PoseTransforms._STAT_ON_DEVICE.clear()  # device copies of replaced tables must not outlive them
+    them in core/datasets/speakers_stat.py; here they are data supplied by the caller / a checkpoint).
+    Replacing a registered table keeps the DEVICE copies of the old one alive and refreshes them in place with the new values: a captured
+    hipGraph reads them by raw pointer, so they are never freed or re-allocated behind it and a replay sees the new statistics."""
+    for table, new in ((SPEAKERS_STAT_121_parted, parted), (SPEAKERS_STAT_121, global_)):
+        if new is None:
+            continue
+        old = table.get(name)
+        table[name] = new
+        if old is not None and old is not new:
+            PoseTransforms._rehome(old, new)
 
 
 class PoseTransforms:
     """normalize / denormalize / parted<->global / get_final_results with the reference semantics."""
     root_node, hand_root_l, hand_root_r, head_root = 1, HAND_ROOT_L, HAND_ROOT_R, HEAD_ROOT
 
-    # (id(ndarray), device) -> (ndarray kept alive, fp32 tensor, the bytes that were uploaded): registered statistics are uploaded once, not per
-    # step.  An entry is served only while the array still holds the uploaded bytes (a 2 KB compare: an in-place edit of a registered mean / std
-    # re-uploads instead of serving the stale copy); the table is bounded and dropped by register_speaker_stat (ADVICE r4).
+    # (id(ndarray), device) -> [ndarray kept alive, fp32 device tensor, the bytes that were uploaded]: registered statistics are uploaded once, not
+    # per step.  The device tensor of an entry is NEVER freed or replaced (a captured hipGraph reads it by raw pointer: the caching allocator
+    # would hand the memory to somebody else and every replay would normalise with garbage, silently -- ADVICE r5); an array whose bytes changed
+    # (in-place edit of a registered mean / std: a 2 KB compare per call) is copied INTO the same tensor, which also makes the edit visible to
+    # replays.  The table only grows; past _STAT_CACHE_MAX distinct arrays further ones are uploaded per call (correct, slower, not capturable).
     _STAT_ON_DEVICE = {}
-    _STAT_CACHE_MAX = 64
+    _STAT_CACHE_MAX = 256
+
+    @staticmethod
+    def _no_capture(what):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("speaker statistics %s inside a hipGraph capture" % what)
+
+    @staticmethod
+    def _rehome(old, new):
+        """register_speaker_stat replaced table ``old`` by ``new``: the device copies of old's arrays now carry new's values (same memory)"""
+        for k in ('mean', 'std'):
+            o, n = old.get(k), new.get(k)
+            if not (isinstance(o, np.ndarray) and isinstance(n, np.ndarray)) or o is n:
+                continue
+            for key in [kk for kk in PoseTransforms._STAT_ON_DEVICE if kk[0] == id(o)]:
+                ent = PoseTransforms._STAT_ON_DEVICE[key]
+                if ent[0] is not o or ent[1].numel() != n.size or (id(n), key[1]) in PoseTransforms._STAT_ON_DEVICE:
+                    continue  # (the old entry stays: its tensor must not be freed)
+                PoseTransforms._no_capture("were replaced")
+                ent[1].copy_(torch.tensor(n.astype(np.float64), dtype=torch.float32).reshape(ent[1].shape))
+                PoseTransforms._STAT_ON_DEVICE[(id(n), key[1])] = [n, ent[1], n.tobytes()]
+                ent[2] = None  # the old array no longer describes the tensor: a later call with it re-uploads (into the same tensor again)
 
     def _stat(self, t, kp):
         K = self.cfg.NUM_LANDMARKS
@@ -44,13 +71,17 @@ class PoseTransforms:
             key = (id(t), str(kp.device))
             hit = PoseTransforms._STAT_ON_DEVICE.get(key)
             raw = t.tobytes()
-            if hit is None or hit[0] is not t or hit[2] != raw:
-                if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("speaker statistics changed (or were never uploaded) inside a hipGraph capture")
-                if len(PoseTransforms._STAT_ON_DEVICE) >= PoseTransforms._STAT_CACHE_MAX:
-                    PoseTransforms._STAT_ON_DEVICE.clear()
+            if hit is not None and hit[0] is t and hit[2] != raw:  # edited in place (or re-homed away): refresh the SAME device tensor
+                self._no_capture("changed")
+                hit[1].copy_(torch.tensor(t.astype(np.float64), dtype=torch.float32).reshape(hit[1].shape))
+                hit[2] = raw
+            elif hit is None or hit[0] is not t:
+                self._no_capture("were never uploaded")
                 # torch.Tensor(ndarray) -> float32, :174-176.  (A host-to-device copy per call also made the step un-capturable in a hipGraph.)
-                hit = PoseTransforms._STAT_ON_DEVICE[key] = (t, torch.tensor(t.astype(np.float64), dtype=torch.float32).to(kp.device), raw)
+                dev_t = torch.tensor(t.astype(np.float64), dtype=torch.float32).to(kp.device)
+                hit = [t, dev_t, raw]
+                if len(PoseTransforms._STAT_ON_DEVICE) < PoseTransforms._STAT_CACHE_MAX:
+                    PoseTransforms._STAT_ON_DEVICE[key] = hit
             t = hit[1]
         else:
             t = t.to(kp.device)

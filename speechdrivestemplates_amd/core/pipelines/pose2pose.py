@@ -49,7 +49,8 @@ class Pose2Pose(Trainer):
         super().__init__(cfg)
 
     def setup_model(self, cfg, state_dict=None):
-        self.knobs = {'storage': 'f32', 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True))}  # the pose VAE is 1-D only: fp32 tensors (Trainer.apply_knobs)
+        # the pose VAE is 1-D only: fp32 tensors (Trainer.apply_knobs); every knob explicit, so that nothing is inherited from a pipeline that ran before
+        self.knobs = {'storage': 'f32', 'chain1d': bool(getattr(cfg.SYS, 'CHAIN1D', True)), 'f32_split': bool(getattr(cfg.SYS, 'CONV_F32_SPLIT', True))}
         self.apply_knobs()
         self.model = Pose2PoseModel(cfg, state_dict, self.num_train_samples, self.get_rank()).cuda()
         if state_dict is not None:

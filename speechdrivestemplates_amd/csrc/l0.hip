@@ -292,7 +292,11 @@ __global__ __launch_bounds__(256) void l0_bwd_sums_kernel(const TZ* __restrict__
         for (int j = 0; j < L0_Q; ++j) {
             const int x = x0 + cxi;
             const bool live = x < W && crow < nrows;
-            const float* c = sMel + crow * WP + min(x, W - 1);  // column x - 1 of image row y - 1
+            // column x - 1 of image row y - 1.  Row AND column are clamped for the dead slots of the last trip (total % L0_Q != 0: crow == nrows):
+            // un-clamped they read the LDS row behind the staged ones -- outside this workgroup's allocation, i.e. whatever a workgroup that held
+            // that LDS before left there (another process's bf16 tiles on a shared GPU) -- and 0 * (garbage -> inf in yhat) is NaN, not 0:
+            // the whole first block's weight gradient went NaN with every error word clean (GPUTEST_r05, tools/debug/dp_nan_hunt.py)
+            const float* c = sMel + min(crow, nrows - 1) * WP + min(x, W - 1);
             float nb[L0_T];
 #pragma unroll
             for (int d = 0; d < 3; ++d)

@@ -769,4 +769,29 @@ extern "C" int sdt_debug_spin(int wgs, int us, int lds_bytes, void* stream) {
     SDT_LAUNCH_CHECK();
     return SDT_OK;
 }
+
+// LDS residue (GPUTEST_r05's silent NaN): LDS is not cleared between workgroups, and an allocation is rounded up to the hardware's granule -- a kernel
+// that indexes past what it staged reads what the previous tenant of that LDS left there (another process's bf16 tiles on a shared GPU), and
+// 0 * residue is NaN when the residue is NaN / inf.  This launch leaves the quiet-NaN pattern 0x7fc07fc0 (NaN as fp32, as two bf16 and in either
+// half of a double) in all 160 KB of LDS of every CU: run on the stream right before a kernel under test, it turns any such read into a NaN
+// deterministically (tests/test_ops_gpu.py::test_kernels_do_not_read_lds_residue).
+__global__ __launch_bounds__(256) void debug_lds_pollute_kernel(int words, long long ticks) {
+    extern __shared__ unsigned pol_lds[];
+    for (int i = threadIdx.x; i < words; i += 256) pol_lds[i] = 0x7fc07fc0u;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);  // stay resident until every CU holds one such workgroup
+    if (pol_lds[(threadIdx.x * 61) % words] == 0u) pol_lds[0] = 1u;   // (keeps the stores alive)
+}
+extern "C" int sdt_debug_lds_pollute(void* stream) {
+    const int bytes = 160 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)debug_lds_pollute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SDT_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(debug_lds_pollute_kernel, dim3(512), dim3(256), (size_t)bytes, (hipStream_t)stream, bytes / 4, (long long)2000);  // 20 us each
+    SDT_LAUNCH_CHECK();
+    return SDT_OK;
+}
 #endif

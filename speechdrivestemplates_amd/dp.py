@@ -199,7 +199,10 @@ class GradReducer:
             ops.flush_deferred_dw()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             side = ops.side_stream_if_any()
-            if side is not None and not capturing:  # (inside a capture nothing runs on the side stream: ops._side_ok)
+            # inside a capture the side stream carries work only when ops.CAPTURE_SIDE_STREAMS forks the weight-gradient launches onto it
+            # (then it is part of the capture and must be joined like in eager mode: ADVICE r5); otherwise it is idle and NOT capturing --
+            # waiting on it would drag an uncaptured stream into the graph
+            if side is not None and (not capturing or ops._side_ok()):
                 self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
@@ -228,15 +231,17 @@ class GradReducer:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         self._in_all_reduce = True
-        for opt in (opts if opts is not None else self.optimizers):
-            early = sorted(self._launched.pop(id(opt), []))
-            pos, n = 0, opt.flat_grad.numel()
-            for lo, hi in early + [(n, n)]:
-                if lo > pos:
-                    self.launch(opt, pos, lo)
-                pos = max(pos, hi)
-            self._launched.pop(id(opt), None)
-        self._in_all_reduce = False
+        try:
+            for opt in (opts if opts is not None else self.optimizers):
+                early = sorted(self._launched.pop(id(opt), []))
+                pos, n = 0, opt.flat_grad.numel()
+                for lo, hi in early + [(n, n)]:
+                    if lo > pos:
+                        self.launch(opt, pos, lo)
+                    pos = max(pos, hi)
+                self._launched.pop(id(opt), None)
+        finally:
+            self._in_all_reduce = False  # (a raising collective must not leave the bucket hooks of later steps in "late" mode)
         self.wait()
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)

@@ -347,8 +347,10 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
         if cfg_name == "pose2pose":
             eps = torch.from_numpy(np.random.Generator(np.random.PCG64([2, step])).standard_normal((4, 32)).astype(np.float32)).to(DEV)
             torch.randn = lambda *a, **k: eps.clone()
+        dec = _Decisions()
         try:
-            losses, results = pipe.forward_backward(batch)
+            with dec:
+                losses, results = pipe.forward_backward(batch)
         finally:
             torch.randn = real_randn
         torch.cuda.synchronize()
@@ -374,10 +376,11 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
         e_ref = {k.split("/grad/")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
         g64_of = lambda k, _s=step: g64["s%d/grad/%s" % (_s, k)][:64]  # noqa: E731
         if step == 0:
-            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, allow=FLIP_ALLOW * n_flip)
+            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, decisions=dec.rec, allow=FLIP_ALLOW * n_flip)
         else:  # behind >= 1 Adam update: chaotic sign noise on both sides -- the distributions only have to overlap
-            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, k_med=5.0, k_max=5.0, anchor=1.0)
-        pipe.optimizer_updates(losses)
+            _check_or_event(other, step, False, title, e_hip, e_ref, g64_of, decisions=dec.rec, k_med=5.0, k_max=5.0, anchor=1.0)
+        with dec:
+            pipe.optimizer_updates(losses)
         if cfg_name == "voice2pose_s2g":  # second backward (discriminator step): its gradients exist after optimizer_updates
             torch.cuda.synchronize()
             params = dict(pipe.model.named_parameters())
@@ -385,7 +388,48 @@ def test_trajectory_is_as_close_to_float64_as_the_fp32_reference(golden_traj, go
             e_hip = {k.split("Dstep:")[1]: _sample_err(sl(params[k.split("Dstep:")[1]].grad)[:64], g64[k][:64]) for k in keys}
             e_ref = {k.split("Dstep:")[1]: _sample_err(g32[k][:64], g64[k][:64]) for k in keys}
             _check_or_event(other, step, True, title + " (discriminator step)", e_hip, e_ref,
-                            lambda k, _s=step: g64["s%d/grad/Dstep:%s" % (_s, k)][:64], k_med=5.0, k_max=5.0, anchor=1.0)
+                            lambda k, _s=step: g64["s%d/grad/Dstep:%s" % (_s, k)][:64], decisions=dec.rec, k_med=5.0, k_max=5.0, anchor=1.0)
+
+
+class _Decisions:
+    """Records the LeakyReLU decisions of everything that runs inside the ``with`` block: the sign bit of every activated output of the norm+activation
+    ops (ops.ColNormActFn / RowNormActFn / L0BlockFn / ConvRowNormFn) and -- the Conv1d chain -- of every block input it keeps for the backward pass
+    plus its output.  ``rec`` is a list of bool tensors in call order; two runs of the same step through the same routing give lists of equal layout."""
+    FNS = ("ColNormActFn", "RowNormActFn", "L0BlockFn", "ConvRowNormFn", "Chain1dFn")
+
+    def __init__(self):
+        self.rec, self._orig = [], {}
+
+    def __enter__(self):
+        from speechdrivestemplates_amd import ops
+        for name in self.FNS:
+            cls = getattr(ops, name)
+            orig = self._orig[name] = cls.__dict__["forward"]
+            fn = orig.__func__ if isinstance(orig, staticmethod) else orig
+
+            def wrapped(ctx, *a, _fn=fn, _name=name):
+                out = _fn(ctx, *a)
+                z = out[0] if isinstance(out, tuple) else out
+                self.rec.append(torch.signbit(z.detach()))
+                if _name == "Chain1dFn":
+                    self.rec.extend(torch.signbit(x.detach()) for x in (getattr(ctx, "xs", None) or []) if x is not None)
+                return out
+
+            setattr(cls, "forward", staticmethod(wrapped))
+        return self
+
+    def __exit__(self, *exc):
+        from speechdrivestemplates_amd import ops
+        for name, orig in self._orig.items():
+            setattr(getattr(ops, name), "forward", orig)
+        return False
+
+    @staticmethod
+    def differing(a, b):
+        """number of activation decisions that differ between two recordings of the same step; ``a`` may stop earlier than ``b`` (recorded up to the
+        generator's backward pass only): the common prefix is compared, and its layout must agree"""
+        assert 0 < len(a) <= len(b) and all(x.shape == y.shape for x, y in zip(a, b)), ("the two runs took different routes", len(a), len(b))
+        return int(sum(int((x != y).sum().item()) for x, y in zip(a, b)))
 
 
 ACT_EVENT_ALLOW = 1e-2  # B=4 fixtures: measured worst effect of ONE differing LeakyReLU decision on a gradient tensor (8.3e-3 of max: unet.e3.norm.weight
@@ -404,7 +448,7 @@ class _OtherConvArithmetic:
 
     def __init__(self, cfg_name, code_std):
         self.cfg_name, self.code_std = cfg_name, code_std
-        self.pipe, self.steps = None, []  # per replayed step: (generator-step grads, discriminator-step grads)
+        self.pipe, self.steps = None, []  # per replayed step: (generator-step grads, discriminator-step grads, activation decisions of the step)
 
     def grads(self, step, dstep=False):
         from speechdrivestemplates_amd import ops
@@ -417,28 +461,39 @@ class _OtherConvArithmetic:
                 batch = O.make_batch(4, 16, step=len(self.steps), seed=1)
                 if self.cfg_name == "voice2pose_s2g":
                     batch["speaker"] = ["oliver"] * 4
-                losses, _ = self.pipe.forward_backward(batch)
-                torch.cuda.synchronize()
-                g = {k: p.grad.detach().clone() for k, p in self.pipe.model.named_parameters() if p.grad is not None}
-                self.pipe.optimizer_updates(losses)
-                torch.cuda.synchronize()
+                with _Decisions() as dec:
+                    losses, _ = self.pipe.forward_backward(batch)
+                    torch.cuda.synchronize()
+                    g = {k: p.grad.detach().clone() for k, p in self.pipe.model.named_parameters() if p.grad is not None}
+                    self.pipe.optimizer_updates(losses)
+                    torch.cuda.synchronize()
                 d = {k: p.grad.detach().clone() for k, p in self.pipe.model.named_parameters() if p.grad is not None}
-                self.steps.append((g, d))
+                self.steps.append((g, d, dec.rec))
         finally:
             ops.F32_SPLIT = prev
         return self.steps[step][1 if dstep else 0]
 
+    def decisions(self, step):
+        self.grads(step)
+        return self.steps[step][2]
 
-def _check_or_event(other, step, dstep, title, e_hip, e_ref, g64_of, **kw):
-    """The unchanged bars; on failure the event protocol of _OtherConvArithmetic (voice2pose configs only: pose2pose has no Conv2d)."""
+
+def _check_or_event(other, step, dstep, title, e_hip, e_ref, g64_of, decisions=None, **kw):
+    """The unchanged bars; on failure the event protocol of _OtherConvArithmetic (voice2pose configs only: pose2pose has no Conv2d).
+    ``decisions``: the default variant's recorded activation decisions of this step (_Decisions.rec).  The allowance is granted only when the EVENT
+    IS PROVEN: at least one LeakyReLU decision of this step differs between the two arithmetic variants -- a gradient defect of the
+    default kernels that leaves every decision alone gets no allowance and fails the unchanged bars."""
     try:
         _check_grad_distributions(title, e_hip, e_ref, **kw)
         return
     except AssertionError:
-        if other is None:
+        if other is None or decisions is None:
             raise
     from speechdrivestemplates_amd import ops
     g2 = other.grads(step, dstep)
+    n_diff = _Decisions.differing(decisions, other.decisions(step))
+    print("  %s: activation decisions differing between F32_SPLIT = %s and %s: %d" % (title, ops.F32_SPLIT, not ops.F32_SPLIT, n_diff))
+    assert n_diff >= 1, (title, "the default arithmetic fails the unchanged bars and no activation decision differs from the other variant: not an event")
     e_other = {k: _sample_err(sl(g2[k])[:64], g64_of(k)) for k in e_hip}
     _check_grad_distributions(title + " [the other fp32 conv arithmetic, F32_SPLIT = %s: unchanged bars]" % (not ops.F32_SPLIT), e_other, e_ref, **kw)
     kw = dict(kw, allow=kw.get("allow", 0.0) + ACT_EVENT_ALLOW)

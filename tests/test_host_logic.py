@@ -159,3 +159,37 @@ def test_three_bf16_numbers_hold_a_fp32_number_exactly():
             + ah.double() * bh.double())
     exact = a.double() * b.double()
     assert ((kept - exact).abs() <= 2.0 ** -23 * exact.abs()).all()
+
+
+def test_device_copies_of_speaker_statistics_are_refreshed_in_place_never_freed():
+    """a captured hipGraph reads the device copy of a speaker's mean / std by raw pointer.  Registering the speaker again (every
+    SyntheticGestureDataset does) or editing a registered array must keep that memory alive and put the new values INTO it."""
+    import numpy as np
+    from types import SimpleNamespace
+    from speechdrivestemplates_amd.core.datasets import gesture_dataset as gd
+    tr = gd.PoseTransforms()
+    tr.cfg = SimpleNamespace(NUM_LANDMARKS=121, HIERARCHICAL_POSE=True)
+    rng = np.random.default_rng(0)
+    stat = {'scale_factor': 1.0, 'mean': rng.standard_normal(242), 'std': rng.random(242) + 0.5}
+    gd.register_speaker_stat('_cache_test', parted=stat)
+    kp = torch.zeros(2, 4, 2, 121)
+    m0 = tr._stat(stat['mean'], kp)
+    ptr = m0.data_ptr()
+    assert tr._stat(stat['mean'], kp).data_ptr() == ptr  # served from the table
+    # in-place edit: same tensor, new values
+    stat['mean'][:] = stat['mean'] + 1.0
+    m1 = tr._stat(stat['mean'], kp)
+    assert m1.data_ptr() == ptr and torch.allclose(m1.reshape(-1), torch.tensor(stat['mean'], dtype=torch.float32))
+    # the speaker is registered again with new arrays (a second dataset after a capture): the SAME memory carries the new table
+    stat2 = {'scale_factor': 1.0, 'mean': rng.standard_normal(242), 'std': rng.random(242) + 0.5}
+    gd.register_speaker_stat('_cache_test', parted=stat2)
+    assert torch.equal(m0.reshape(-1), torch.tensor(stat2['mean'], dtype=torch.float32))  # the old view sees the new values
+    assert tr._stat(stat2['mean'], kp).data_ptr() == ptr
+    # filling the table past its bound never drops an entry
+    keep = [rng.standard_normal(242) for _ in range(gd.PoseTransforms._STAT_CACHE_MAX + 8)]
+    for a in keep:
+        tr._stat(a, kp)
+    assert tr._stat(stat2['mean'], kp).data_ptr() == ptr
+    assert len(gd.PoseTransforms._STAT_ON_DEVICE) <= gd.PoseTransforms._STAT_CACHE_MAX
+    for k in [k for k, v in gd.PoseTransforms._STAT_ON_DEVICE.items() if any(v[0] is a for a in keep)]:
+        del gd.PoseTransforms._STAT_ON_DEVICE[k]  # (test hygiene only: nothing captured these)
