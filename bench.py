@@ -167,6 +167,18 @@ def cited_traffic(kernel_name):
     return info
 
 
+def cited_sustained_mhz():
+    """Shader clock during the dominant kernel's launches (GRBM_GUI_ACTIVE / duration) from the newest committed PMC pass (tools/pmc_summary.py
+    prints 'clock N GHz' per kernel); None when no summary carries it."""
+    import re
+    prof = os.path.join(REPO, "profiles")
+    for f in sorted((f for f in os.listdir(prof) if "_pmc_" in f and f.endswith(".txt")), reverse=True) if os.path.isdir(prof) else []:
+        m = re.search(r"clock ([0-9.]+) GHz", open(os.path.join(prof, f)).read())  # first line = the dominant kernel's launches
+        if m:
+            return {"sustained_mhz": float(m.group(1)) * 1e3, "sustained_mhz_source": "profiles/" + f}
+    return {"sustained_mhz": None}
+
+
 def cited_trace_fraction(kernel_name):
     """The rocprofv3 kernel-trace average of the dominant kernel (tools/collect_profiles.sh writes profiles/<round>_trace_fraction.json next
     to the trace summaries): cited beside the event-based figure while the kernel sources still hash to the digest recorded there."""
@@ -638,10 +650,17 @@ def main(argv=None):
                 r: {"launches_per_step": v[0] / dom_steps, "avg_launch_us": v[1] / v[0], "achieved": v[2] / (v[1] * 1e-6) / 1e12,
                     "frac": v[2] / (v[1] * 1e-6) / 1e12 / peak} for r, v in sorted(d["roles"].items())}
             out["roofline"].update(cited_traffic(name))
+            out["roofline"].update(cited_sustained_mhz())
             # the whole step against the fp32-MFMA floor of its convolutions: algorithmic conv FLOPs of a step / matrix peak / step time
             step_gflop = sum(v["flops"] for v in summ.values()) / prof_steps / 1e9
             out["roofline"]["step_gflop"] = step_gflop
-            out["roofline"]["step_frac"] = step_gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) / (clean_mean_ms * 1e-3)  # against the fp32-MFMA floor of rounds 1-4
+            # ONE peak convention per object: step_frac is quoted against the SAME peak as frac (the dominant kernel's); the figure
+            # against the fp32-MFMA floor of rounds 1-4 keeps its own, explicit name
+            out["roofline"]["step_frac"] = step_gflop * 1e9 / (peak * 1e12) / (clean_mean_ms * 1e-3)
+            out["roofline"]["step_frac_vs_fp32_mfma"] = step_gflop * 1e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12) / (clean_mean_ms * 1e-3)
+            out["roofline"]["peak_clock_mhz"] = 2400  # every peak in this line is at the 2.4 GHz boost clock; sustained_mhz is what the PMC run saw
+            if out["roofline"].get("traffic"):
+                out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / (d["bytes"] / d["launches"])
             out["conv_kernels_peak_tflops"] = {k: matrix_peak_tflops(k) for k in sorted(summ)}
             out["roofline"]["trace_based"] = cited_trace_fraction(name)
             if prof_ovl is not None and n_ovl > 0:

@@ -19,6 +19,34 @@ import torch.distributed as dist
 # step): 7.67 -> 7.89 / 8.12 ms per step without a reserve, 7.8 -> 7.9 with 32 (64 buys nothing more); the reserve costs ~0.1 ms when nothing else
 # runs, which is why it is not the single-GPU default.
 RESERVED_SLOTS = 32
+
+
+def reserved_slots():
+    """The reserve a new GradReducer takes: RESERVED_SLOTS (32: what RCCL's all-reduce kernels were emulated with), or -- when the launcher caps or
+    raises RCCL's channel count (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS: one long-lived 256-thread workgroup per channel) -- that many slots,
+    rounded up to the plan builder's multiple of 8 and kept within [8, 256]."""
+    n = int(RESERVED_SLOTS)
+    try:
+        ch = max(int(os.environ.get("NCCL_MAX_NCHANNELS", 0)), int(os.environ.get("NCCL_MIN_NCHANNELS", 0)))
+    except ValueError:
+        ch = 0
+    if ch > 0 and RESERVED_SLOTS == 32:  # (a caller that set RESERVED_SLOTS itself keeps its value)
+        n = ch
+    return max(8, min(256, (n + 7) // 8 * 8))
+
+
+def other_gpu_processes():
+    """PIDs (as the kernel driver numbers them) of OTHER processes that hold a compute context on a GPU of this node, from /sys/class/kfd/kfd/proc.
+    The persistent kernels assume the workgroup slots they plan for are theirs: a second tenant (another rank on the same GPU, a profiler's agent
+    process, somebody else's job) does not break results -- a starved launch sets its error word and the Trainer raises -- but it is worth a warning
+    before the first step rather than an exception at the first log step.  Empty when the directory is not readable (containers often hide it)."""
+    root = "/sys/class/kfd/kfd/proc"
+    try:
+        pids = [int(p) for p in os.listdir(root) if p.isdigit()]
+    except OSError:
+        return []
+    me = os.getpid()
+    return sorted(p for p in pids if p != me)
 # Reducers of this process that currently hold the reserve (ADVICE r4): the knob is process-wide, so it is set when the FIRST active reducer
 # appears and given back when the LAST one is closed -- a reducer dropped out of order (or collected late by the GC) must not switch the
 # reserve off under one that is still exchanging gradients.
@@ -31,7 +59,7 @@ def _acquire_reserve():
     from . import ops
     if _RESERVE_HOLDERS == 0:
         _RESERVE_PREV = ops.SK_RESERVED_SLOTS
-        ops.SK_RESERVED_SLOTS = RESERVED_SLOTS
+        ops.SK_RESERVED_SLOTS = reserved_slots()
     _RESERVE_HOLDERS += 1
 
 
@@ -144,6 +172,7 @@ class GradReducer:
             # persistent stream-K launches would otherwise occupy every workgroup slot of the GPU: leave the collective room (ops.SK_RESERVED_SLOTS)
             _acquire_reserve()
             self._holds_reserve = True
+            self._startup_warnings()
         self._pending = []
         # graph.GraphedStep, "split" form (a backend whose collectives cannot be captured): while a step is being captured, all_reduce() hands the
         # exchange to this callback -- it closes the graph segment, records the exchange as an eager item and opens the next segment -- and the
@@ -154,6 +183,23 @@ class GradReducer:
         # bench.py: pairs of events on the MAIN stream around all_reduce() -- the window is what the exchange costs the step
         # (launching the late buckets + waiting for the communication stream), i.e. the all-reduce time that backward did not hide
         self.exposed_events = None
+
+    def _startup_warnings(self):
+        """Things that cost a data-parallel run speed or robustness and are invisible otherwise: said once, up front."""
+        import warnings
+        from . import hw_queues
+        val, late = hw_queues()
+        if late:
+            warnings.warn("GPU_MAX_HW_QUEUES=8 was set by `import speechdrivestemplates_amd` AFTER the HIP runtime had initialised (a torch.cuda call came "
+                          "first): the runtime keeps its default of 4 hardware queues and the weight-gradient side stream will share a queue with the "
+                          "main stream (~8 % of a data-parallel step).  Export GPU_MAX_HW_QUEUES=8 in the launcher or import this package first.",
+                          RuntimeWarning, stacklevel=3)
+        others = other_gpu_processes()
+        if others and self.ws == 1:  # (with world > 1 the other ranks of this node are expected to show up here, one per GPU)
+            warnings.warn("%d other process(es) hold a compute context on this node's GPUs (kfd pids %s): the persistent conv kernels plan for a GPU of "
+                          "their own apart from %d reserved workgroup slots; if one of them runs on THIS GPU expect starved launches (error words -> "
+                          "RuntimeError at the next log step) -- raise dp.RESERVED_SLOTS (up to 256 = half of the GPU) for a shared device."
+                          % (len(others), others[:8], reserved_slots()), RuntimeWarning, stacklevel=3)
 
     def close(self):
         """Give the process-wide plan knob back (a reducer that is torn down must not leave later single-GPU work planning with a reserve).

@@ -20,6 +20,17 @@ from test_dp_gloo import _collect  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 CFG, N_CLIPS, B_RANK, STEPS = "voice2pose_sdt_vae", 16, 2, 2
+HALF_GPU = 256  # reserve (of 512 two-per-CU workgroup slots) with which two processes' persistent grids fit on one GPU side by side
+
+
+def _share_the_gpu(world):
+    """Two PROCESSES on one GPU (every world-2 test of this file): each plans its persistent stream-K grids for HALF of the GPU -- 256 two-per-CU
+    workgroups or 128 one-per-CU ones -- so that both are co-resident (round 5 reserved 248: 2 x 264 > 512 and 2 x 132 > 256, oversubscribed by
+    construction).  Not a production layout: a real run has one process per GPU and reserves dp.RESERVED_SLOTS."""
+    if world > 1:
+        from speechdrivestemplates_amd import dp, ops
+        dp.RESERVED_SLOTS = HALF_GPU
+        ops.SK_RESERVED_SLOTS_FWD = HALF_GPU
 
 
 def _slice(batch, lo, hi):
@@ -41,6 +52,7 @@ def _run(world, rank):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle import sdt_oracle as O
     from test_model_gpu import _make_pipeline
+    _share_the_gpu(world)
     pipe, _ = _make_pipeline(CFG, N_CLIPS, 0.0)
     launches = []
     if world > 1:
@@ -107,6 +119,7 @@ def _seed_worker(rank, world, port, q):
     from oracle import sdt_oracle as O
     from __graft_entry__ import make_pipeline
     torch.manual_seed(1234 + rank)
+    _share_the_gpu(world)
     for cfg_name in ("voice2pose_sdt_bp", "voice2pose_s2g"):
         pipe, _ = make_pipeline(cfg_name, N_CLIPS, batch_global=2 * B_RANK)
         w_init = pipe.optimizers["optimizerG"].flat_param.detach().cpu().clone()
@@ -216,6 +229,28 @@ def test_graph_replay_with_the_gradient_exchange_over_rccl(tmp_path, config, sto
     assert np.abs(d_full["flat"] - d_split["flat"]).max() <= 2 * 1e-4 * 4
 
 
+def _assert_step_is_finite_and_clean(pipe, ops, losses, step):
+    """After every step of a rank: no error word, and every loss, gradient and weight finite -- a non-finite value is reported HERE, with
+    the step and the parameters it covers, not four steps later as 'all weights NaN' (GPUTEST_r05; the invariant the persistent kernels promise is
+    'a lost partner poisons AND sets the word', so NaN with clean words is a kernel bug of another kind: tools/debug/dp_nan_hunt.py)."""
+    torch.cuda.synchronize()
+    codes = ops.streamk_error_codes()
+    assert not codes, (step, codes)
+    bad = [k for k, v in losses.items() if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all().item()]
+    assert not bad, "step %d: non-finite losses %s" % (step, bad)
+    for oname, opt in pipe.optimizers.items():
+        for what in ("flat_grad", "flat_param"):
+            t = getattr(opt, what)
+            nf = ~torch.isfinite(t)
+            if nf.any().item():
+                idx = nf.nonzero().reshape(-1)
+                lo, hi = int(idx[0]), int(idx[-1])
+                names = [n for (n, p), off in zip([(n, p) for n, p in pipe.model.named_parameters() if any(p is q for q in opt.params)], opt.offsets)
+                         if off <= hi and off + p.numel() > lo]
+                raise AssertionError("step %d: %d non-finite elements in %s.%s [%d, %d] (error words clean) covering %s"
+                                     % (step, int(nf.sum()), oname, what, lo, hi, names[:6]))
+
+
 def _run_modes(world, rank, storage, graph):
     """as _run, with the pipeline in ``storage`` and (graph) stepped through graph.GraphedStep; returns (weights, losses, segment kinds)"""
     sys.path.insert(0, REPO)
@@ -225,13 +260,7 @@ def _run_modes(world, rank, storage, graph):
     from speechdrivestemplates_amd.graph import GraphedStep
     from test_model_gpu import _make_pipeline
     ops.set_storage(storage)
-    if world > 1:
-        # two PROCESSES on one GPU: their persistent stream-K grids (bf16 storage uses them at every size) must fit side by side -- 264 workgroup
-        # slots each instead of 512 -- or owners spinning for partners that the other process's workgroups keep out starve each other until the
-        # spin limit poisons tiles with NaN (seen: this test, before the reserve).  A production run has one process per GPU.
-        from speechdrivestemplates_amd import dp
-        dp.RESERVED_SLOTS = 248
-        ops.SK_RESERVED_SLOTS_FWD = 248
+    _share_the_gpu(world)
     pipe, _ = _make_pipeline(CFG, N_CLIPS, 0.0)
     dev = torch.device("cuda", 0)
     gs = GraphedStep(pipe, warmup=1) if graph else None
@@ -247,7 +276,7 @@ def _run_modes(world, rank, storage, graph):
             losses, _ = pipe.forward_backward(batch)
             pipe.optimizer_updates(losses)
         hist.append(float(losses["G_reg_loss"].detach()))
-        assert not ops.streamk_error_codes(), (step, ops.streamk_error_codes())
+        _assert_step_is_finite_and_clean(pipe, ops, losses, step)
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu() for k, v in pipe.model.netG.state_dict().items()}
     return sd, hist, (None if gs is None or gs.segments is None else [k for k, _ in gs.segments])
@@ -310,6 +339,7 @@ def _error_word_worker(rank, world, port, q, tmp):
     from oracle import sdt_oracle as O
     from speechdrivestemplates_amd import ops
     from test_model_gpu import _make_pipeline
+    _share_the_gpu(world)
     pipe, _ = _make_pipeline(CFG, N_CLIPS, 0.0, extra_opts=["SYS.DISTRIBUTED", True, "SYS.LOG_INTERVAL", 2])
     pipe.base_path = tmp
 

@@ -229,6 +229,7 @@ def _plan_tables(ops, garr, n, rpg, bwd_groups, reserve=0):
 @pytest.mark.parametrize("case", [("3x3 pad 1, 10-row images (row-major, n-tile-major)", 32, 10, 53, 256, 256, 3, 3, 1, 1, "fwd", 0),
                                   ("(6,3) valid: input gradient (row-major, n-tile-major)", 32, 10, 53, 256, 256, 6, 3, 1, 0, "dx", 32),
                                   ("4x4 stride 2: input gradient, 4 parity classes", 8, 40, 213, 128, 128, 4, 4, 2, 1, "dx", 0),
+                                  ("3x3 pad 1 with HALF of the GPU reserved (two processes on one GPU)", 32, 20, 106, 128, 256, 3, 3, 1, 1, "fwd", 256),
                                   ("3x3 pad 1, 40-row images (natural order)", 8, 40, 213, 64, 128, 3, 3, 1, 1, "fwd", 0)], ids=lambda c: c[0])
 def test_streamk_plan_is_a_partition_of_the_work(case):
     """sdt_convsk_plan_build is host code: every output row appears exactly once with the offsets / tap masks a brute-force statement gives,
@@ -245,7 +246,7 @@ def test_streamk_plan_is_a_partition_of_the_work(case):
         rpg = -1
     hdr, rowinfo, tileinfo, tilecum, range_tile = _plan_tables(ops, garr, n, rpg, B if role == "dx" else 1, reserve)
     bm, nnb = hdr["bm"], hdr["nnb"]
-    assert hdr["G"] == 256 * hdr["wpc"] - reserve and hdr["ncls"] == n and hdr["bn"] * nnb == gs[0].Cout
+    assert hdr["G"] == (512 - reserve if hdr["wpc"] == 2 else (256 - reserve // 2) & ~7) and hdr["ncls"] == n and hdr["bn"] * nnb == gs[0].Cout
     SK_OOB = -(1 << 31)
     row0 = mt0 = 0
     total_live = 0

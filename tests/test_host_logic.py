@@ -193,3 +193,21 @@ def test_device_copies_of_speaker_statistics_are_refreshed_in_place_never_freed(
     assert len(gd.PoseTransforms._STAT_ON_DEVICE) <= gd.PoseTransforms._STAT_CACHE_MAX
     for k in [k for k, v in gd.PoseTransforms._STAT_ON_DEVICE.items() if any(v[0] is a for a in keep)]:
         del gd.PoseTransforms._STAT_ON_DEVICE[k]  # (test hygiene only: nothing captured these)
+
+
+def test_reserve_follows_the_rccl_channel_count(monkeypatch):
+    """dp.reserved_slots(): 32 by default; the launcher's RCCL channel cap when there is one (a channel is one long-lived workgroup), in the plan
+    builder's units (multiple of 8, at most half of the GPU); a caller's own dp.RESERVED_SLOTS wins."""
+    from speechdrivestemplates_amd import dp
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS", raising=False)
+    assert dp.reserved_slots() == 32
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "12")
+    assert dp.reserved_slots() == 16
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "64")
+    assert dp.reserved_slots() == 64
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "1000")
+    assert dp.reserved_slots() == 256
+    monkeypatch.setattr(dp, "RESERVED_SLOTS", 248)
+    assert dp.reserved_slots() == 248
+    assert isinstance(dp.other_gpu_processes(), list)

@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--poison", action="store_true")
     ap.add_argument("--trace", action="store_true")
-    ap.add_argument("--reserve", type=int, default=248)
+    ap.add_argument("--reserve", type=int, default=256)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=2)
     a = ap.parse_args()
