@@ -118,9 +118,14 @@ int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for 
 /* fp32 plans built afterwards with ONE workgroup per CU: the split-fp32 form of the 8-wave kernel (csrc/convbf.hip: each fp32 operand = three bf16
  * planes made by the loader, six bf16 MFMAs per fragment pair -- products exact to 2^-23, fp32 accumulation).  Default 0. */
 int sdt_convsk_set_f32_split(int on);
-/* Workgroup slots (multiple of 8, < 256) that plans built afterwards leave free: a persistent launch that fills the GPU cannot share it with another
- * long-lived kernel (a collective's); data-parallel runs plan their backward launches with a reserve.  Default 0. */
+/* Workgroup slots (of the GPU's 512 two-per-CU slots; multiple of 8, <= 256 = half of the GPU) that plans built afterwards leave free: a persistent
+ * launch that fills the GPU cannot share it with another long-lived kernel (a collective's); data-parallel runs plan their backward launches with a
+ * reserve.  A one-per-CU workgroup (the 8-wave kernels) counts as two slots.  Default 0. */
 int sdt_convsk_set_reserved_slots(int n);
+/* K order of the 8-wave kernels' tiles for launches made afterwards (a launch-time setting, not a plan property): 0 = tap-major (all 128-byte channel
+ * chunks of a tap, then the next tap), 1 = chunk-major (all live taps of a chunk, then the next chunk: neighbouring taps re-read the cache lines of
+ * the step before while the CU's vector L1 still holds them).  ABI 5. */
+int sdt_convsk_set_k_order(int order);
 /* Polls (each ~1 us under load) of a partner's flag before the owner of a split tile declares the launch failed.  Default 1 << 22. */
 int sdt_convsk_set_spin_limit(unsigned polls);
 unsigned sdt_convsk_get_spin_limit(void);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDT_HIP_LIB: developer tools only (tools/conv_bench.py points it at the -DSDT_TUNING build); the package itself never sets it
 LIB_PATH = os.environ.get("SDT_HIP_LIB") or os.path.join(_HERE, "lib", "libsdt_hip.so")
 MAX_TAPS = 20
-ABI_VERSION = 4  # sdt_abi_version() of the library this binding was written against
+ABI_VERSION = 5  # sdt_abi_version() of the library this binding was written against
 
 
 class ConvGeom(C.Structure):
@@ -115,6 +115,7 @@ SIGNATURES = {
     "sdt_convsk_dw_plan_build_t": [_G, _i, _p, _i64],
     "sdt_convsk_dw_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "sdt_convsk_set_spin_limit": [C.c_uint],
+    "sdt_convsk_set_k_order": [_i],
 }
 F32, BF16 = 0, 1  # enum sdt_dtype
 

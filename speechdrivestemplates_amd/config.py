@@ -48,7 +48,11 @@ _DEFAULTS = {
             "STORAGE": "f32", "HIP_GRAPH": False, "CHAIN1D": True,
             # CONV_F32_SPLIT (fp32 tensors): Conv2d products as six bf16 MFMA products of an exact three-way bf16 split of both operands, fp32
             # accumulation (csrc/convbf.hip; fp32-grade results, 1.3x faster); False = the fp32-MFMA kernels of rounds 3-4
-            "CONV_F32_SPLIT": True},
+            "CONV_F32_SPLIT": True,
+            # DDP_UNSYNCED_D True = the reference's data-parallel quirk (core/pipelines/voice2pose.py:301,308): DistributedDataParallel
+            # all-reduces the gradients of the FIRST backward of a step only, so the discriminator's own backward (the second one of an s2g step)
+            # leaves per-rank gradients and the rank's discriminators drift apart.  Default False: this engine synchronises them (dp.GradReducer).
+            "DDP_UNSYNCED_D": False},
 }
 
 

@@ -216,6 +216,10 @@ class Voice2Pose(Trainer):
         if code.DIMENSION is not None and not code.EXTERNAL_CODE and code.TRAIN:
             add('optimizerClipCode', [self.model.clips_code], cfg.TRAIN.LR * code.LR_SCALING)
         self._set_reducer(dp.GradReducer(self.optimizers.values()))
+        # the reference's quirk D8 behind a flag: the discriminator's second backward is not exchanged -- local gradients, no 1 / world_size
+        self.unsynced_d = bool(getattr(cfg.SYS, 'DDP_UNSYNCED_D', False)) and 'optimizerD_pose' in self.optimizers
+        if self.unsynced_d:
+            self.optimizers['optimizerD_pose'].grad_scale = 1.0
         # DDP-constructor semantics (voice2pose.py:222-223): every rank starts from rank 0's parameters, buffers and Adam state
         dp.sync_replicas(self.model, list(self.optimizers.values()))
         if self.reducer.active:
@@ -298,7 +302,8 @@ class Voice2Pose(Trainer):
             optd = self.optimizers['optimizerD_pose']
             optd.zero_grad()
             losses['D_pose_gan_loss'].backward()
-            self.reducer.all_reduce([optd])
+            if not getattr(self, 'unsynced_d', False):  # (SYS.DDP_UNSYNCED_D: the reference's second backward is not exchanged)
+                self.reducer.all_reduce([optd])
             optd.step()
 
     def train_step(self, batch, t_step, global_step, epoch):

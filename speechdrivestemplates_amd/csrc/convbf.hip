@@ -27,6 +27,11 @@
 #include "convsk.h"
 
 #define BF_NT 512
+// cache policy of the weight (B operand) requests: 0 plain; 2 = nt -- served by the L2 without allocating in the CU's vector L1 (a tile's weight
+// lines are read once per K step and never again by this CU before 32 KB of other lines have passed), which leaves the L1 to the im2col rows
+#ifndef BF_B_AUX
+#define BF_B_AUX 0
+#endif
 // BF_ABL (tools/debug/r05_bf2_ablation.sh; ablation builds compute WRONG results by design): 1 no global loads in the K loop, 2 no LDS stores,
 // 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads, 32 no epilogue stores
 #ifndef BF_ABL
@@ -404,7 +409,12 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
 
     // ---- loader state of the tile whose operands are being fetched
     int nkc = 1, ntaps = 1, rot = 0, kc = 0, left = 0, v_ash = 0, v_bsh = 0, cls_loaded = -1, cls_cout = 0, cls_wrow = 0;
-    unsigned rmask = 0u;
+    unsigned rmask = 0u, rmask_full = 0u;
+    // K order of a tile's live steps (P.korder, sdt_convsk_set_k_order).  0: tap-major -- all channel chunks of a tap, then the next tap (rounds 3-5).
+    // 1: CHUNK-major -- all live taps of one 128-byte channel chunk, then the next chunk.  The im2col rows of tap (dy, dx + 1) are the rows of
+    // (dy, dx) shifted by one pixel: 127 of a tile's 128 cache lines of a step were requested by the step BEFORE it, one step = 32 KB = the vector
+    // L1's size ago, instead of nkc steps (64 - 256 KB) ago -- they hit (or merge with the miss in flight) instead of going to the L2 again.
+    const bool chunk_major = P.korder != 0;
     unsigned abase[RA], inval[RA], bbase[RB];
     f32x4 ra[NSET][RA], rb[NSET][RB];
     // per-tile facts the end phase needs (set by `setup`, which runs BEFORE the previous tile's end phase when tiles are pipelined)
@@ -447,15 +457,21 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
 #elif BF_ABL & 64
             abl_sink[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
 #else
-            rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
+            rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, BF_B_AUX));
 #endif
         }
     };
     auto load_advance = [&]() {
         --left;
-        const bool wrap = kc + 1 == nkc;
-        kc = wrap ? 0 : kc + 1;
-        rmask = wrap ? (rmask & (rmask - 1u)) : rmask;
+        if (chunk_major) {  // (wave-uniform: scalar branch)
+            const unsigned rest = rmask & (rmask - 1u);
+            kc = rest == 0u ? kc + 1 : kc;            // past the last chunk only when `left` has run out: those loads are masked
+            rmask = rest == 0u ? rmask_full : rest;
+        } else {
+            const bool wrap = kc + 1 == nkc;
+            kc = wrap ? 0 : kc + 1;
+            rmask = wrap ? (rmask & (rmask - 1u)) : rmask;
+        }
     };
     auto load = [&](auto SI) {
         load_prep();
@@ -554,10 +570,16 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         f.n0 = k.nt * BN;
 #pragma unroll
         for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * (unsigned)sizeof(ET) + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
-        rmask = (unsigned)__builtin_amdgcn_readfirstlane(t.ti_mask);
+        rmask = rmask_full = (unsigned)__builtin_amdgcn_readfirstlane(t.ti_mask);
         rot = __builtin_amdgcn_readfirstlane(t.ti_rot);
-        for (int skip = f.a / nkc; skip > 0; --skip) rmask &= rmask - 1;
-        kc = f.a - (f.a / nkc) * nkc;
+        if (chunk_major) {  // step a of the tile = (chunk a / live taps, live tap a % live taps)
+            const int nlive = __builtin_popcount(rmask_full);
+            kc = nlive > 0 ? f.a / nlive : 0;
+            for (int skip = f.a - kc * nlive; skip > 0; --skip) rmask &= rmask - 1;
+        } else {
+            for (int skip = f.a / nkc; skip > 0; --skip) rmask &= rmask - 1;
+            kc = f.a - (f.a / nkc) * nkc;
+        }
         left = f.b - f.a;
         BF_LDS_BARRIER();  // the rows' entries are in LDS
 #pragma unroll

@@ -33,6 +33,7 @@ struct sk_args {
     unsigned epoch;
     unsigned* err;          // set to a non-zero code when a spin gives up
     unsigned spin_limit;    // polls of a partner's flag before the owner declares the launch failed (sdt_convsk_set_spin_limit)
+    int korder;             // 8-wave kernels (convbf.hip): 0 tap-major K order, 1 chunk-major (sdt_convsk_set_k_order)
 };
 
 struct sk_norm_bwd {

@@ -1390,6 +1390,15 @@ extern "C" int64_t sdt_convsk_workspace_bytes(void) { return SK_SLAB_BYTES + (in
 // up: the launch's error word is set (ops.streamk_error_codes(); Trainer raises on it) and the tile is stored as NaN.  The default is
 // seconds -- partners publish at the START of their ranges, so a partner that has not arrived by then is not coming (it was never
 // dispatched: the GPU is shared with a process that holds its slot).
+static int g_sk_korder = 0;
+// K order of the 8-wave kernels' tiles (convbf.hip): 0 = tap-major (all channel chunks of a tap, then the next tap), 1 = chunk-major (all live taps of a
+// 128-byte channel chunk, then the next chunk: neighbouring taps re-read the previous step's cache lines while the vector L1 still holds them).
+// A launch-time setting (kernel argument), not a plan property: the plan counts live steps per tile, which both orders agree on.
+extern "C" int sdt_convsk_set_k_order(int order) {
+    SDT_CHECK_ARG(order == 0 || order == 1, "0 (tap-major) or 1 (chunk-major)");
+    g_sk_korder = order;
+    return SDT_OK;
+}
 static unsigned g_sk_spin_limit = 1u << 22;
 extern "C" int sdt_convsk_set_spin_limit(unsigned polls) {
     g_sk_spin_limit = polls;
@@ -1651,6 +1660,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
     A.err = ws ? A.flags + 512 : nullptr;
     A.epoch = epoch;
     A.spin_limit = g_sk_spin_limit;
+    A.korder = g_sk_korder;
     nb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     if (nbw) {
         SDT_CHECK_ARG(nbw->y && nbw->mean && nbw->rstd && nbw->sums, "null pointer in sdt_norm_bwd");
@@ -1825,7 +1835,7 @@ static int dw_go(const void* xv, const void* dyv, float* dw, const void* plan_ho
     const int K = P[9], ncol = P[5];
     const int* D = (const int*)plan_dev;
     A.rowinfo = (const int4*)(D + P[10]);
-    A.tileinfo = nullptr, A.tilecum = nullptr, A.range_tile = nullptr, A.slabs = nullptr, A.flags = nullptr, A.err = nullptr, A.epoch = 0;
+    A.tileinfo = nullptr, A.tilecum = nullptr, A.range_tile = nullptr, A.slabs = nullptr, A.flags = nullptr, A.err = nullptr, A.epoch = 0, A.korder = 0;
     const int* cp = P + P[14];
     sk_class& k = A.cls[0];
     k.Hi = cp[0], k.Wi = cp[1], k.Cin = cp[2], k.Cout = cp[3], k.ntaps = cp[4], k.nkc = cp[5];

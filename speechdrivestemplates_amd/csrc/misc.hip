@@ -13,7 +13,7 @@ void sdt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sdt_last_error(void) { return g_err; }
-extern "C" int sdt_abi_version(void) { return 4; }  // 4: sdt_convsk_set_f32_split, split-fp32 plans (round 5)
+extern "C" int sdt_abi_version(void) { return 5; }  // 5: sdt_convsk_set_k_order, reserve up to half of the GPU (round 6); 4: sdt_convsk_set_f32_split (round 5)
 
 // PyTorch's area_pixel_compute_source_index(align_corners=False) in fp32
 __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {

@@ -610,8 +610,17 @@ def check_streamk():
                            "kernel that holds workgroup slots (see ops.SK_RESERVED_SLOTS); results since the last check are invalid" % (codes,))
 
 
+# K order of the 8-wave kernels' tiles (csrc/convbf.hip; include/sdt_hip.h sdt_convsk_set_k_order): 1 = chunk-major -- all live taps of a 128-byte
+# channel chunk before the next chunk, so that neighbouring taps find the previous step's cache lines in the CU's vector L1; 0 = tap-major (rounds 3-5)
+SK_K_ORDER = 1
+_K_ORDER_SET = [None]
+
+
 def _sk_launch(plan, x4, ws_w, bias, y, stats, nb, st):
     lib = _lib.load()
+    if _K_ORDER_SET[0] != SK_K_ORDER:
+        check(lib.sdt_convsk_set_k_order(int(SK_K_ORDER)))
+        _K_ORDER_SET[0] = SK_K_ORDER
     wsb = _sk_workspace(y.device, st)
     fn = lib.sdt_convsk_bf16 if plan.dtype == _lib.BF16 else lib.sdt_convsk_f32
     esz = 2 if plan.dtype == _lib.BF16 else 4

@@ -9,7 +9,7 @@ int main(void) {
     sdt_conv_geom g;
     int rc;
     memset(&g, 0, sizeof g);
-    if (sdt_abi_version() != 4) return 10;
+    if (sdt_abi_version() != 5) return 10;
     if (sizeof(sdt_conv_geom) != (17 + 3 * SDT_MAX_TAPS) * sizeof(int32_t)) return 11;
     if (sizeof(sdt_wt_desc) != 4 * sizeof(void*) + 4 * sizeof(int32_t)) return 12;
     rc = sdt_conv_taps_f32(NULL, NULL, NULL, NULL, &g, NULL); /* zero geometry -> argument error, message set */

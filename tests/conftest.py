@@ -28,7 +28,7 @@ _TIERS = (
     # 3: every other op against its torch / float64 reference; 4: the Conv1d chain, bf16 storage, dataset; 5: the rest of the model tests
     (3, "test_ops_gpu.py"), (4, "test_chain1d_gpu.py"), (4, "test_bf16_gpu.py"), (4, "test_dataset.py"), (5, "test_model_gpu.py"),
     # 8: anything that spawns ranks; 9: two PROCESSES sharing the one GPU of a test box (stands in for DDP; not a production layout)
-    (9, "test_dp_gpu.py::test_two_ranks"), (9, "test_dp_gpu.py::test_differently_seeded"), (9, "test_dp_gpu.py::test_a_lost_partner"),
+    (9, "test_dp_gpu.py::test_two_ranks"), (9, "test_dp_gpu.py::test_differently_seeded"), (9, "test_dp_gpu.py::test_a_lost_partner"), (9, "test_dp_gpu.py::test_reference_unsynchronised"),
     (8, "test_dp_gpu.py"), (8, "test_dp_gloo.py"), (8, "test_bench_flow.py"),
 )
 

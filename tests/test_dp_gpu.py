@@ -160,6 +160,47 @@ def test_differently_seeded_ranks_are_synchronised_at_construction():
             assert any(not np.array_equal(sd0[k], sd1[k]) for k in sd0 if "running_mean" in k)
 
 
+def _quirk_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, REPO)
+    from oracle import sdt_oracle as O
+    from __graft_entry__ import make_pipeline
+    _share_the_gpu(world)
+    pipe, _ = make_pipeline("voice2pose_s2g", N_CLIPS, batch_global=2 * B_RANK, sys_opts={"DDP_UNSYNCED_D": True})
+    assert pipe.unsynced_d and pipe.optimizers["optimizerD_pose"].grad_scale == 1.0 and pipe.optimizers["optimizerG"].grad_scale == 0.5
+    for step in range(STEPS):
+        full = O.make_batch(B_RANK * 2, N_CLIPS, step=step, seed=1)
+        full["speaker"] = ["synthetic"] * (2 * B_RANK)
+        losses, _ = pipe.forward_backward(_slice(full, rank * B_RANK, (rank + 1) * B_RANK))
+        pipe.optimizer_updates(losses)
+    torch.cuda.synchronize()
+    q.put((rank, pipe.optimizers["optimizerG"].flat_param.detach().cpu().numpy(), pipe.optimizers["optimizerD_pose"].flat_param.detach().cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_reference_unsynchronised_discriminator_quirk_behind_a_flag():
+    """SURVEY D8 / VERDICT r5 missing 6: under DistributedDataParallel the reference exchanges the gradients of a step's FIRST backward only
+    (core/pipelines/voice2pose.py:301,308), so its per-rank discriminators drift.  This engine synchronises them by default (the test above:
+    every s2g tensor identical on both ranks); SYS.DDP_UNSYNCED_D reproduces the quirk: generators identical, discriminators not."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_quirk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    (_, g0, d0), (_, g1, d1) = sorted(_collect(procs, q, 2, 800), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert np.isfinite(g0).all() and np.isfinite(d0).all() and np.isfinite(d1).all()
+    assert np.array_equal(g0, g1)          # first backward: exchanged
+    assert not np.array_equal(d0, d1)      # second backward: per-rank gradients (different half batches) -> the discriminators have drifted
+
+
 def test_emulated_collective_costs_at_most_three_percent():
     """the one thing a single-GPU box can say about persistent conv kernels sharing the GPU with a collective.  32 spinning
     workgroups that need a CU slot (64 KB of LDS each) for 600 us per step -- what RCCL's all-reduce kernels look like to the stream-K launches,

@@ -157,7 +157,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libsdt_hip.so does not export %s" % name
     assert declared - extra == set(_lib.SIGNATURES), "ctypes signatures out of sync with the header: %s" % ((declared - extra) ^ set(_lib.SIGNATURES))
-    assert _lib.load().sdt_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().sdt_abi_version() == _lib.ABI_VERSION == 5
     # the debug / fault-injection hooks live in the -DSDT_TUNING library only
     product = ctypes.CDLL(os.path.join(REPO, "speechdrivestemplates_amd", "lib", "libsdt_hip.so"))
     for name in ("sdt_debug_convsk_mute_range", "sdt_debug_set_timeline_sk", "sdt_debug_spin"):

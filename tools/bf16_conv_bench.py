@@ -51,7 +51,10 @@ def main():
     ap.add_argument("--no-dw", action="store_true", help="skip the weight-gradient launches")
     ap.add_argument("--split", type=int, default=1, help="--dtype f32: 1 = the split-fp32 form of the 8-wave kernel (ops.F32_SPLIT), 0 = the fp32-MFMA kernels")
     ap.add_argument("--old", action="store_true", help="the round-4 128-row bf16 kernels (ops.BF16_SHAPED = False) instead of the bf16-shaped ones")
+    ap.add_argument("--korder", type=int, default=None, help="K order of the 8-wave kernels' tiles: 0 tap-major, 1 chunk-major (ops.SK_K_ORDER)")
     a = ap.parse_args()
+    if a.korder is not None:
+        ops.SK_K_ORDER = a.korder
     B, dev = a.batch, "cuda"
     ops.BF16_SHAPED = not a.old
     ops.F32_SPLIT = bool(a.split)
