@@ -112,6 +112,10 @@ int sdt_conv_taps_multi_f32(const float* x, const float* w, float* y, const sdt_
  *   sdt_convsk_f32           the launch; stats / nb as in sdt_conv_taps_stats_f32 / sdt_conv_taps_multi_f32 (at most one of them);
  *                            xbytes / wbytes / ybytes: sizes of the X, W and Y tensors
  */
+/*   sdt_convsk_f32_w3        the same launch for a split-fp32 plan (sdt_convsk_set_f32_split) with the weights ALREADY split: w3 = three bf16 planes
+ *                            [hi | mid | lo] of the (N, Tw, Cin) weight tensor (sdt_wt_desc.planes = 3 makes them); wbytes = the fp32 tensor's size.
+ *                            Bit-identical results to sdt_convsk_f32 on the fp32 weights (the same split, made once per optimiser step instead of in
+ *                            every tile on every K step).  ABI 5. */
 int sdt_convsk_supported(const sdt_conv_geom* geoms, int ncls);
 int sdt_convsk_grid(void);
 int sdt_convsk_set_wg_per_cu(int n); /* 1 or 2 persistent workgroups per CU for plans built afterwards (default 2) */
@@ -126,6 +130,8 @@ int sdt_convsk_set_reserved_slots(int n);
  * chunks of a tap, then the next tap), 1 = chunk-major (all live taps of a chunk, then the next chunk: neighbouring taps re-read the cache lines of
  * the step before while the CU's vector L1 still holds them).  ABI 5. */
 int sdt_convsk_set_k_order(int order);
+int sdt_convsk_f32_w3(const float* x, const void* w3, const float* bias, float* y, const void* plan_host, const void* plan_dev, void* workspace,
+                      unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream);
 /* Polls (each ~1 us under load) of a partner's flag before the owner of a split tile declares the launch failed.  Default 1 << 22. */
 int sdt_convsk_set_spin_limit(unsigned polls);
 unsigned sdt_convsk_get_spin_limit(void);
@@ -211,6 +217,10 @@ typedef struct sdt_wt_desc {
     void* w16;      /* nullable: bf16 copy of w (round to nearest even), the bf16-storage path's forward / weight operand */
     void* wt16;     /* nullable: bf16 copy of the mirror */
     int32_t cout, taps, cin, tile_begin;
+    int32_t planes; /* what w16 / wt16 receive: 1 (or 0) = one bf16 copy; 3 = the exact three-way bf16 split [hi | mid | lo], three planes of
+                       cout * taps * cin elements each: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) -- the pre-split B operand of
+                       sdt_convsk_f32_w3 (ABI 5) */
+    int32_t reserved;
 } sdt_wt_desc;
 int sdt_weight_transpose_batched_f32(const sdt_wt_desc* table, int n_layers, int total_tiles, void* stream);
 

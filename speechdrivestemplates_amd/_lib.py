@@ -30,7 +30,7 @@ class NormBwd(C.Structure):
 class WtDesc(C.Structure):
     """Mirror of ``sdt_wt_desc`` (include/sdt_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("w16", C.c_void_p), ("wt16", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32),
-                ("cin", C.c_int32), ("tile_begin", C.c_int32)]
+                ("cin", C.c_int32), ("tile_begin", C.c_int32), ("planes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ChainLayer(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "sdt_convsk_dw_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "sdt_convsk_f32": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
     "sdt_convsk_bf16": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
+    "sdt_convsk_f32_w3": [_p, _p, _p, _p, _p, _p, _p, C.c_uint, _p, C.POINTER(NormBwd), _i64, _i64, _i64, _p],
     "sdt_convsk_supported_t": [_G, _i, _i],
     "sdt_convsk_plan_build_t": [_G, _i, _i, _i, _i, _i, _p, _i64],
     "sdt_convsk_dw_supported_t": [_G, _i],

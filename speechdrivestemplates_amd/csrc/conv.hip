@@ -1495,6 +1495,20 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+// one bf16 copy (round to nearest even), or -- planes == 3 -- the exact three-way split the split-fp32 kernels make in their loaders (convbf.hip
+// x3_stage: the same conversions and the same exact fp32 differences, so a launch on pre-split weights is bit-identical to one that splits itself)
+__device__ __forceinline__ void wt_store16(__bf16* dst, const size_t o, const size_t nel, const int planes, const float v) {
+    const __bf16 hi = (__bf16)v;
+    dst[o] = hi;
+    if (planes == 3) {
+        const float r = v - (float)hi;
+        const __bf16 mid = (__bf16)r;
+        const float t = r - (float)mid;
+        dst[nel + o] = mid;
+        dst[2 * nel + o] = (__bf16)t;
+    }
+}
+
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt_wt_desc* __restrict__ table, int n_layers) {
     __shared__ float tile[32][33];
     const int bid = blockIdx.x;
@@ -1502,6 +1516,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt
     while (l + 1 < n_layers && table[l + 1].tile_begin <= bid) ++l;  // <= a few dozen layers
     const sdt_wt_desc d = table[l];
     const int nci = (d.cin + 31) >> 5, nco = (d.cout + 31) >> 5;
+    const size_t nel = (size_t)d.cout * d.taps * d.cin;
     int rem = bid - d.tile_begin;
     const int ci0 = (rem % nci) * 32;
     rem /= nci;
@@ -1514,7 +1529,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt
         const size_t o = ((size_t)co * d.taps + t) * d.cin + ci;
         const float v = ok ? d.w[o] : 0.f;
         tile[ty + 8 * i][tx] = v;
-        if (ok && d.w16 != nullptr) ((__bf16*)d.w16)[o] = (__bf16)v;  // bf16 copy of W itself (the bf16-storage path's forward operand)
+        if (ok && d.w16 != nullptr) wt_store16((__bf16*)d.w16, o, nel, d.planes, v);  // bf16 copy of W itself (the bf16-storage path's forward operand) / its split
     }
     __syncthreads();
 #pragma unroll
@@ -1524,7 +1539,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const sdt
             const size_t o = ((size_t)ci * d.taps + t) * d.cout + co;
             const float v = tile[tx][ty + 8 * i];
             if (d.wt != nullptr) d.wt[o] = v;
-            if (d.wt16 != nullptr) ((__bf16*)d.wt16)[o] = (__bf16)v;  // and of the mirror (its input-gradient operand)
+            if (d.wt16 != nullptr) wt_store16((__bf16*)d.wt16, o, nel, d.planes, v);  // and of the mirror (its input-gradient operand)
         }
     }
 }

@@ -305,18 +305,20 @@ __device__ __forceinline__ void x3_stage(float* dst, const int plane_stride, con
 
 // sched_group_barrier templates of an X3 K step (literal counts, hence the recursion).  Region 1, per MFMA q of NQ: one fragment read while any are
 // left, the VALU share of the splits (NL x 24 instructions over the first NQ - 2 MFMAs), one LDS store every other MFMA, one request every NQ / NL.
-template <int Q, int NQ, int NR, int NL>
+// NSP: operand rows a thread SPLITS per step (24 VALU + 3 ds_write_b64 each), NCP: rows it only COPIES (pre-split weight planes: one ds_write_b128 each)
+template <int Q, int NQ, int NR, int NSP, int NCP>
 __device__ __forceinline__ void x3_pattern() {
     if constexpr (Q < NQ) {
+        constexpr int NL = NSP + NCP;
         SK_SGB(0x8, 1);
         if constexpr (Q < NR) SK_SGB(0x100, 1);
-        constexpr int NV = NL * 24, per = (NV + NQ - 3) / (NQ - 2);
+        constexpr int NV = NSP * 24, per = (NV + NQ - 3) / (NQ - 2);
         if constexpr (Q * per < NV) SK_SGB(0x2, per);
-        constexpr int NW = NL * 3, w0 = Q * NW / NQ, w1 = (Q + 1) * NW / NQ;
+        constexpr int NW = NSP * 3 + NCP, w0 = Q * NW / NQ, w1 = (Q + 1) * NW / NQ;
         if constexpr (Q >= 2 && w1 > w0) SK_SGB(0x200, w1 - w0);
         constexpr int l0 = Q * NL / NQ, l1 = (Q + 1) * NL / NQ;
         if constexpr (Q >= 3 && l1 > l0) SK_SGB(0x20, l1 - l0);
-        x3_pattern<Q + 1, NQ, NR, NL>();
+        x3_pattern<Q + 1, NQ, NR, NSP, NCP>();
     }
 }
 template <int Q, int NQ, int NR>
@@ -331,11 +333,16 @@ __device__ __forceinline__ void x3_pattern2() {
 
 // EPI: 0 = store (+ bias), 1 = + forward statistics (stats: fp64 atomics, zero on entry), 2 = + normalisation-backward statistics
 // ET = __bf16: bf16 tensors, one MFMA per fragment pair.   ET = float: the SPLIT-fp32 form (X3) -- see the note above x3_split.
-template <typename ET, int BM, int BN, int WGM, int WGN, int EPI>
+// W3 (split form only): W points to the weights ALREADY split -- three bf16 planes [hi | mid | lo], each (N, Tw * Cin), made once per optimiser step
+// (sdt_split3_batched_f32) instead of by every tile of every launch on every K step: the B operand's share of the split (half of a 128 x 128
+// tile's 96 VALU instructions per loader thread and step) leaves the loop; a B row of a step is 3 x 64 bytes copied global -> LDS in 16-byte chunks.
+template <typename ET, int BM, int BN, int WGM, int WGN, int EPI, bool W3 = false>
 __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict__ X, const ET* __restrict__ W, const float* __restrict__ bias,
                                                           ET* __restrict__ Y, const sk_args P, double* __restrict__ stats, const sk_norm_bwd nb) {
     constexpr bool X3 = sizeof(ET) == 4;
+    static_assert(X3 || !W3, "pre-split weights belong to the split-fp32 form");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32, RA = BM / 64, RB = BN / 64, NM = TM * TN, NF = TM + TN;
+    constexpr int RBL = W3 ? (BN * 12 + BF_NT - 1) / BF_NT : RB;  // B requests per loader thread and step (W3: BN rows x 3 planes x 4 chunks of 16 bytes)
     // LDS floats per buffer of A / B.  bf16: [row][128 B + 16 B pad].  X3: [plane hi / mid / lo][row][64 B], 16-byte chunks XOR-swizzled by (row >> 2) & 3
     constexpr int A_BUF = X3 ? 3 * BM * X3_ROW : BM * SK_LDP, B_BUF = X3 ? 3 * BN * X3_ROW : BN * SK_LDP;
     // Staging register sets = how many K steps a request has to land before its data is stored to LDS: two when the accumulators leave room.
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     if (s_end <= s_begin) return;
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)P.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)P.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, W3 ? (int)(P.wbytes / 2 * 3) : (int)P.wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)P.ybytes, 0x00020000);
 
     const int row0 = wm * (TM * 32), col0 = wn * (TN * 32);
@@ -374,6 +381,18 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     const int fk0 = (((lane >> 5)) ^ fsw) * 4, fk1 = ((2 + (lane >> 5)) ^ fsw) * 4;  // X3: float offset of the lane's chunk of k-group 0 / 1
     // loader thread (r0, kv): 16 bytes = 8 bf16 channels (bf16) / 4 fp32 channels that become 8 bytes per plane (X3)
     const int wofs = X3 ? r0 * X3_ROW + ((((kv >> 1) ^ ((r0 >> 2) & 3)) * 4) + (kv & 1) * 2) : r0 * SK_LDP + kv * 4;
+    // W3: request j of this thread is 16-byte chunk c = (tid + 512 j) mod (12 BN) of the step's B tile: plane c / (4 BN), row (c mod 4 BN) / 4, chunk c & 3
+    // (the wrapped-around chunks of the last request duplicate another thread's load and store: same address, same data)
+    // BN = 128: 4 BN = 512 = the workgroup -- request j IS plane j of row tid >> 2: one LDS offset / one global base + a constant per plane
+    constexpr bool W3_PLANE_PER_REQ = W3 && BN * 4 == BF_NT;
+    auto b3_plane = [&](const int j) { return W3_PLANE_PER_REQ ? j : ((tid + BF_NT * j) % (BN * 12)) / (BN * 4); };
+    auto b3_row = [&](const int j) { return W3_PLANE_PER_REQ ? (tid >> 2) : (((tid + BF_NT * j) % (BN * 12)) % (BN * 4)) >> 2; };
+    int wofs3[(W3 && !W3_PLANE_PER_REQ) ? RBL : 1];
+    if constexpr (W3) {
+#pragma unroll
+        for (int j = 0; j < (W3_PLANE_PER_REQ ? 1 : RBL); ++j)
+            wofs3[j] = b3_plane(j) * (BN * X3_ROW) + b3_row(j) * X3_ROW + (((tid & 3) ^ ((b3_row(j) >> 2) & 3)) * 4);
+    }
 
     // ---- the walk over the range's tiles: cursor (tile, class c, m-tile mt, n-tile nt)
     struct Cursor {
@@ -415,8 +434,9 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     // (dy, dx) shifted by one pixel: 127 of a tile's 128 cache lines of a step were requested by the step BEFORE it, one step = 32 KB = the vector
     // L1's size ago, instead of nkc steps (64 - 256 KB) ago -- they hit (or merge with the miss in flight) instead of going to the L2 again.
     const bool chunk_major = P.korder != 0;
-    unsigned abase[RA], inval[RA], bbase[RB];
-    f32x4 ra[NSET][RA], rb[NSET][RB];
+    unsigned abase[RA], inval[RA], bbase[W3_PLANE_PER_REQ ? 1 : RBL];
+    unsigned b3_plane_bytes = 0u;  // W3_PLANE_PER_REQ: distance of the weight planes (scalar)
+    f32x4 ra[NSET][RA], rb[NSET][RBL];
     // per-tile facts the end phase needs (set by `setup`, which runs BEFORE the previous tile's end phase when tiles are pipelined)
     struct TileFacts {
         int Cout, n0, a, b, tbeg, tend;
@@ -425,7 +445,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     // load_advance().  The K loop places the ops one by one between its MFMAs; `load` is all of them in a row (pipeline fill).
     int ld_ash = 0, ld_cs = 0, ld_sh = 0;
 #if BF_ABL & 64
-    f32x4 abl_sink[RA + RB];
+    f32x4 abl_sink[RA + RBL];
 #endif
     unsigned ld_bsh = 0u;
     auto load_prep = [&]() {
@@ -437,6 +457,9 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         ld_ash = __builtin_amdgcn_readlane(v_ash, t);
         ld_bsh = (unsigned)__builtin_amdgcn_readlane(v_bsh, t) + (on ? 0u : SK_OOB);  // bbase + bshift < 2^31: the top bit pushes it out of range
         ld_cs = kc * 128;  // a K step is 128 bytes of a row
+        if constexpr (W3) {    // ... and 64 bytes of a row of each weight plane; byte shifts of the bf16 planes are half the fp32 tensor's
+            ld_bsh = ((unsigned)__builtin_amdgcn_readlane(v_bsh, t) >> 1) + (on ? 0u : SK_OOB);
+        }
         // the row's invalid-tap bit moves to bit 31 of the offset: out of range, the load returns zeros.  Loader off: shift 0 brings the always-set bit 31 there
         ld_sh = on ? 31 - t : 0;
     };
@@ -451,13 +474,16 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
 #else
             ra[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)o, ld_cs, 0));
 #endif
-        } else if (i < RA + RB) {
+        } else if (i < RA + RBL) {
+            // W3: 64 bytes of a plane's row per step; plane-per-request: the plane's distance rides in the scalar offset
+            const int bcs = W3 ? (ld_cs >> 1) + (W3_PLANE_PER_REQ ? (i - RA) * (int)b3_plane_bytes : 0) : ld_cs;
+            const unsigned bb = bbase[W3_PLANE_PER_REQ ? 0 : i - RA];
 #if BF_ABL & 1
-            rb[S_][i - RA][0] = __uint_as_float(bbase[i - RA] + ld_bsh + (unsigned)ld_cs);
+            rb[S_][i - RA][0] = __uint_as_float(bb + ld_bsh + (unsigned)bcs);
 #elif BF_ABL & 64
-            abl_sink[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, 0));
+            abl_sink[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bb + ld_bsh), bcs, 0));
 #else
-            rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bbase[i - RA] + ld_bsh), ld_cs, BF_B_AUX));
+            rb[S_][i - RA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(bb + ld_bsh), bcs, BF_B_AUX));
 #endif
         }
     };
@@ -476,18 +502,20 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     auto load = [&](auto SI) {
         load_prep();
 #pragma unroll
-        for (int i = 0; i < RA + RB; ++i) load_op(SI, i);
+        for (int i = 0; i < RA + RBL; ++i) load_op(SI, i);
         load_advance();
     };
     auto stage_op = [&](auto SI, const int buf, const int i) {  // operand row i of the staged step: registers -> LDS[buf]
         constexpr int S_ = decltype(SI)::value;
 #if BF_ABL & 2
         if (i < RA) asm volatile("" ::"v"(ra[S_][i]));
-        else if (i < RA + RB) asm volatile("" ::"v"(rb[S_][i - RA]));
+        else if (i < RA + RBL) asm volatile("" ::"v"(rb[S_][i - RA]));
 #else
         if constexpr (X3) {
             if (i < RA) x3_stage(sA + buf * A_BUF + wofs + 64 * i * X3_ROW, BM * X3_ROW, ra[S_][i]);
-            else if (i < RA + RB) x3_stage(sB + buf * B_BUF + wofs + 64 * (i - RA) * X3_ROW, BN * X3_ROW, rb[S_][i - RA]);
+            else if constexpr (W3) {  // already planes: a copy
+                if (i < RA + RBL) *(f32x4*)(sB + buf * B_BUF + (W3_PLANE_PER_REQ ? wofs3[0] + (i - RA) * (BN * X3_ROW) : wofs3[i - RA])) = rb[S_][i - RA];
+            } else if (i < RA + RB) x3_stage(sB + buf * B_BUF + wofs + 64 * (i - RA) * X3_ROW, BN * X3_ROW, rb[S_][i - RA]);
         } else {
             if (i < RA) *(f32x4*)&sA[buf * A_BUF + wofs + 64 * i * SK_LDP] = ra[S_][i];
             else if (i < RA + RB) *(f32x4*)&sB[buf * B_BUF + wofs + 64 * (i - RA) * SK_LDP] = rb[S_][i - RA];
@@ -498,7 +526,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         constexpr int S_ = decltype(SI)::value;
         if constexpr (X3) {
 #pragma unroll
-            for (int i = 0; i < RA + RB; ++i) stage_op(SI, buf, i);
+            for (int i = 0; i < RA + RBL; ++i) stage_op(SI, buf, i);
             return;
         }
         float* wA = sA + buf * A_BUF + wofs;
@@ -568,8 +596,17 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
         f.a = pos - f.tbeg;
         f.b = min(s_end, f.tend) - f.tbeg;
         f.n0 = k.nt * BN;
+        if constexpr (W3_PLANE_PER_REQ) {
+            b3_plane_bytes = P.wbytes >> 1;  // plane (N, Tw * Cin) bf16; the planes are wbytes / 2 apart
+            bbase[0] = (unsigned)((f.n0 + b3_row(0)) * cls_wrow) * 2u + (unsigned)(tid & 3) * 16u;
+        } else if constexpr (W3) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * (unsigned)sizeof(ET) + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
+            for (int j = 0; j < RBL; ++j)
+                bbase[j] = (unsigned)b3_plane(j) * (P.wbytes >> 1) + (unsigned)((f.n0 + b3_row(j)) * cls_wrow) * 2u + (unsigned)(tid & 3) * 16u;
+        } else {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) bbase[i] = (unsigned)((f.n0 + r0 + 64 * i) * cls_wrow) * (unsigned)sizeof(ET) + (unsigned)kv * 16u;  // W is (N, Tw, Cin)
+        }
         rmask = rmask_full = (unsigned)__builtin_amdgcn_readfirstlane(t.ti_mask);
         rot = __builtin_amdgcn_readfirstlane(t.ti_rot);
         if (chunk_major) {  // step a of the tile = (chunk a / live taps, live tap a % live taps)
@@ -612,7 +649,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
     // reads, of the LDS stores of step s + 1 and of the requests that re-fill the registers just stored.  Left to itself hipcc chained the four
     // k-groups of one accumulator back to back (dependent MFMAs) with an `s_waitcnt lgkmcnt(0)` in front of each: nothing overlapped, and the
     // ablation was additive -- without MFMAs the loop got shorter by exactly the MFMAs' execution time (profiles/r05_bf2_ablation_v0.txt).
-    constexpr int NL = RA + RB;
+    constexpr int NL = RA + RBL;
     constexpr int RPM = (NF + NM - 1) / NM;  // fragment reads per MFMA slot
     // The L1 accepts 64 B per clock: the 48 (BN 128) / 64 / 40 KB that a workgroup requests per K step keep it busy for 768 / 1024 / 640 cycles, and
     // a wave whose request is not accepted yet issues nothing else (in order) -- with all requests in the first half of the step the eight waves
@@ -683,7 +720,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
                 const int J = q / (6 * NM), pr = (q % (6 * NM)) / NM, t = q % NM;
                 BF_MFMA(acc[t / TN][t % TN], xa[J][PA[pr]][t / TN], xb[J][PB[pr]][t % TN]);
             }
-            x3_pattern<0, BAR, NR, NL>();
+            x3_pattern<0, BAR, NR, W3 ? RA : NL, W3 ? RBL : 0>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my stores to LDS[next] are done
 #ifdef SDT_TUNING
@@ -884,7 +921,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
 #endif
 #if BF_ABL & 64
 #pragma unroll
-        for (int i = 0; i < RA + RB; ++i) asm volatile("" ::"v"(abl_sink[i]));
+        for (int i = 0; i < RA + RBL; ++i) asm volatile("" ::"v"(abl_sink[i]));
 #endif
 
         // ---- the tile's facts for the end phase; then the NEXT tile's loader state and first request, before the end phase
@@ -1017,17 +1054,17 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
 #undef sFlagOk
 }
 
-template <typename ET, int BM, int BN, int WGM, int WGN, int EPI>
+template <typename ET, int BM, int BN, int WGM, int WGN, int EPI, bool W3 = false>
 static void bf2_launch_one(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, hipStream_t s) {
     // A / B tiles (double-buffered; X3: three planes of 64 B per row), sOut + sGrp + sRow (double-buffered), flag
     const size_t tiles = sizeof(ET) == 4 ? (size_t)(2 * 3 * (BM + BN) * X3_ROW) * 4 : (size_t)(2 * (BM + BN) * SK_LDP) * 4;
     const size_t lds = tiles + (size_t)8 * BM * 4 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)convbf2_kernel<ET, BM, BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)convbf2_kernel<ET, BM, BN, WGM, WGN, EPI, W3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((convbf2_kernel<ET, BM, BN, WGM, WGN, EPI>), dim3(A.G), dim3(BF_NT), lds, s, (const ET*)x, (const ET*)w, bias, (ET*)y, A, stats, nb);
+    hipLaunchKernelGGL((convbf2_kernel<ET, BM, BN, WGM, WGN, EPI, W3>), dim3(A.G), dim3(BF_NT), lds, s, (const ET*)x, (const ET*)w, bias, (ET*)y, A, stats, nb);
 }
 
 #define BF2_GO(ET_, BM_, BN_, WGM_, WGN_)                                                              \
@@ -1049,8 +1086,20 @@ int convbf2_launch(const void* x, const void* w, const float* bias, void* y, con
 
 // fp32 tensors, split-fp32 products (plans built with sdt_convsk_set_f32_split(1)): 128 x 128 tiles, 256 x 64 for the 64-channel outputs -- 64 x 32
 // per wave: two accumulator sets (running chunk + chunk sums) and two fragment sets of three planes fit 256 registers; 64 x 64 per wave does not
+#define BF2_GO_W3(BM_, BN_, WGM_, WGN_)                                                                     \
+    do {                                                                                                     \
+        if (epi == 0) bf2_launch_one<float, BM_, BN_, WGM_, WGN_, 0, true>(x, w, bias, y, A, stats, nb, s);      \
+        else if (epi == 1) bf2_launch_one<float, BM_, BN_, WGM_, WGN_, 1, true>(x, w, bias, y, A, stats, nb, s); \
+        else bf2_launch_one<float, BM_, BN_, WGM_, WGN_, 2, true>(x, w, bias, y, A, stats, nb, s);               \
+    } while (0)
 int convx3_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
-                  hipStream_t s) {
+                  int w3, hipStream_t s) {
+    if (w3) {
+        if (bm == 256 && bn == 64) BF2_GO_W3(256, 64, 4, 2);
+        else if (bm == 128 && bn == 128) BF2_GO_W3(128, 128, 2, 4);
+        else return SDT_ERR_ARG;
+        return SDT_OK;
+    }
     if (bm == 256 && bn == 64) BF2_GO(float, 256, 64, 4, 2);
     else if (bm == 128 && bn == 128) BF2_GO(float, 128, 128, 2, 4);
     else return SDT_ERR_ARG;

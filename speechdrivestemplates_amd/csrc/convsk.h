@@ -85,8 +85,9 @@ __device__ __forceinline__ void sk_bf_interleave() {
 int convbf2_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
                    hipStream_t s);
 // ... and of its split-fp32 form (fp32 tensors; three bf16 planes made by the loader, six bf16 MFMAs per fragment pair): 256 x {128,64} or 128 x 128 tiles
+// w3 != 0: `w` holds the weights pre-split into three bf16 planes (sdt_convsk_f32_w3)
 int convx3_launch(const void* x, const void* w, const float* bias, void* y, const sk_args& A, double* stats, const sk_norm_bwd& nb, int bm, int bn, int epi,
-                  hipStream_t s);
+                  int w3, hipStream_t s);
 #ifdef SDT_TUNING
 int convbf2_debug_mute_range(int r);  // convbf.hip's copy of the fault injector (device symbols are per translation unit)
 #endif

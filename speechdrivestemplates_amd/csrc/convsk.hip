@@ -1680,7 +1680,7 @@ static int sk_fill_args(sk_args& A, sk_norm_bwd& nb, const void* plan_host, cons
 // Element types of x / w / nbw->y and of y: the ones the plan was built for (sdt_convsk_plan_build: fp32; _t: fp32 or bf16).
 static int sk_go(const void* x, const void* w, const float* bias, void* y, const void* plan_host, const void* plan_dev, void* workspace,
                  unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream, int want_x,
-                 int want_y) {
+                 int want_y, int w3 = 0) {
     SDT_CHECK_ARG(x && w && y && plan_host && plan_dev && workspace, "null pointer");
     SDT_CHECK_ARG(epoch >= 1, "epoch must be >= 1");
     SDT_CHECK_ARG(!(stats && nbw), "forward and backward statistics are exclusive");
@@ -1703,8 +1703,9 @@ static int sk_go(const void* x, const void* w, const float* bias, void* y, const
         else if (epi == 1) sk_launch<TX_, TY_, BM_, BN_, 1, WPC_>(x, w, bias, y, A, stats, 0, nb, s); \
         else sk_launch<TX_, TY_, BM_, BN_, 2, WPC_>(x, w, bias, y, A, stats, 0, nb, s);               \
     } while (0)
+    SDT_CHECK_ARG(!w3 || (!xbf && !ybf && ((P[3] >> 26) & 1)), "pre-split weights need a split-fp32 plan (sdt_convsk_set_f32_split)");
     if (!xbf && !ybf && ((P[3] >> 26) & 1)) {
-        rc = convx3_launch(x, w, bias, y, A, stats, nb, bm, bn, epi, s);
+        rc = convx3_launch(x, w, bias, y, A, stats, nb, bm, bn, epi, w3, s);
         SDT_CHECK_ARG(rc == SDT_OK, "plan with a tile shape the split-fp32 kernel is not built for");
     } else if (!xbf && !ybf) {
         if (bm == 128 && bn == 128 && wpc == 1) SK_GO(float, float, 128, 128, 1);
@@ -1730,6 +1731,12 @@ extern "C" int sdt_convsk_f32(const float* x, const float* w, const float* bias,
                               void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
                               int64_t ybytes, void* stream) {
     return sk_go(x, w, bias, y, plan_host, plan_dev, workspace, epoch, stats, nbw, xbytes, wbytes, ybytes, stream, 0, 0);
+}
+// split-fp32 plan, weights pre-split into three bf16 planes (sdt_wt_desc.planes = 3): wbytes is the size of the fp32 weight tensor they came from
+extern "C" int sdt_convsk_f32_w3(const float* x, const void* w3, const float* bias, float* y, const void* plan_host, const void* plan_dev,
+                                 void* workspace, unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes,
+                                 int64_t ybytes, void* stream) {
+    return sk_go(x, w3, bias, y, plan_host, plan_dev, workspace, epoch, stats, nbw, xbytes, wbytes, ybytes, stream, 0, 0, 1);
 }
 // bf16 tensors (x, w, y, nbw->y), fp32 bias / statistics / accumulation: the bf16-storage path of BASELINE config 4
 extern "C" int sdt_convsk_bf16(const void* x, const void* w, const float* bias, void* y, const void* plan_host, const void* plan_dev,

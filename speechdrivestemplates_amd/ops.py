@@ -616,12 +616,25 @@ SK_K_ORDER = 1
 _K_ORDER_SET = [None]
 
 
+# Split-fp32 launches can read the weights PRE-SPLIT (three bf16 planes kept beside the transposed mirrors, refreshed by the same batched launch once
+# per optimiser step) instead of splitting them in every tile on every K step: half of the loader's VALU work of a 128 x 128 tile leaves the K loop --
+# and the B operand's bytes per step grow by 50 % (3 x 64 B of planes instead of 128 B of fp32).  Measured (profiles/r06_w3_ab.txt, B = 32, L1-L7
+# forward + input gradient, twice each): 2.89 ms split in the loader, 2.98 ms pre-split -- the kernel is bound by operand DELIVERY, not by the split's
+# VALU work (bit-identical results either way: tests/test_ops_gpu.py::test_presplit_weights_are_bit_identical_to_the_in_kernel_split).  Off.
+W3_PRESPLIT = False
+
+
 def _sk_launch(plan, x4, ws_w, bias, y, stats, nb, st):
     lib = _lib.load()
     if _K_ORDER_SET[0] != SK_K_ORDER:
         check(lib.sdt_convsk_set_k_order(int(SK_K_ORDER)))
         _K_ORDER_SET[0] = SK_K_ORDER
     wsb = _sk_workspace(y.device, st)
+    if plan.dtype == _lib.F32 and (plan.host[3] >> 26) & 1:
+        w3 = WeightMirrors.lookup3(ws_w)
+        if w3 is not None:
+            return lib.sdt_convsk_f32_w3(_p(x4), _p(w3), _p(bias), _p(y), plan.host, _p(plan.dev), _p(wsb), 1, _p(stats), nb,
+                                         x4.numel() * 4, ws_w.numel() * 4, y.numel() * 4, st)
     fn = lib.sdt_convsk_bf16 if plan.dtype == _lib.BF16 else lib.sdt_convsk_f32
     esz = 2 if plan.dtype == _lib.BF16 else 4
     return fn(_p(x4), _p(ws_w), _p(bias), _p(y), plan.host, _p(plan.dev), _p(wsb), 1, _p(stats), nb,
@@ -752,10 +765,12 @@ class WeightMirrors:
     and the parameter's autograd version counter is unchanged (``load_state_dict`` / in-place edits bump it).  Code
     that writes weights through ``.data`` or raw pointers must call ``mark_dirty`` itself."""
     _by_ptr = {}
+    _by_mirror = {}  # data_ptr of an fp32 mirror -> (owner, entry index): _sk_launch finds the pre-split planes of EITHER operand form by pointer
     dirty = True
 
     def __init__(self, params):
         self.entries, tiles = [], 0
+        self.planes = 1  # what e[3] / e[4] hold: 1 = bf16 copies (bf16 storage), 3 = the three bf16 planes of the split-fp32 kernels (W3_PRESPLIT)
         for p in params:
             if p.dim() not in (3, 4):
                 continue
@@ -772,26 +787,35 @@ class WeightMirrors:
         if self.entries:
             if STORAGE == "bf16":
                 self._alloc16()
+            elif F32_SPLIT and W3_PRESPLIT:
+                self._alloc16(planes=3)
             self._build_table()
             import weakref
             me = weakref.ref(self)
             for i, e in enumerate(self.entries):
                 WeightMirrors._by_ptr[e[0].data_ptr()] = (me, i)  # weak: a dead optimiser's mirrors are dropped
+                WeightMirrors._by_mirror[e[1].data_ptr()] = (me, i)
 
-    def _alloc16(self):
-        """bf16 copies of the Conv2d weights and of their mirrors (the operands of the bf16-storage path's kernels)"""
+    def _alloc16(self, planes=1):
+        """bf16 copies of the Conv2d weights and of their mirrors (the operands of the bf16-storage path's kernels), or -- planes == 3 -- their
+        exact three-way bf16 split [hi | mid | lo] (the pre-split B operand of the split-fp32 kernels: csrc/convbf.hip, W3)"""
+        if planes != self.planes:
+            for e in self.entries:
+                e[3] = e[4] = None
+            self.planes = planes
         for e in self.entries:
             p = e[0]
             if p.dim() == 4 and e[3] is None:
                 cout, taps, cin = weight_storage(p.data).shape
-                e[3] = torch.empty((cout, taps, cin), device=p.device, dtype=torch.bfloat16)
-                e[4] = torch.empty((cin, taps, cout), device=p.device, dtype=torch.bfloat16)
+                lead = (3,) if planes == 3 else ()
+                e[3] = torch.empty(lead + (cout, taps, cin), device=p.device, dtype=torch.bfloat16)
+                e[4] = torch.empty(lead + (cin, taps, cout), device=p.device, dtype=torch.bfloat16)
 
     def _build_table(self):
         descs = []
         for p, wt, _v, w16, wt16, tile0 in self.entries:
             cout, taps, cin = weight_storage(p.data).shape
-            descs.append(_lib.WtDesc(p.data_ptr(), wt.data_ptr(), _p(w16), _p(wt16), cout, taps, cin, tile0))
+            descs.append(_lib.WtDesc(p.data_ptr(), wt.data_ptr(), _p(w16), _p(wt16), cout, taps, cin, tile0, self.planes if w16 is not None else 0, 0))
         arr = (_lib.WtDesc * len(descs))(*descs)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.entries[0][0].device)
 
@@ -836,15 +860,44 @@ class WeightMirrors:
         owner, e = WeightMirrors._entry(w)
         if owner is None or e[0].dim() != 4:
             return None
-        if e[3] is None:  # the storage mode was switched on after this group was built
+        if e[3] is None or owner.planes != 1:  # the storage mode was switched on after this group was built
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("bf16 weight copies must exist before a hipGraph capture (set ops.STORAGE before setup_optimizer)")
-            owner._alloc16()
+            owner._alloc16(planes=1)
             owner._build_table()
             owner.dirty = True
         if owner.dirty or e[2] != e[0]._version:
             owner.refresh()
         return e[3], e[4]
+
+    @staticmethod
+    def lookup3(operand):
+        """The pre-split planes (3, rows, taps, cols) bf16 of a conv operand given as the tensor a launch would otherwise read: a registered
+        weight's storage (Cout,taps,Cin) or its fp32 mirror (Cin,taps,Cout); refreshed with the mirrors (one batched launch per optimiser step).
+        None: not a registered Conv2d weight / pre-splitting is off -- the kernel then splits the fp32 weights itself, tile by tile."""
+        if not W3_PRESPLIT:
+            return None
+        ptr = operand.data_ptr()
+        hit, which = WeightMirrors._by_ptr.get(ptr), 3
+        if hit is None:
+            hit, which = WeightMirrors._by_mirror.get(ptr), 4
+        if hit is None:
+            return None
+        owner = hit[0]()
+        if owner is None:
+            return None
+        e = owner.entries[hit[1]]
+        if e[0].dim() != 4 or (e[0].data_ptr() if which == 3 else e[1].data_ptr()) != ptr:
+            return None
+        if e[3] is None or owner.planes != 3:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # (no allocation inside a capture: this launch splits in the kernel)
+            owner._alloc16(planes=3)
+            owner._build_table()
+            owner.dirty = True
+        if owner.dirty or e[2] != e[0]._version:
+            owner.refresh()
+        return e[which]
 
 
 FUSE_DX_CLASSES = True   # one launch for all output parity classes of a strided layer's input gradient (fp32 math)

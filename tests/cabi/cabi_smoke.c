@@ -11,7 +11,7 @@ int main(void) {
     memset(&g, 0, sizeof g);
     if (sdt_abi_version() != 5) return 10;
     if (sizeof(sdt_conv_geom) != (17 + 3 * SDT_MAX_TAPS) * sizeof(int32_t)) return 11;
-    if (sizeof(sdt_wt_desc) != 4 * sizeof(void*) + 4 * sizeof(int32_t)) return 12;
+    if (sizeof(sdt_wt_desc) != 4 * sizeof(void*) + 6 * sizeof(int32_t)) return 12;
     rc = sdt_conv_taps_f32(NULL, NULL, NULL, NULL, &g, NULL); /* zero geometry -> argument error, message set */
     if (rc != SDT_ERR_ARG || strlen(sdt_last_error()) == 0) return 13;
     printf("last error: %s\n", sdt_last_error());

@@ -1219,3 +1219,49 @@ def test_split_f32_conv_vs_float64_and_the_fp32_mfma_kernels(ops, case):
     e_sums = ((out[True][3] - rs).abs().max() / rs.abs().max()).item()
     assert e_sums < 2e-7, (tag, "statistics", e_sums)
     assert not ops.streamk_error_codes()
+
+
+@pytest.mark.parametrize("case", [("L2 3x3", 8, 40, 213, 64, 128, 3, 3, 1, 1), ("L1 4x4 s2 (256 x 64 tiles)", 8, 80, 427, 64, 64, 4, 4, 2, 1),
+                                  ("L7 (6,3) valid", 32, 10, 53, 256, 256, 6, 3, 1, 0)], ids=lambda c: c[0])
+def test_presplit_weights_are_bit_identical_to_the_in_kernel_split(ops, case):
+    """Round 6: split-fp32 launches read the weights pre-split into three bf16 planes (made once per optimiser step with the transposed mirrors,
+    sdt_wt_desc.planes = 3 -> sdt_convsk_f32_w3) instead of splitting them in every tile on every K step.  Same conversions, same exact differences:
+    forward and input gradient must be BIT-identical to the launches that split the fp32 weights themselves, for a weight a mirror group has
+    registered (as optim.FlatAdam does); and the planes must follow the weights when the optimiser steps (mark_dirty -> refresh)."""
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    assert ops.F32_SPLIT
+    prev_w3, ops.W3_PRESPLIT = ops.W3_PRESPLIT, True  # (measured slower than splitting in the loader, profiles/r06_w3_ab.txt: not the default)
+    try:
+        _presplit_case(ops, case)
+    finally:
+        ops.W3_PRESPLIT = prev_w3
+
+
+def _presplit_case(ops, case):
+    tag, B, Hi, Wi, Cin, Cout, kh, kw, s, p = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Hi, Wi, Cin, generator=g).to(DEV)
+    w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(DEV))
+    y_plain = ops.conv_forward(x, w, None, s, p)  # not registered anywhere: the kernel splits
+    gy = torch.randn(y_plain.shape, generator=g).to(DEV)
+    dx_plain = ops.conv_input_grad(gy, w, x.shape, s, p)
+    plan = ops._sk_plan(ops.conv_geom_for(x.shape, w, s, p), 1, 0, 1, x.device, forward=True)
+    assert plan is not None and (plan.host[3] >> 26) & 1, "this shape is meant to take the split-fp32 kernel"
+    group = ops.WeightMirrors([w])
+    assert ops.WeightMirrors.lookup3(ops.weight_storage(w)) is not None and group.planes == 3
+    y3 = ops.conv_forward(x, w, None, s, p)
+    dx3 = ops.conv_input_grad(gy, w, x.shape, s, p)
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y_plain) and torch.equal(dx3, dx_plain)
+    # the three planes ARE the weight: hi + mid + lo == w exactly (fp32 sums of bf16 numbers in this order are exact)
+    w3 = ops.WeightMirrors.lookup3(ops.weight_storage(w)).float()
+    assert torch.equal((w3[0] + w3[1]) + w3[2], ops.weight_storage(w.detach()))
+    # an optimiser step: the weights change behind the planes' back, mark_dirty is what FlatAdam.step calls
+    with torch.no_grad():
+        w.mul_(1.25)
+    group.mark_dirty()
+    y3b = ops.conv_forward(x, w, None, s, p)
+    w_copy = torch.nn.Parameter(w.detach().clone())  # same values, registered nowhere: the kernel splits
+    y_ref = ops.conv_forward(x, w_copy, None, s, p)
+    torch.cuda.synchronize()
+    assert torch.equal(y3b, y_ref) and not torch.equal(y3b, y_plain)

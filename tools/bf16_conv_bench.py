@@ -51,11 +51,15 @@ def main():
     ap.add_argument("--no-dw", action="store_true", help="skip the weight-gradient launches")
     ap.add_argument("--split", type=int, default=1, help="--dtype f32: 1 = the split-fp32 form of the 8-wave kernel (ops.F32_SPLIT), 0 = the fp32-MFMA kernels")
     ap.add_argument("--old", action="store_true", help="the round-4 128-row bf16 kernels (ops.BF16_SHAPED = False) instead of the bf16-shaped ones")
+    ap.add_argument("--w3", type=int, default=1, help="--dtype f32 split: 1 = weights pre-split into three bf16 planes once (ops.W3_PRESPLIT; the weights are registered "
+                                                     "with a WeightMirrors group as an optimiser would), 0 = split by every tile's loader")
     ap.add_argument("--korder", type=int, default=None, help="K order of the 8-wave kernels' tiles: 0 tap-major, 1 chunk-major (ops.SK_K_ORDER)")
     a = ap.parse_args()
     if a.korder is not None:
         ops.SK_K_ORDER = a.korder
     B, dev = a.batch, "cuda"
+    ops.W3_PRESPLIT = bool(a.w3)
+    keep = []
     ops.BF16_SHAPED = not a.old
     ops.F32_SPLIT = bool(a.split)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -67,6 +71,8 @@ def main():
         g = torch.Generator().manual_seed(1)
         x = torch.randn(B, Hi, Wi, Cin, generator=g).to(dt).to(dev)
         w = torch.nn.Parameter(ops.to_weight_layout(torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev))
+        if a.dtype == "f32" and a.w3:
+            keep.append(ops.WeightMirrors([w]))  # transposed mirror + pre-split planes, refreshed on first use (as optim.FlatAdam keeps them)
         y, sums = ops.ConvStatsFn.apply(x, w, s, p, B, None)
         gy = torch.randn(y.shape, generator=g).to(dt).to(dev)
         geo = ops.conv_geom_for(x.shape, w, s, p)
