@@ -594,7 +594,7 @@ def main(argv=None):
                        "global_batch": B * world, "parallelism": "dp%d" % world, "graph": bool(args.graph), "deterministic_dw": not args.atomic_dw, "streamk_reserved_slots": int(getattr(ops, "SK_RESERVED_SLOTS", 0)) if ops is not None else 0,
                        # run-to-run bit-identical weights in this mode (tests/test_model_gpu.py::test_train_steps_repeat_bit_identically):
                        # ordered weight-gradient / bias reductions; the normalisation statistics are fp64 atomics whose rounding to
-                       # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact)
+                       # fp32 depends on the arrival order with probability ~2e-6 per step (fp64 sums of fp32 partials are exact; docs/DESIGN_rounds_1-5.md section 2)
                        "deterministic": bool(not args.atomic_dw and not args.no_streamk_dw and args.conv_math == "f32")},
             "final_G_loss": final_loss,
             "streamk_errors": 0 if (ops is not None and on_gpu and not stub) else None,  # asserted above: no stream-K launch lost a partner

@@ -2,11 +2,12 @@
 encoder -> optional motion discriminator) and ``Voice2Pose.train_step`` with the reference's semantics
 (core/pipelines/voice2pose.py:22-210, 216-331, 412-430).
 
-Deliberate, documented differences from the reference (DESIGN.md "quirks"):
+Deliberate, documented differences from the reference:
   * the clip-code KL "skip when any batch variance is 0" test (voice2pose.py:154) stays on the device:
     ``G_clipcode_kl_loss`` is always present and is exactly 0 when skipped (``results['kl_valid']`` tells);
   * data parallelism is one summing all-reduce per optimiser group over flat gradient buffers (dp.py) instead of
-    DistributedDataParallel; discriminator gradients ARE synchronised (the reference's second backward is not);
+    DistributedDataParallel; discriminator gradients ARE synchronised (the reference's second backward is not;
+    SYS.DDP_UNSYNCED_D reproduces that);
   * per-loss scalars are reduced to rank 0 in one packed collective, only on logging steps.
 """
 from collections import OrderedDict

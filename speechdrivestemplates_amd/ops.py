@@ -611,8 +611,11 @@ def check_streamk():
 
 
 # K order of the 8-wave kernels' tiles (csrc/convbf.hip; include/sdt_hip.h sdt_convsk_set_k_order): 1 = chunk-major -- all live taps of a 128-byte
-# channel chunk before the next chunk, so that neighbouring taps find the previous step's cache lines in the CU's vector L1; 0 = tap-major (rounds 3-5)
-SK_K_ORDER = 1
+# channel chunk before the next chunk, so that neighbouring taps find the previous step's cache lines in the CU's vector L1; 0 = tap-major (rounds 3-5).
+# Measured +1.3 % over the 14 forward / input-gradient launches (profiles/r06_korder_ab.txt) -- inside the box-to-box spread of the step, and it
+# regroups every Conv2d sum: trajectory quantities behind an Adam step move past their CALIBRATED bounds (tests/golden/margins.json; e.g. sdt_bp
+# step-1 lip_sync 7e-7 -> 2e-5 against a stated 1e-3).  Not worth re-recording 800 margins in the round that had to turn the suite green: off.
+SK_K_ORDER = 0
 _K_ORDER_SET = [None]
 
 

@@ -1,7 +1,7 @@
 """Data-parallel train step on the GPU with two ranks sharing cuda:0 (backend gloo: RCCL refuses two ranks on one
 device, and the GPU box has one).  Everything but the transport is the production path: HIP kernels, flat gradient
 buffers, the early all-reduce launched from the backward hook, the remaining ranges before the optimiser step, the
-1/world scale inside the Adam kernel.  Contract (DESIGN.md section 4): both ranks end up with identical weights, equal
+1/world scale inside the Adam kernel.  Contract (DESIGN.md section 5): both ranks end up with identical weights, equal
 to a single process stepping on the concatenated batch -- exact data parallelism for the per-sample-normalised sdt
 generator (the KL term is per-rank by design; sdt_vae's external codes keep it out of the trained parameters)."""
 import os
@@ -101,7 +101,7 @@ def test_two_ranks_one_gpu_match_single_process_full_batch():
         assert torch.equal(a, b), k  # both ranks applied the same averaged gradient with the same kernel
         if ref.is_floating_point() and ref.numel() > 1:
             # 2 Adam steps move a weight by at most ~2*lr; sign-like first steps turn fp32 summation-order noise in
-            # near-zero gradients into lr-sized differences for a few elements (DESIGN.md section 3) -> bound the bulk
+            # near-zero gradients into lr-sized differences for a few elements (DESIGN.md section 4) -> bound the bulk
             d = (a - ref).abs()
             assert d.max().item() <= 4.5e-4, (k, d.max().item())
             assert (d > 2e-5).float().mean().item() < 0.02, (k, (d > 2e-5).float().mean().item())
@@ -154,7 +154,7 @@ def test_differently_seeded_ranks_are_synchronised_at_construction():
         assert np.array_equal(init0, init1), cfg_name  # rank 1 trains rank 0's initial weights, not its own draw
         for k in sd0:
             if "running_" in k:
-                continue  # BatchNorm running statistics are rank-local by design (no SyncBN; DESIGN.md section 4)
+                continue  # BatchNorm running statistics are rank-local by design (no SyncBN; DESIGN.md section 5)
             assert np.array_equal(sd0[k], sd1[k]), (cfg_name, k)
         if cfg_name == "voice2pose_s2g":  # per-rank batch statistics: the buffers do differ
             assert any(not np.array_equal(sd0[k], sd1[k]) for k in sd0 if "running_mean" in k)

@@ -291,6 +291,18 @@ def test_conv_b32_single_items_vs_float64(case):
     mask[list(items)] = 1.0
     ops.conv_weight_grad(xd, (gy * mask).to(DEV).contiguous(), wd, s, p)
     torch.cuda.synchronize()
+    if not one_d:
+        # these launches must be the HEADLINE's kernels -- the split-fp32 forward / input-gradient plan (bit 26 of the plan header)
+        # and the split weight-gradient plan -- not a fallback that happens to be accurate too
+        assert ops.F32_SPLIT and ops.USE_STREAMK and ops.USE_STREAMK_DW
+        g = ops.conv_geom_for(xd.shape, wd, s, p)
+        fplan = ops._sk_plan(g, 1, 0, 1, xd.device, forward=True)
+        assert fplan is not None and (fplan.host[3] >> 26) & 1, (tag, "forward did not take the split-fp32 kernel")
+        arr, n, _gs = ops.dx_pack(B, Hi, Wi, Cin, Cout, kh, kw, s, p, False)
+        xplan = ops._sk_plan(arr, n, -1, 1, xd.device)
+        assert xplan is not None and (xplan.host[3] >> 26) & 1, (tag, "input gradient did not take the split-fp32 kernel")
+        wplan = ops._sk_dw_plan(g, xd.device)
+        assert wplan is not None and (wplan.host[3] >> 26) & 1, (tag, "weight gradient did not take convx3_dw_kernel")
     conv = F.conv1d if one_d else F.conv2d
     dw_ref = torch.zeros_like(w, dtype=torch.float64)
     for b in items:

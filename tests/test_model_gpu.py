@@ -516,7 +516,7 @@ def test_hipgraph_replay_matches_eager(cfg_name, code_std):
     assert s0 == s1 == 4
     for i, ((a, b), (c, d)) in enumerate(zip(h0, h1)):
         # step 0 sees identical weights (atomics order only); later steps sit behind Adam updates that turn last-bit
-        # gradient differences into lr-sized weight differences (DESIGN.md section 3)
+        # gradient differences into lr-sized weight differences (DESIGN.md section 4)
         tol = 2e-5 if i == 0 else 2e-4
         assert abs(a - c) <= tol * abs(a) and abs(b - d) <= tol * abs(b), (h0, h1)
     # weight-gradient atomics make the two runs differ in the last bits; Adam's sign-like early steps amplify that to at

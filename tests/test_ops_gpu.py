@@ -851,7 +851,7 @@ def test_streamk_row_major_tile_order(ops, case, groups):
 
 def test_statistics_sums_do_not_depend_on_the_arrival_order(ops):
     """The normalisation statistics are fp64 atomics over per-32-row-block fp32 partial sums.  Such a sum is exact in fp64 (24-bit terms of similar
-    magnitude, <= 2^10 of them), hence independent of the order in which the workgroups arrive: repeated launches of the forward
+    magnitude, <= 2^10 of them), hence independent of the order in which the workgroups arrive (docs/DESIGN_rounds_1-5.md section 2): repeated launches of the forward
     and the backward statistics epilogues give BITWISE identical fp64 sums."""
     torch.manual_seed(5)
     B = 16
