@@ -315,3 +315,77 @@ def test_bf16_storage_blocks_round_where_the_emulating_oracle_rounds(ops):
             continue
         assert e_emu <= 1.5e-4 and e_emu <= 0.05 * e_plain, (i, e_emu, e_plain)
         assert frac <= 5e-4, (i, frac)
+
+
+def test_bf16_storage_block_backward_rounds_where_the_emulating_oracle_rounds(ops):
+    """the backward-side counterpart of the test above.  The step-level bf16 bars (prediction 4e-2, every gradient within 40 % of
+    max-norm, cosine >= 0.97: test_b32_bf16_storage_vs_oracle) are set by bf16 rounding itself and cannot be tightened end to end (rounding decorrelates
+    two fp32-equivalent computations within three or four layers).  Per BLOCK on the engine's own tensors they can: every encoder block 1-7 runs forward
+    in bf16 storage on the engine's input of that block, then backward on a bf16 gradient of its output; the three things the backward produces are
+    compared with a float64 emulation that rounds exactly where the kernels round --
+        dy  = IN-backward of g = gz * act'(yhat), yhat from the STORED (bf16) conv output and the statistics of the unrounded one   -> stored bf16
+        dX  = conv_transpose(dy_bf16, W_bf16), fp32 accumulation                                                                     -> stored bf16
+        dW  = conv weight gradient of (x_bf16, dy_bf16), fp32 accumulation                                                           -> fp32
+    -- and with the same float64 formulas WITHOUT the two roundings (the distance bf16 storage itself costs).  Bars: relative RMS difference to the
+    emulation <= 3e-4 for dX and dW (what is left are one-ulp rounding flips of a few 1e-4 of the stored dy / dX values) AND at most a fifth of the
+    distance to the formulas that do not round."""
+    from test_model_gpu import _make_pipeline
+    B, N, cfg_name = 4, 64, "voice2pose_sdt_bp"
+    batch = O.make_batch(B, N, step=3, seed=11)
+
+    def rms(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    def q(t):  # round to bf16, keep float64
+        return t.float().to(torch.bfloat16).double()
+
+    rows = []
+    ops.set_storage("bf16")
+    try:
+        pipe, _ = _make_pipeline(cfg_name, N, 0.5)
+        net = pipe.model.netG
+        blocks = [b for stage in net.audio_encoder.specgram_encoder_2d for b in stage]
+        with torch.no_grad():
+            x = pipe.model.mel_transfm(batch["audio"].to(DEV)).unsqueeze(-1)
+            x = blocks[0].forward_cl(x, None, None)
+        gen = torch.Generator().manual_seed(77)
+        for i in range(1, 8):
+            blk = blocks[i]
+            pipe.optimizers["optimizerG"].zero_grad()
+            xin = x.detach().clone().requires_grad_(True)
+            holder = ops.NormBwdHolder()
+            y = blk.forward_cl(xin, None, holder, out_f32=(i == 7))
+            gz = (torch.randn(y.shape, generator=gen) * 1e-3).to(DEV).to(y.dtype)
+            y.backward(gz)
+            torch.cuda.synchronize()
+            dx_eng = xin.grad.detach().float().cpu()
+            # ---- the emulation, float64 on the CPU, from the ENGINE's stored tensors
+            ys = holder.y.detach().double().cpu()                      # (B, Ho, Wo, C) as stored (bf16)
+            Bq, Ho, Wo, C = ys.shape
+            mean = holder.mean.detach().double().cpu().reshape(Bq, 1, 1, C)
+            rstd = holder.rstd.detach().double().cpu().reshape(Bq, 1, 1, C)
+            yhat = (ys - mean) * rstd
+            g = gz.detach().double().cpu() * torch.where(yhat > 0, torch.ones_like(yhat), torch.full_like(yhat, blk.slope))
+            m1, m2 = g.mean(dim=(1, 2), keepdim=True), (g * yhat).mean(dim=(1, 2), keepdim=True)
+            dy = rstd * (g - m1 - yhat * m2)
+            w_log = blk.conv.weight.detach()                           # logical (Cout, Cin, kh, kw), fp32 master
+            res = {}
+            for name, rnd in (("emu", True), ("plain", False)):
+                xa = xin.detach().double().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)   # the bf16 input the engine read
+                wa = (q(w_log.cpu()) if rnd else w_log.double().cpu()).clone().requires_grad_(True)
+                ya = torch.nn.functional.conv2d(xa, wa, None, blk.stride, blk.padding)
+                ya.backward((q(dy) if rnd else dy).permute(0, 3, 1, 2))
+                res[name] = ((q(xa.grad) if rnd else xa.grad).permute(0, 2, 3, 1), wa.grad)
+            dw_eng = blk.conv.weight.grad.detach().double().cpu()      # logical layout view of the flat gradient buffer
+            rows.append((i, rms(dx_eng, res["emu"][0]), rms(dx_eng, res["plain"][0]), rms(dw_eng, res["emu"][1]), rms(dw_eng, res["plain"][1])))
+            with torch.no_grad():
+                x = y.detach()
+    finally:
+        ops.set_storage("f32")
+    for i, ex, px, ew, pw in rows:
+        print("  encoder block %d backward in bf16 storage: dX rms difference to the emulation %.2e (to the formulas that do not round %.2e), "
+              "dW %.2e (%.2e)" % (i, ex, px, ew, pw))
+    for i, ex, px, ew, pw in rows:
+        assert ex <= 3e-4 and ex <= 0.2 * px, (i, "dX", ex, px)
+        assert ew <= 3e-4 and ew <= 0.2 * pw, (i, "dW", ew, pw)
