@@ -34,7 +34,7 @@ def per_kernel(path, counter):
         name = re.sub(r"^convsk_kernel<float, float, (\d+, \d+), \d+, \d+>", r"convsk_kernel<\1>", name)
         name = re.sub(r"^_Z13convsk_kernelIDF16bDF16bLi(\d+)ELi(\d+)E.*", r"convsk_kernel<\1, \2> bf16", name)
         # <ET, BM, BN, WGM, WGN, EPI> of the 8-wave kernel (csrc/convbf.hip): float = the split-fp32 form, mangled = bf16 tensors
-        name = re.sub(r"^convbf2_kernel<float, (\d+, \d+), \d+, \d+, \d+>", r"convbf2_kernel<float, \1>", name)
+        name = re.sub(r"^convbf2_kernel<float, (\d+, \d+), \d+, \d+, \d+(?:, (?:true|false))?>", r"convbf2_kernel<float, \1>", name)
         name = re.sub(r"^_Z14convbf2_kernelIDF16bLi(\d+)ELi(\d+)E.*", r"convbf2_kernel<\1, \2>", name)
         tot[name] += float(r["Counter_Value"]) * 1024.0
         if r["Dispatch_Id"] not in seen:
