@@ -130,6 +130,9 @@ int sdt_convsk_set_reserved_slots(int n);
  * chunks of a tap, then the next tap), 1 = chunk-major (all live taps of a chunk, then the next chunk: neighbouring taps re-read the cache lines of
  * the step before while the CU's vector L1 still holds them).  ABI 5. */
 int sdt_convsk_set_k_order(int order);
+/* Split-fp32 weight-gradient plans built afterwards (sdt_convsk_dw_plan_build_t with sdt_convsk_set_f32_split(1)): 1 = 128-wide column tiles with a
+ * ragged last one when taps * Cin = 64 (mod 128); 0 (default) = tiles by divisibility, the rule of rounds 3-5.  ABI 5. */
+int sdt_convsk_set_dw_wide_tiles(int on);
 int sdt_convsk_f32_w3(const float* x, const void* w3, const float* bias, float* y, const void* plan_host, const void* plan_dev, void* workspace,
                       unsigned epoch, double* stats, const sdt_norm_bwd* nbw, int64_t xbytes, int64_t wbytes, int64_t ybytes, void* stream);
 /* Polls (each ~1 us under load) of a partner's flag before the owner of a split tile declares the launch failed.  Default 1 << 22. */

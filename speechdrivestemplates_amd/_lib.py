@@ -117,6 +117,7 @@ SIGNATURES = {
     "sdt_convsk_dw_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "sdt_convsk_set_spin_limit": [C.c_uint],
     "sdt_convsk_set_k_order": [_i],
+    "sdt_convsk_set_dw_wide_tiles": [_i],
 }
 F32, BF16 = 0, 1  # enum sdt_dtype
 

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256, WPC) void convsk_dw_kernel(const float* __rest
 template <int W>
 __device__ __forceinline__ int bfdw_off(const int row, const int col) {  // element offset of (row, col) in a swizzled [64][W] bf16 tile
     constexpr int S = W / 32;                                            // 64-byte segments per row
-    const int f = S == 4 ? (row & 3) : ((row >> 1) & 1);
+    const int f = S >= 4 ? (row & 3) : ((row >> 1) & 1);
     return row * W + ((((col >> 5) ^ f) << 5) | (col & 31));
 }
 typedef short sk_s16x4 __attribute__((ext_vector_type(4)));
@@ -1074,8 +1074,11 @@ __global__ __launch_bounds__(256, 2) void convx3_dw_kernel(const float* __restri
     const int n0 = nt * BM, j0 = ct * BN;
     const int j = j0 + cqb * 4;  // this thread's B columns: 4 consecutive channels of ONE tap
     const int t = j / Cin, c = j - t * Cin;
+    // ragged last column tile (taps * Cin not a multiple of BN: the 9 x 64 = 576 columns of L2 in five 128-wide tiles): columns of a tap that does
+    // not exist load zeros (the reduce kernel does not store them)
+    const unsigned tmask = t < cl.ntaps ? 0u : SK_OOB;
     const unsigned acol = (unsigned)(n0 + cqa * 4) * 4u;
-    const unsigned bcol = (unsigned)cl.ashift[t] + (unsigned)c * 4u;
+    const unsigned bcol = (unsigned)cl.ashift[t < SDT_MAX_TAPS ? t : SDT_MAX_TAPS - 1] + (unsigned)c * 4u;
     const int sh = 31 - t;  // the row's invalid-tap bit t -> bit 31 of the offset
     int ya[LA];
     int2 xb[LB];
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void convx3_dw_kernel(const float* __restri
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask;
+            const unsigned ob = (((unsigned)xb[i].x + bcol) & 0x7fffffffu) | (((unsigned)xb[i].y << sh) & 0x80000000u) | off_mask | tmask;
             rb[S_][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)ob, 0, 0));
         }
         --left;
@@ -1250,7 +1253,7 @@ __global__ __launch_bounds__(256) void dw_sk_reduce_kernel(const float* __restri
     const sk_class& cl = P.cls[0];
     const int j = ct * BN + jl, t = j / cl.Cin, c = j - t * cl.Cin;
     const int n = nt * BM + nl;
-    if (n < Cout) {
+    if (n < Cout && t < cl.ntaps) {  // (columns of a ragged last tile past the last tap: nothing to store)
         float* d = dw + ((size_t)n * Tw + cl.dyx[t]) * cl.Cin + c;  // dyx[] of a weight-gradient plan holds wt[t]
         *(f32x4*)d += sum;
     }
@@ -1327,6 +1330,11 @@ static int64_t sk_plan_ints(const sdt_conv_geom* const* gs, int ncls, int bm, in
 static int g_sk_split = 0;
 extern "C" int sdt_convsk_set_f32_split(int on) {
     g_sk_split = on ? 1 : 0;
+    return SDT_OK;
+}
+static int g_dw_wide = 0;  // 1: ragged 128-wide column tiles for the split-fp32 weight gradient (dw_tile); 0: the tile rule of rounds 3-5
+extern "C" int sdt_convsk_set_dw_wide_tiles(int on) {
+    g_dw_wide = on ? 1 : 0;
     return SDT_OK;
 }
 static bool is_x3(int esz) { return esz == 4 && g_sk_wpc == 1 && g_sk_split; }
@@ -1747,6 +1755,17 @@ extern "C" int sdt_convsk_bf16(const void* x, const void* w, const float* bias, 
 
 // ---- weight gradient through the stream-K machinery (esz: bytes per element of x / dy: 4 -> convsk_dw_kernel, 32 rows per K step;
 // 2 -> convbf_dw_kernel, 64 rows per K step)
+// Tile of a weight gradient (rows = output channels, columns = (tap, input channel) pairs): by divisibility.  sdt_convsk_set_dw_wide_tiles(1) lets the
+// split-fp32 kernel (convx3_dw_kernel) take 128-wide column tiles with a RAGGED last one where taps * Cin = 64 (mod 128) -- L2: 9 x 64 = 576 columns in
+// five tiles, the last half empty, instead of nine 64-wide ones: 279 -> 248 us at 32 clips (profiles/r06_dw_wide_ab.txt).  Off by default: 0.5 % of
+// a step, and the re-cut K chunks regroup the sums behind the calibrated margins.  (64 x 256 tiles for the 64-channel layer L1 were measured too:
+// 256 registers + spills, 274 -> 279 us; not kept.)
+static void dw_tile(const sdt_conv_geom& g, int esz, int& bm, int& bn) {
+    const int N = g.ntaps * g.Cin;
+    bm = g.Cout % 128 == 0 ? 128 : 64;
+    bn = N % 128 == 0 ? 128 : 64;
+    if (esz == 4 && g_sk_split && g_sk_wpc == 2 && g_dw_wide && N >= 128) bn = 128;
+}
 static int dw_supported(const sdt_conv_geom* g, int esz) {
     if (!g || (esz != 4 && esz != 2)) return 0;
     if (esz == 2 && g_sk_wpc != 2) return 0;
@@ -1759,8 +1778,9 @@ static int dw_supported(const sdt_conv_geom* g, int esz) {
             if (g->wt[t] == g->wt[u]) return 0;
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
     const int step = esz == 4 ? 32 : 64;
-    const int bm = g->Cout % 128 == 0 ? 128 : 64, bn = (g->ntaps * g->Cin) % 128 == 0 ? 128 : 64;
-    const int64_t K = cdiv64(M, step), T = (int64_t)(g->Cout / bm) * ((int64_t)g->ntaps * g->Cin / bn);
+    int bm, bn;
+    dw_tile(*g, esz, bm, bn);
+    const int64_t K = cdiv64(M, step), T = (int64_t)(g->Cout / bm) * cdiv64((int64_t)g->ntaps * g->Cin, bn);
     const int G = sk_grid(g_sk_wpc);
     return T <= G && K >= (esz == 4 ? 8 : 4) * (G / T) && T * K < (1ll << 31) / G ? 1 : 0;  // G / T chunks of the K loop per tile, >= 8 (4) steps each
 }
@@ -1785,8 +1805,9 @@ static int dw_plan_build(const sdt_conv_geom* gp, void* out, int64_t out_bytes, 
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
     const int step = esz == 4 ? 32 : 64;
     const int64_t K = cdiv64(M, step), rows = (K + (esz == 4 ? 3 : 4)) * step;
-    const int bm = g.Cout % 128 == 0 ? 128 : 64, bn = (g.ntaps * g.Cin) % 128 == 0 ? 128 : 64;
-    const int ncol = g.ntaps * g.Cin / bn;
+    int bm, bn;
+    dw_tile(g, esz, bm, bn);
+    const int ncol = (int)cdiv64((int64_t)g.ntaps * g.Cin, bn);
     const int64_t T = (int64_t)(g.Cout / bm) * ncol;
     const int G = sk_grid(g_sk_wpc);
     int* rowinfo = P + SK_HDR;

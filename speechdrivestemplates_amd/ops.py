@@ -670,22 +670,33 @@ class _SKDwPlan:
         self.dev = torch.frombuffer(self.host, dtype=torch.int32).to(dev)
 
 
+# Tiles of the split-fp32 weight gradient (csrc/convsk.hip dw_tile): True = 128-wide column tiles with a ragged last one where taps * Cin is an odd
+# multiple of 64 (L2: five tiles instead of nine 64-wide ones: 279 -> 248 us, profiles/r06_dw_wide_ab.txt = 0.5 % of a step); False (default) = the
+# rule of rounds 3-5 -- the re-cut K chunks regroup the sums behind the calibrated margins, which half a percent does not pay for
+SK_DW_WIDE = False
+
+
 def _sk_dw_plan(g, dev, dtype=0):
     reserve = int(SK_RESERVED_SLOTS)
     wpc = 2 if dtype != _lib.F32 else int(SK_WPC_DW)
     split = bool(F32_SPLIT) and dtype == _lib.F32 and wpc == 2
-    key = (_geom_key(g), dev.index, reserve, dtype, wpc, split)
+    wide = bool(SK_DW_WIDE)
+    key = (_geom_key(g), dev.index, reserve, dtype, wpc, split, wide)
     plan = _SK_DW_PLANS.get(key, False)
     if plan is False:
         lib = _lib.load()
-        check(lib.sdt_convsk_set_reserved_slots(reserve))  # "supported" depends on the grid (K steps per chunk)
+        check(lib.sdt_convsk_set_reserved_slots(reserve))  # "supported" depends on the grid (K steps per chunk) and on the tile rule
         check(lib.sdt_convsk_set_wg_per_cu(wpc))
+        check(lib.sdt_convsk_set_f32_split(1 if split else 0))
+        check(lib.sdt_convsk_set_dw_wide_tiles(1 if wide else 0))
         try:
             ok = lib.sdt_convsk_dw_supported_t(g, dtype)
+            plan = _SKDwPlan(g, dev, dtype, reserve, wpc, split) if ok else None  # (_SKDwPlan sets and resets the same knobs; the tile rule stays set)
         finally:
             check(lib.sdt_convsk_set_reserved_slots(0))
             check(lib.sdt_convsk_set_wg_per_cu(2))
-        plan = _SKDwPlan(g, dev, dtype, reserve, wpc, split) if ok else None
+            check(lib.sdt_convsk_set_f32_split(0))
+            check(lib.sdt_convsk_set_dw_wide_tiles(0))
         _SK_DW_PLANS[key] = plan
     return plan
 

@@ -778,10 +778,26 @@ SK_DW = [("128x128 tile", 8, 20, 106, 128, 256, 3, 1, 1), ("128x64 tile", 4, 40,
          ("64x64 tile", 4, 40, 213, 64, 64, 3, 1, 1), ("128x64 tile, Cout 192", 4, 20, 106, 64, 192, 3, 1, 1), ("64x128 tile, ragged rows", 5, 33, 77, 192, 64, 3, 1, 1)]
 
 
+# tile (rows x columns) the split-fp32 weight gradient takes for each case under the ragged-tile rule (ops.SK_DW_WIDE; csrc/convsk.hip dw_tile): the
+# 576-column cases get five 128-wide tiles with a ragged last one
+SK_DW_WIDE_TILE = {"128x128 tile": (128, 128), "128x64 tile": (128, 128), "64x128 tile": (64, 128), "64x64 tile": (64, 128),
+                   "128x64 tile, Cout 192": (64, 128), "64x128 tile, ragged rows": (64, 128)}
+
+
+@pytest.mark.parametrize("wide", [True, False], ids=["wide-tiles", "r5-tiles"])
 @pytest.mark.parametrize("case", SK_DW, ids=lambda c: c[0])
-def test_streamk_weight_gradient_tile_shapes(ops, case):
+def test_streamk_weight_gradient_tile_shapes(ops, case, wide):
     """sdt_convsk_dw_f32 (ordered (tile, K-chunk) units + fixed-order slab reduce) on every tile shape it instantiates: the launch takes
-    that kernel (sdt_convsk_dw_supported), equals the float64 weight gradient, repeats bit-identically and accumulates."""
+    that kernel (sdt_convsk_dw_supported), equals the float64 weight gradient, repeats bit-identically and accumulates.  Round 6: both tile rules of
+    the split-fp32 kernel (the case names are the rule of rounds 3-5)."""
+    prev, ops.SK_DW_WIDE = ops.SK_DW_WIDE, wide
+    try:
+        _dw_tile_case(ops, case, wide)
+    finally:
+        ops.SK_DW_WIDE = prev
+
+
+def _dw_tile_case(ops, case, wide):
     from speechdrivestemplates_amd import _lib
     tag, B, Hi, Wi, Cin, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(map(ord, tag)))
@@ -795,6 +811,11 @@ def test_streamk_weight_gradient_tile_shapes(ops, case):
     wd = torch.nn.Parameter(ops.to_weight_layout(w.float()).to(DEV))
     geom = ops.conv_geom_for(xd.shape, wd, s, p)
     assert ops.USE_STREAMK_DW and _lib.load().sdt_convsk_dw_supported(geom), "this case must run on the stream-K weight-gradient kernel"
+    if ops.F32_SPLIT:
+        plan = ops._sk_dw_plan(geom, xd.device)
+        assert plan is not None and (plan.host[3] >> 26) & 1
+        want = SK_DW_WIDE_TILE[tag] if wide else tuple(int(v) for v in tag.split(" ")[0].split("x"))
+        assert (plan.host[1], plan.host[2]) == want, (tag, wide, plan.host[1], plan.host[2], want)
     runs = []
     for _ in range(2):
         wd.grad = None

@@ -53,12 +53,14 @@ def main():
     ap.add_argument("--old", action="store_true", help="the round-4 128-row bf16 kernels (ops.BF16_SHAPED = False) instead of the bf16-shaped ones")
     ap.add_argument("--w3", type=int, default=1, help="--dtype f32 split: 1 = weights pre-split into three bf16 planes once (ops.W3_PRESPLIT; the weights are registered "
                                                      "with a WeightMirrors group as an optimiser would), 0 = split by every tile's loader")
+    ap.add_argument("--dw-wide", type=int, default=0, help="--dtype f32 split: tile rule of the weight gradient (ops.SK_DW_WIDE)")
     ap.add_argument("--korder", type=int, default=None, help="K order of the 8-wave kernels' tiles: 0 tap-major, 1 chunk-major (ops.SK_K_ORDER)")
     a = ap.parse_args()
     if a.korder is not None:
         ops.SK_K_ORDER = a.korder
     B, dev = a.batch, "cuda"
     ops.W3_PRESPLIT = bool(a.w3)
+    ops.SK_DW_WIDE = bool(a.dw_wide)
     keep = []
     ops.BF16_SHAPED = not a.old
     ops.F32_SPLIT = bool(a.split)
