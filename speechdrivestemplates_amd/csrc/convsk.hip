@@ -1764,7 +1764,13 @@ static void dw_tile(const sdt_conv_geom& g, int esz, int& bm, int& bn) {
     const int N = g.ntaps * g.Cin;
     bm = g.Cout % 128 == 0 ? 128 : 64;
     bn = N % 128 == 0 ? 128 : 64;
-    if (esz == 4 && g_sk_split && g_sk_wpc == 2 && g_dw_wide && N >= 128) bn = 128;
+    if (esz == 4 && g_sk_split && g_sk_wpc == 2 && g_dw_wide && N >= 128 && bn == 64) {
+        // ... unless the fewer, wider tiles would leave the K loop (32 rows per step) too short for its G / T chunks of >= 8 steps (dw_supported):
+        // the wide rule never takes a launch away from this kernel
+        const int64_t K = cdiv64((int64_t)g.B * g.Ho * g.Wo, 32), T = (int64_t)(g.Cout / bm) * cdiv64(N, 128);
+        const int G = sk_grid(g_sk_wpc);
+        if (T <= G && K >= 8 * (G / T)) bn = 128;
+    }
 }
 static int dw_supported(const sdt_conv_geom* g, int esz) {
     if (!g || (esz != 4 && esz != 2)) return 0;

@@ -778,10 +778,18 @@ SK_DW = [("128x128 tile", 8, 20, 106, 128, 256, 3, 1, 1), ("128x64 tile", 4, 40,
          ("64x64 tile", 4, 40, 213, 64, 64, 3, 1, 1), ("128x64 tile, Cout 192", 4, 20, 106, 64, 192, 3, 1, 1), ("64x128 tile, ragged rows", 5, 33, 77, 192, 64, 3, 1, 1)]
 
 
-# tile (rows x columns) the split-fp32 weight gradient takes for each case under the ragged-tile rule (ops.SK_DW_WIDE; csrc/convsk.hip dw_tile): the
-# 576-column cases get five 128-wide tiles with a ragged last one
-SK_DW_WIDE_TILE = {"128x128 tile": (128, 128), "128x64 tile": (128, 128), "64x128 tile": (64, 128), "64x64 tile": (64, 128),
-                   "128x64 tile, Cout 192": (64, 128), "64x128 tile, ragged rows": (64, 128)}
+def _dw_tile_rule(case, wide, grid=512):
+    """csrc/convsk.hip dw_tile restated: rows by the divisibility of Cout, columns by that of taps * Cin; the ragged-tile rule (ops.SK_DW_WIDE) widens
+    64-column tiles to 128 (the 576-column cases: five tiles with a ragged last one) unless that leaves the K loop fewer than 8 steps per chunk."""
+    _tag, B, Hi, Wi, Cin, Cout, k, s, p = case
+    Ho, Wo = (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1
+    N, K = k * k * Cin, -(-(B * Ho * Wo) // 32)
+    bm, bn = (128 if Cout % 128 == 0 else 64), (128 if N % 128 == 0 else 64)
+    if wide and bn == 64 and N >= 128:
+        T = (Cout // bm) * -(-N // 128)
+        if T <= grid and K >= 8 * (grid // T):
+            bn = 128
+    return bm, bn
 
 
 @pytest.mark.parametrize("wide", [True, False], ids=["wide-tiles", "r5-tiles"])
@@ -814,7 +822,7 @@ def _dw_tile_case(ops, case, wide):
     if ops.F32_SPLIT:
         plan = ops._sk_dw_plan(geom, xd.device)
         assert plan is not None and (plan.host[3] >> 26) & 1
-        want = SK_DW_WIDE_TILE[tag] if wide else tuple(int(v) for v in tag.split(" ")[0].split("x"))
+        want = _dw_tile_rule(case, wide)
         assert (plan.host[1], plan.host[2]) == want, (tag, wide, plan.host[1], plan.host[2], want)
     runs = []
     for _ in range(2):
