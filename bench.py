@@ -564,6 +564,64 @@ def main(argv=None):
                         "neither -- LDS feeding and the per-tile epilogue of a persistent fp32-shaped tile (DESIGN.md section 2)" % BF16_MATRIX_PEAK_TFLOPS}
         return out.get("alt_conv_math")
 
+    def pcie_leg():
+        """informational, OUTSIDE the timed region and never `value`: the reference's boundary hands over HOST tensors (voice2pose.py:86-90 moves
+        the DataLoader's collated batch with .cuda()).  The same fp32 step fed from pinned host memory: (a) `prefetched` -- the next batch's copies
+        are issued on a copy stream while the current step runs (DataLoader(pin_memory=True) + non_blocking copies); (b) `serial` -- the copies sit
+        on the step's own stream in front of it.  One rank only: a measurement of the host link of this box, not of the job."""
+        try:
+            keys = ("audio", "poses", "clip_index")
+            host = [{k: (b[k].cpu().pin_memory() if k in keys else b[k]) for k in b} for b in batches]
+            for hb in host:
+                hb["speaker_stat"] = {k: v.cpu().pin_memory() for k, v in hb["speaker_stat"].items()}
+            nbytes = sum(host[0][k].numel() * host[0][k].element_size() for k in keys) + sum(v.numel() * v.element_size() for v in host[0]["speaker_stat"].values())
+            copy_stream = torch.cuda.Stream(device=dev)
+
+            def to_dev(hb):
+                d = {k: (hb[k].to(dev, non_blocking=True) if k in keys else hb[k]) for k in hb}
+                d["speaker_stat"] = {k: v.to(dev, non_blocking=True) for k, v in hb["speaker_stat"].items()}
+                return d
+
+            def run(prefetch, n):
+                cur_stream = torch.cuda.current_stream(dev)
+                nxt = None
+                if prefetch:
+                    with torch.cuda.stream(copy_stream):
+                        nxt = to_dev(host[0])
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                sync()
+                t0p = time.perf_counter()
+                for i in range(n):
+                    if prefetch:
+                        cur_stream.wait_event(ev)
+                        b = nxt
+                        for t in list(b[k] for k in keys) + list(b["speaker_stat"].values()):
+                            t.record_stream(cur_stream)
+                        with torch.cuda.stream(copy_stream):
+                            nxt = to_dev(host[(i + 1) % len(host)])
+                            ev = torch.cuda.Event()
+                            ev.record(copy_stream)
+                    else:
+                        b = to_dev(host[i % len(host)])
+                    lo, _ = pipe.forward_backward(b)
+                    pipe.optimizer_updates(lo)
+                sync()
+                return (time.perf_counter() - t0p) * 1e3 / n
+
+            run(True, 3)
+            n = 20
+            ms_pref, ms_ser = run(True, n), run(False, n)
+            return {"unit": "clips/s", "steps": n, "mb_per_batch": nbytes / 1e6,
+                    "prefetched": {"value": B / (ms_pref * 1e-3), "ms_per_step": ms_pref}, "serial": {"value": B / (ms_ser * 1e-3), "ms_per_step": ms_ser},
+                    "note": "the timed step fed from PINNED HOST batches (the reference's boundary: collated CPU tensors moved with .cuda()); prefetched = "
+                            "next batch copied on a copy stream under the current step, serial = copies in front of the step on its own stream; never `value`"}
+        except Exception as e:  # informational: must not take the bench line with it
+            return {"error": repr(e)[:300]}
+
+    pcie = None
+    if not stub and on_gpu and world == 1 and not forced_dp and not args.graph and not args.no_alt_mode and args.storage == "f32" and args.conv_math == "f32":
+        pcie = pcie_leg()
     dp_graph = None
     if not stub and on_gpu and (world > 1 or forced_dp) and not args.graph and args.config == "voice2pose_sdt_bp" and not args.no_alt_mode:
         dp_graph = graph_leg_f32()  # every rank (collectives inside)
@@ -707,6 +765,8 @@ def main(argv=None):
             if "value" in dp_graph:
                 dp_graph["vs_default"] = dp_graph["value"] / out["value_uninstrumented"]
             out["dp_graph_replay"] = dp_graph
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if alt is not None:
             if "value" in alt:
                 alt["vs_default"] = alt["value"] / out["value_uninstrumented"]

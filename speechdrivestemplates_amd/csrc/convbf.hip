@@ -33,7 +33,8 @@
 #define BF_B_AUX 0
 #endif
 // BF_ABL (tools/debug/r05_bf2_ablation.sh; ablation builds compute WRONG results by design): 1 no global loads in the K loop, 2 no LDS stores,
-// 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads, 32 no epilogue stores
+// 4 no MFMAs, 8 no barrier in the K loop, 16 no fragment reads, 32 no epilogue stores, 64 requests never waited for, 128 / 256 A operand on every
+// other step / never (split form)
 #ifndef BF_ABL
 #define BF_ABL 0
 #endif
@@ -710,8 +711,11 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
             // ---- region 1
 #pragma unroll
             for (int i = 0; i < NR; ++i) x3_rd(1, pa, pb, fk1, i);
+            // BF_ABL 128 / 256 (wrong results): the A operand is requested, split and stored on every other step only / never -- the ceiling of a
+            // loader that fetches an im2col row once per (dy, channel chunk) instead of once per tap (sliding window, kw = 2 / kw -> infinity)
+            constexpr bool skipA = !W3 && (((BF_ABL & 128) && cur == 1) || (BF_ABL & 256));
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
+            for (int j = skipA ? RA : 0; j < NL; ++j) {
                 stage_op(SETN, nx, j);
                 load_op(SETN, j);
             }
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(BF_NT, 2) void convbf2_kernel(const ET* __restrict_
                 const int J = q / (6 * NM), pr = (q % (6 * NM)) / NM, t = q % NM;
                 BF_MFMA(acc[t / TN][t % TN], xa[J][PA[pr]][t / TN], xb[J][PB[pr]][t % TN]);
             }
-            x3_pattern<0, BAR, NR, W3 ? RA : NL, W3 ? RBL : 0>();
+            x3_pattern<0, BAR, NR, W3 ? RA : (skipA ? RB : NL), W3 ? RBL : 0>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of LDS[cur] and my stores to LDS[next] are done
 #ifdef SDT_TUNING
