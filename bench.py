@@ -239,6 +239,8 @@ def main(argv=None):
     ap.add_argument("--atomic-dw", action="store_true",
                     help="weight gradients with fp32 atomics (the round-2 default) instead of the ordered, bit-reproducible reductions")
     ap.add_argument("--bwd-wpc", default=None, help="experiment: persistent workgroups per CU of the backward stream-K plans, 'DX,DW' (e.g. 1,1 or 2,1)")
+    ap.add_argument("--dp-legs", action="store_true", help="N > 1: also run the informational legs behind the timed region (graph replay of the data-parallel step, bf16 storage) -- "
+                                                           "they issue collectives on every rank; off by default between real ranks so that nothing behind the timed region can take the scaling number with it")
     ap.add_argument("--dp-graph-full", action="store_true", help="N > 1: the informational graph-replay legs capture the RCCL all-reduces WITH the step (graph.GraphedStep "
                     "mode 'full', the product default under SYS.HIP_GRAPH; exercised here on a 1-rank group only) instead of graph segments around an eager exchange ('split')")
     ap.add_argument("--no-f32-split", action="store_true", help="Conv2d forward / input gradient on the fp32-MFMA kernels of rounds 3-4 (A/B of the split-fp32 kernel)")
@@ -623,10 +625,11 @@ def main(argv=None):
     if not stub and on_gpu and world == 1 and not forced_dp and not args.graph and not args.no_alt_mode and args.storage == "f32" and args.conv_math == "f32":
         pcie = pcie_leg()
     dp_graph = None
-    if not stub and on_gpu and (world > 1 or forced_dp) and not args.graph and args.config == "voice2pose_sdt_bp" and not args.no_alt_mode:
+    legs_ok = world == 1 or args.dp_legs  # (a forced 1-rank group keeps them: that is where they are tested)
+    if not stub and on_gpu and (world > 1 or forced_dp) and legs_ok and not args.graph and args.config == "voice2pose_sdt_bp" and not args.no_alt_mode:
         dp_graph = graph_leg_f32()  # every rank (collectives inside)
     alt = None
-    if not stub and not args.no_alt_mode and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
+    if not stub and not args.no_alt_mode and legs_ok and args.conv_math == "f32" and args.storage == "f32" and not args.graph and on_gpu \
             and args.config == "voice2pose_sdt_bp":
         try:
             alt = bf16_leg()  # every rank (collectives inside)
