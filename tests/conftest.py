@@ -30,6 +30,8 @@ _TIERS = (
     # 8: anything that spawns ranks; 9: two PROCESSES sharing the one GPU of a test box (stands in for DDP; not a production layout)
     (9, "test_dp_gpu.py::test_two_ranks"), (9, "test_dp_gpu.py::test_differently_seeded"), (9, "test_dp_gpu.py::test_a_lost_partner"), (9, "test_dp_gpu.py::test_reference_unsynchronised"),
     (8, "test_dp_gpu.py"), (8, "test_dp_gloo.py"), (8, "test_bench_flow.py"),
+    # 10: the fault-injection tests on the -DSDT_TUNING library, in a child process (last: under -x nothing hides behind it)
+    (10, "test_tuning_subprocess_gpu.py"),
 )
 
 

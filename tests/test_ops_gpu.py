@@ -1166,12 +1166,19 @@ def test_streamk_lost_partner_is_loud(ops, variant):
 
     tol = 2e-2 if bf16 else 3e-6  # (bf16: the OUTPUT is stored as bf16)
     _lib.check(lib.sdt_convsk_set_spin_limit(20000))
-    _lib.check(lib.sdt_debug_convsk_mute_range(100 if bf16 else 200))
     try:
-        y, ref = launch()
+        # which ranges are partners (not owners) of a split tile depends on the plan -- tile shape, workgroups, reserve: whatever ran before in this
+        # process -- so a few candidates are tried: muting a range that owns every tile it touches changes nothing (and must change nothing)
+        bad = None
+        for cand in ([100, 101, 102, 103, 57, 58, 59] if bf16 else [200, 201, 202, 203, 57, 58, 59]):
+            _lib.check(lib.sdt_debug_convsk_mute_range(cand))
+            y, ref = launch()
+            bad = torch.isnan(y)
+            if bad.any():
+                break
+            assert ops.streamk_error_codes() == {}, ("a muted OWNER range cannot lose anything", cand, ops.streamk_error_codes())
         codes = ops.streamk_error_codes()
-        bad = torch.isnan(y)
-        assert bad.any(), "the muted range was not part of a split tile: pick another range for this plan"
+        assert bad.any(), "none of the muted ranges was a partner of a split tile: pick other ranges for this plan"
         assert len(codes) == 1 and list(codes.values())[0] > 0, ("NaN tile with a clean error word", codes)  # NaN => word set
         assert bad.sum().item() <= 256 * 256, "exactly one tile is poisoned"
         ok = ~bad.cpu()
