@@ -278,6 +278,11 @@ def main(argv=None):
     if world > 1 or forced_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            # RCCL runs one long-lived workgroup per channel; the backward stream-K plans leave dp.reserved_slots() workgroup slots free for them
+            # (32, or this variable when the launcher sets it).  Unset, RCCL picks its own channel count for the topology -- possibly more than the
+            # reserve, and the persistent kernels would then wait for slots held by a collective that waits for a slower rank.  Cap it to the reserve.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if on_gpu:
             torch.cuda.set_device(local_rank)
         if backend == "nccl":

@@ -194,6 +194,11 @@ class GradReducer:
                           "first): the runtime keeps its default of 4 hardware queues and the weight-gradient side stream will share a queue with the "
                           "main stream (~8 % of a data-parallel step).  Export GPU_MAX_HW_QUEUES=8 in the launcher or import this package first.",
                           RuntimeWarning, stacklevel=3)
+        if self.ws > 1 and dist.get_backend() == "nccl" and not (os.environ.get("NCCL_MAX_NCHANNELS") or os.environ.get("NCCL_MIN_NCHANNELS")):
+            warnings.warn("NCCL_MAX_NCHANNELS is not set: RCCL picks its own channel count (one long-lived workgroup per channel) while the backward "
+                          "stream-K plans leave %d workgroup slots free for it; with more channels than that, persistent conv launches wait for slots a "
+                          "collective holds.  Export NCCL_MAX_NCHANNELS=%d before init_process_group (bench.py does), or set dp.RESERVED_SLOTS to "
+                          "RCCL's channel count." % (reserved_slots(), reserved_slots()), RuntimeWarning, stacklevel=3)
         others = other_gpu_processes()
         if others and self.ws == 1:  # (with world > 1 the other ranks of this node are expected to show up here, one per GPU)
             warnings.warn("%d other process(es) hold a compute context on this node's GPUs (kfd pids %s): the persistent conv kernels plan for a GPU of "
