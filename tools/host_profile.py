@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""cProfile of the host side of the train step (where do the ~6 ms of Python per step go?).  python tools/host_profile.py"""
+"""cProfile of the host side of the train step (where do the ~6 ms of Python per step go?).  python tools/host_profile.py [config]"""
 import cProfile
 import os
 import pstats
@@ -11,7 +11,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from __graft_entry__ import make_pipeline  # noqa: E402
 
-pipe, cfg = make_pipeline("voice2pose_sdt_bp", bench.N_CLIPS, batch_global=32)
+CFG = sys.argv[1] if len(sys.argv) > 1 else "voice2pose_sdt_bp"
+pipe, cfg = make_pipeline(CFG, bench.N_CLIPS, batch_global=32)
 batches = bench.stage_batches(4, 32, 0, torch.device("cuda", 0))
 
 
