@@ -362,6 +362,32 @@ def test_deferred_weight_gradients_cover_every_layer():
     check("deferred vs inline weight gradients", grads[1], grads[0], 2e-5)
 
 
+@pytest.mark.parametrize("B", [3, 33])
+def test_ragged_batches_match_the_oracle(B):
+    """Edge batches through the WHOLE train step (the plans are tuned for 32 clips; the fixtures hold 2 and 4): 3 clips = ragged tiles in every launch,
+    33 = one clip more than a full batch.  Step-0 losses and float64 metrics against the CPU oracle, prediction to the forward tolerance; a batch
+    of ONE clip raises where the reference's unbiased variance over one code turns the loss into NaN (voice2pose.py:152-155)."""
+    from speechdrivestemplates_amd import ops
+    n_clips = 40
+    pipe, cfg = _make_pipeline("voice2pose_sdt_bp", n_clips, 0.5)
+    ocfg = O.cfg_named("voice2pose_sdt_bp")
+    state = O.make_voice2pose_state(ocfg, n_clips, seed=0, code_std=0.5)
+    eng = O.OracleVoice2Pose(ocfg, state)
+    batch = O.make_batch(B, n_clips, step=0, seed=5)
+    losses, results = pipe.forward_backward(batch)
+    pipe.optimizer_updates(losses)
+    ref_losses, ref_results = eng.train_step(batch)
+    torch.cuda.synchronize()
+    for k in ("G_reg_loss", "G_clipcode_kl_loss", "G_loss", "L2_dist", "lip_sync_error_n"):
+        a, b = float(losses[k].detach()), float(ref_losses[k])
+        assert abs(a - b) <= 2e-6 * abs(b) + 1e-7, (B, k, a, b)
+    check("ragged batch B=%d prediction vs oracle" % B, results["poses_pred_normalized"], ref_results["poses_pred_batch"], 2e-4)
+    assert ops.streamk_error_codes() == {}
+    if B == 3:
+        with pytest.raises(RuntimeError, match="at least 2 clips"):
+            pipe.forward_backward(O.make_batch(1, n_clips, step=1, seed=5))
+
+
 @pytest.mark.parametrize("name,code_std,tol", [("voice2pose_sdt_vae", 0.0, 2e-5), ("voice2pose_sdt_bp", 0.5, 1e-3)])
 def test_overlapped_gradient_exchange_single_rank(name, code_std, tol):
     """The bucketed, backward-overlapped all-reduce path (dp.GradReducer + the post-encoder hook) exercised over RCCL with
